@@ -1,0 +1,102 @@
+/*
+ * qqq_amd.h -- C-ABI of the MI355X-native (gfx950) W4A8 GEMM behind QQQ's `qqq_gemm` operator.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no torch types.  Every entry point
+ * cites the reference interface (HandH1998/QQQ, /root/reference) it replaces.  The reference-side
+ * binding a QQQ / vLLM maintainer would add is shown in INTEGRATION.md.
+ *
+ * All device pointers must be resident on device `dev`; every call only ENQUEUES work on
+ * `stream` (a hipStream_t passed as void*; NULL = the legacy default stream) and returns without
+ * synchronising -- the same contract as the reference (csrc/qqq_gemm.cu:1089).
+ * The library allocates nothing, keeps no state between calls and frees nothing
+ * (reference ownership rules: qlinear_marlin.py:97-133).
+ */
+#ifndef QQQ_AMD_H_
+#define QQQ_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QQQ_AMD_ABI_VERSION 1
+
+/* return codes; 0/1/2 are the reference's (csrc/qqq_gemm.cu:947-948, :1002-1003) */
+#define QQQ_OK 0
+#define QQQ_ERR_PROB_SHAPE 1 /* (m,n,k) not compatible with thread_k/thread_n / group size  */
+#define QQQ_ERR_KERN_SHAPE 2 /* no kernel for thread_k/thread_n/groupsize                    */
+#define QQQ_ERR_HIP 16       /* a HIP runtime call failed; see qqq_amd_last_error()          */
+#define QQQ_ERR_ARG 17       /* NULL / misaligned pointer or scratch too small               */
+
+/*
+ * Replaces `int qqq_cuda(...)` (csrc/qqq_gemm.cu:950-969), argument for argument:
+ *   A   int8  [m,k] row-major                                (qlinear_marlin.py:32)
+ *   B   int32 [k/16, n*16/8] Marlin/QQQ packed int4 weights  (qlinear_marlin.py:33, pack() :181-262)
+ *   C   int32 [max_par*64, n] scratch ("reduce buffer")      (qlinear_marlin.py:34) -- used for split-K
+ *       partial sums; contents on return are unspecified, as in the reference
+ *   D   fp16  [m,n] row-major output                          (qlinear_marlin.py:35)
+ *   s1  f32   [m,1] per-token activation scales               (qlinear_marlin.py:36)
+ *   s2  f32   [1,n] per-channel weight scales, stored order   (qlinear_marlin.py:37)
+ *   s3  f16   [k/groupsize, n] per-group scales, stored order; ignored when groupsize == -1 (:38)
+ *   workspace int32, >= n/128*max_par entries, all zero on entry, all zero on return (:39, .cu:1068)
+ *   groupsize -1 (per-channel) or 128                        (csrc/qqq_gemm.cu:1065, :990)
+ *   thread_k, thread_n, sms, max_par: reference tuning knobs (qqq_gemm.h:32-35).  thread_k/thread_n
+ *       are validated exactly like the reference (is_valid_config, .cu:867-897; CALL_IF table
+ *       :935-945) so the same calls fail with the same code, but they do not select CDNA4 tiles;
+ *       sms is ignored; max_par bounds the rows of C that may be used (max_par*64).
+ * D[i,j] = fp16_rn( (f32_rn(sum_k A[i,k]*Wq[k,j]) * s2[j]) * s1[i] ), Wq as the reference kernel
+ * forms it (csrc/qqq_gemm.cu:146-151, :167-210, :695-700).  int32 accumulators are bit-exact.
+ */
+int qqq_w4a8_gemm(const void* A, const void* B, void* C, void* D, const void* s1, const void* s2,
+                  const void* s3, int prob_m, int prob_n, int prob_k, void* workspace, int groupsize,
+                  int dev, void* stream, int thread_k, int thread_n, int sms, int max_par);
+
+/* Tuning / test hooks for the same operation.  All fields 0 => automatic (== qqq_w4a8_gemm). */
+typedef struct qqq_tune {
+  int kernel;  /* 0 auto, 1 = "stream" (weights straight to VGPRs, 16x16x64 MFMA, small m),
+                  2 = "tiled" (LDS-staged 32x32x32 MFMA tiles, large m)                       */
+  int ksplit;  /* 0 auto, else number of K slices (partials go through C)                   */
+  int waves;   /* stream: waves per workgroup (4, 8 or 16); 0 auto                           */
+  int fused;   /* stream split-K: 1 = last-arriving workgroup reduces in-launch (tickets in
+                  workspace), 2 = separate reduce launch; 0 auto                             */
+  int bm;      /* tiled: rows per workgroup tile (64, 128, 256); 0 auto                      */
+  int glds;    /* tiled: 1 = direct global->LDS loads, 2 = register staged; 0 auto          */
+  int reserved[6];
+} qqq_tune_t;
+
+/* As qqq_w4a8_gemm; `tune` may be NULL; if `acc_out` != NULL the raw int32 accumulators
+ * ([m,n] row-major; x16 convention in per-channel mode) are also written there. */
+int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, const void* s1, const void* s2,
+                     const void* s3, int prob_m, int prob_n, int prob_k, void* workspace,
+                     int groupsize, int dev, void* stream, int thread_k, int thread_n, int sms,
+                     int max_par, const qqq_tune_t* tune, int32_t* acc_out);
+
+/*
+ * Fused per-token dynamic int8 quantisation; replaces the ~8 torch launches of
+ * QuantLinear.dynamic_quant (qlinear_marlin.py:265-268):
+ *   s1[i]  = f32( f16_rn( max_k|x[i,k]| * (1.0f/127.0f) ) )     (torch-GPU lowering of .div(127.0))
+ *   xq[i,k]= int8( clamp( rint( f32(x[i,k]) / s1[i] ), -128, 127 ) )
+ * x fp16 [m,k] row-major, xq int8 [m,k], s1 f32 [m].  k must be a multiple of 8.
+ */
+int qqq_dynamic_quant(const void* x, void* xq, void* s1, int m, int k, int dev, void* stream);
+
+/* out[i,j] += bias[j] in fp16 (the reference's `D + self.bias`, qlinear_marlin.py:287). */
+int qqq_add_bias(void* D, const void* bias, int m, int n, int dev, void* stream);
+
+int qqq_amd_abi_version(void);
+const char* qqq_amd_last_error(void);
+
+/* Hardware self-tests used by tests/test_gpu_probe.py: run one MFMA / one LDS-DMA copy on raw
+ * per-lane operands so the lane<->element maps the kernels rely on are checked on the device.
+ * kind 16: v_mfma_i32_16x16x64_i8 (a,b: 64 lanes x 16 B; out: 64 x 4 int32)
+ * kind 32: v_mfma_i32_32x32x32_i8 (a,b: 64 lanes x 16 B; out: 64 x 16 int32) */
+int qqq_probe_mfma(int kind, const void* a, const void* b, void* out, int dev, void* stream);
+/* copies 64 x 16 B through LDS with global_load_lds; lane l reads src chunk perm[l] */
+int qqq_probe_glds(const void* src, const void* perm, void* dst, int dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QQQ_AMD_H_ */

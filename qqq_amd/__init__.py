@@ -1,0 +1,19 @@
+"""qqq_amd -- MI355X-native (gfx950) W4A8 GEMM behind QQQ's `qqq_gemm` operator.
+
+Public surface (mirrors the reference's hot path, HandH1998/QQQ):
+    qqq_gemm(A, B, C, D, s1, s2, s3, workspace, thread_k, thread_n, sms, max_par)   # QQQ._CUDA.qqq_gemm
+    mul(...)                                                                       # qlinear_marlin.mul
+    QuantLinear                                                                    # qlinear_marlin.QuantLinear
+    marlin_qqq_gemm(...)                                                           # vLLM-style wrapper
+    dynamic_quant(x)                                                               # fused per-token int8 quant
+"""
+from .ops import (  # noqa: F401
+    dynamic_quant,
+    marlin_qqq_gemm,
+    mul,
+    qqq_gemm,
+    qqq_gemm_ex,
+)
+from .qlinear import QuantLinear  # noqa: F401
+
+__all__ = ["qqq_gemm", "qqq_gemm_ex", "mul", "marlin_qqq_gemm", "dynamic_quant", "QuantLinear"]

@@ -1,0 +1,59 @@
+"""ctypes binding of the C-ABI in include/qqq_amd.h.  No fallback: if the HIP library is missing or
+does not load, every entry point raises -- the product path never routes through a CPU implementation."""
+from __future__ import annotations
+
+import ctypes
+import os
+
+from . import build as _build
+
+_lib = None
+
+
+class QQQTune(ctypes.Structure):
+    _fields_ = [
+        ("kernel", ctypes.c_int), ("ksplit", ctypes.c_int), ("waves", ctypes.c_int),
+        ("fused", ctypes.c_int), ("bm", ctypes.c_int), ("glds", ctypes.c_int),
+        ("reserved", ctypes.c_int * 6),
+    ]
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    # torch first: it brings the HIP runtime (SONAME libamdhip64.so.7) into the process, and our
+    # library's NEEDED entry then binds to that same runtime (one HIP runtime per process).
+    import torch  # noqa: F401
+
+    path = _build.LIB
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} is missing: the gfx950 HIP kernels are not built. Run `python -c 'import "
+            "__graft_entry__ as g; g.build()'` (needs hipcc). There is no CPU fallback."
+        )
+    L = ctypes.CDLL(path)
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    gemm_args = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp, ci, ci, vp, ci, ci, ci, ci]
+    L.qqq_w4a8_gemm.argtypes = gemm_args
+    L.qqq_w4a8_gemm.restype = ci
+    L.qqq_w4a8_gemm_ex.argtypes = gemm_args + [ctypes.POINTER(QQQTune), vp]
+    L.qqq_w4a8_gemm_ex.restype = ci
+    L.qqq_dynamic_quant.argtypes = [vp, vp, vp, ci, ci, ci, vp]
+    L.qqq_dynamic_quant.restype = ci
+    L.qqq_add_bias.argtypes = [vp, vp, ci, ci, ci, vp]
+    L.qqq_add_bias.restype = ci
+    L.qqq_probe_mfma.argtypes = [ci, vp, vp, vp, ci, vp]
+    L.qqq_probe_mfma.restype = ci
+    L.qqq_probe_glds.argtypes = [vp, vp, vp, ci, vp]
+    L.qqq_probe_glds.restype = ci
+    L.qqq_amd_abi_version.restype = ci
+    L.qqq_amd_last_error.restype = ctypes.c_char_p
+    if L.qqq_amd_abi_version() != 1:
+        raise RuntimeError("libqqq_amd.so ABI version mismatch; rebuild")
+    _lib = L
+    return L
+
+
+def last_error() -> str:
+    return lib().qqq_amd_last_error().decode()

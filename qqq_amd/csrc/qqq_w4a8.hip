@@ -1,0 +1,1078 @@
+// qqq_w4a8.hip -- MI355X (gfx950 / CDNA4) W4A8 GEMM kernels behind QQQ's `qqq_gemm` operator.
+//
+// Not a port of the reference CUDA kernel (csrc/qqq_gemm.cu): the only things shared with it are
+// the DATA contracts -- the Marlin/QQQ packed int4 layout produced by QuantLinear.pack()
+// (qlinear_marlin.py:147-262) and the arithmetic
+//     D[m,n] = fp16_rn( (f32_rn(sum_k A[m,k] * Wq[k,n]) * s2[n]) * s1[m] )
+// (csrc/qqq_gemm.cu:106-117, :146-151, :167-210, :695-700).  Everything else is designed for
+// wave64 / MFMA / LDS:
+//
+//  * Packed layout, closed form: word B[kt][128*ng + 4*(4*c + kq) + jt] holds, for k-tile kt
+//    (16 k) and 64-column group ng, the 4 consecutive k = 16*kt + 4*kq + r (r = 0..3) of the two
+//    columns n = 64*ng + 16*jt + c + 8*b (b = 0,1).  Hence for a fixed (kt, ng, c) the 64
+//    contiguous bytes [64*c, 64*c+64) of the 512-byte block are ALL 16 k of the 8 columns
+//    {16*jt + 8*b + c}.  One lane that loads those 64 bytes owns complete MFMA operands
+//    (16 int8 along k) for 8 columns: the unpack `q & 0xF0F0F0F0`, `(q << 4) & 0xF0F0F0F0`
+//    doubles as the register transpose, no cross-lane traffic, every bit used exactly once.
+//  * MFMA operand roles are swapped w.r.t. the textbook: the WEIGHTS are the MFMA "A" operand
+//    (tile row i <-> weight column n), the ACTIVATIONS the "B" operand (tile column j <-> token m),
+//    so that each lane ends up with 4 CONSECUTIVE n of one token: 8-byte fp16 stores, 16-byte
+//    int32 partial-sum stores.  The integer dot products do not care about the k order inside
+//    an operand as long as both operands use the same order ("k-slot freedom"), and the
+//    packed order [kq][r] IS natural k order, so the activation operand is 16 contiguous bytes.
+//  * "stream" kernel (m <= 64): HBM-bound.  v_mfma_i32_16x16x64_i8; a lane (i = 8*g + c, h)
+//    loads its 64 weight bytes of k-tile 4*s + h straight from HBM into VGPRs (no LDS: the
+//    weights are used once), a wave eats 128 columns x 64 k = 4 KiB per step, waves of a
+//    workgroup split K and reduce through LDS, workgroups split K through int32 slabs in the
+//    reduce buffer C (int32 addition is associative: bit-exact for every split).
+//  * "tiled" kernel (m > 64): MFMA-bound.  v_mfma_i32_32x32x32_i8; BMx256 tiles, BK = 128,
+//    activations and RAW packed weights staged in LDS (XOR-swizzled 16-byte chunks so that every
+//    ds_read_b128 is bank-conflict free), 2-stage software pipeline, XCD-aware tile order.
+//
+// The accumulators are the reference's: per-channel weights enter as 16*w4 (high nibble of each
+// byte) and pack() has pre-divided s_channel by 16; per-group weights are re-quantised to int8
+// with ONE packed-fp16 FMA exactly like dequant_per_group (csrc/qqq_gemm.cu:167-210).
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/qqq_amd.h"
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+#define QQQ_NIB_MASK 0xF0F0F0F0u
+
+// ------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------
+
+// stored position of logical column n's per-channel scale (inverse of _scale_perm_single,
+// qlinear_marlin.py:173-175):  n%32 = 2*i + 8*q + e  ->  32*(n/32) + 8*i + 2*q + e
+__device__ __forceinline__ int s2_stored_index(int n) {
+  const int w = n & 31;
+  return (n & ~31) + 8 * ((w & 7) >> 1) + 2 * (w >> 3) + (w & 1);
+}
+
+// One lane's 4 consecutive outputs (n % 4 == 0): the fused dequant epilogue
+// (csrc/qqq_gemm.cu:695-700): two separate fp32 RN multiplies, then RN to fp16.
+__device__ __forceinline__ void epilogue_store4(const int v0, const int v1, const int v2,
+                                                const int v3, const int m, const int n,
+                                                const int N, const float a_s,
+                                                const float* __restrict__ s2,
+                                                _Float16* __restrict__ D,
+                                                int32_t* __restrict__ acc_out) {
+  const int i0 = s2_stored_index(n);  // n%4==0: (n, n+1) -> (i0, i0+1); (n+2, n+3) -> (i0+8, i0+9)
+  const float2 sa = *reinterpret_cast<const float2*>(s2 + i0);
+  const float2 sb = *reinterpret_cast<const float2*>(s2 + i0 + 8);
+  h4 o;
+  o[0] = (_Float16)__fmul_rn(__fmul_rn((float)v0, sa.x), a_s);
+  o[1] = (_Float16)__fmul_rn(__fmul_rn((float)v1, sa.y), a_s);
+  o[2] = (_Float16)__fmul_rn(__fmul_rn((float)v2, sb.x), a_s);
+  o[3] = (_Float16)__fmul_rn(__fmul_rn((float)v3, sb.y), a_s);
+  *reinterpret_cast<h4*>(D + (size_t)m * N + n) = o;
+  if (acc_out) {
+    v4i a = {v0, v1, v2, v3};
+    *reinterpret_cast<v4i*>(acc_out + (size_t)m * N + n) = a;
+  }
+}
+
+// per-group int4 -> int8 re-quantisation of 4 weights (nibbles p0,p4,p1,p5 of q):
+// u -> fp16(u-8) exactly, ONE fp16 FMA (u-8)*s + 1152, low byte, ^0x80
+// (bit-identical to dequant_per_group, csrc/qqq_gemm.cu:167-210).
+__device__ __forceinline__ unsigned dequant_group4(const unsigned q, const h2 s) {
+  const unsigned t0 = (q & 0x000f000fu) | 0x64006400u;  // {1024+p0, 1024+p4}
+  const unsigned t1 = (q & 0x00f000f0u) | 0x64006400u;  // {1024+16*p1, 1024+16*p5}
+  const h2 c_sub = {(_Float16)-1032.0f, (_Float16)-1032.0f};
+  const h2 c_mul = {(_Float16)0.0625f, (_Float16)0.0625f};
+  const h2 c_add = {(_Float16)-72.0f, (_Float16)-72.0f};
+  const h2 c_mag = {(_Float16)1152.0f, (_Float16)1152.0f};
+  h2 a = __builtin_bit_cast(h2, t0) + c_sub;                                  // exact
+  h2 b = __builtin_elementwise_fma(__builtin_bit_cast(h2, t1), c_mul, c_add);  // exact
+  a = __builtin_elementwise_fma(a, s, c_mag);
+  b = __builtin_elementwise_fma(b, s, c_mag);
+  // bytes: [a.lo, a.hi, b.lo, b.hi] low bytes  (v_perm pool: src1 = bytes 0-3, src0 = bytes 4-7)
+  return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, b), __builtin_bit_cast(unsigned, a),
+                               0x06040200u) ^
+         0x80808080u;
+}
+
+template <bool GROUPED>
+__device__ __forceinline__ void unpack_pair(const unsigned q, const h2 s_b0, const h2 s_b1,
+                                            int& w_b0, int& w_b1) {
+  if constexpr (GROUPED) {
+    w_b0 = (int)dequant_group4(q, s_b0);
+    w_b1 = (int)dequant_group4(q >> 8, s_b1);
+  } else {
+    w_b0 = (int)(q & QQQ_NIB_MASK);         // odd nibbles  -> 16*w4 of column n      (b = 0)
+    w_b1 = (int)((q << 4) & QQQ_NIB_MASK);  // even nibbles -> 16*w4 of column n + 8  (b = 1)
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// "stream" kernel: small m, weights HBM -> VGPR -> MFMA 16x16x64
+// ------------------------------------------------------------------------------------------
+//
+// grid = (ceil(N/128) strips, ksplit, ceil(M / (16*MT)));  block = WAVES * 64.
+// MFMA A operand lane l = (i = l & 15, h = l >> 4): i = 8*g + c  <->  weight columns
+//     n = 128*strip + 64*g + 16*jt + 8*b + c   for the 8 MFMAs (jt, b) of a step,
+//     k = 64*s + 16*h + [0,16)   (k-tile 4*s + h).
+// MFMA B operand lane l = (j = l & 15, h): token m = mbase + 16*mt + j, same 16 k.
+// MFMA D: lane l holds column j = l & 15 (token) and rows i = 4*(l >> 4) + r, r = 0..3, i.e.
+//     g = l >> 5, c = 4*((l >> 4) & 1) + r  ->  4 consecutive n.
+
+template <int MT>
+struct StreamStep {
+  v4u w[4];   // w[kq][jt]
+  v4i x[MT];  // activation operands
+  h8 sc;      // per-group scales [2*jt + b]
+};
+
+template <int MT, bool GROUPED, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void qqq_stream_kernel(
+    const int8_t* __restrict__ A, const unsigned char* __restrict__ B, int32_t* __restrict__ C,
+    _Float16* __restrict__ D, const float* __restrict__ s1, const float* __restrict__ s2,
+    const _Float16* __restrict__ s3, int32_t* __restrict__ acc_out, int* __restrict__ tickets,
+    const int M, const int N, const int K, const int ksplit, const int fused) {
+  constexpr int NQ = MT * 8;  // MFMA output tiles per wave
+  __shared__ int red[NQ * 4 * 64 + 64];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int strip = blockIdx.x;
+  const int sp = blockIdx.y;
+  const int mbase = blockIdx.z * (16 * MT);
+
+  if constexpr (WAVES > 1) {
+    for (int i = tid; i < NQ * 4 * 64; i += WAVES * 64) red[i] = 0;
+    __syncthreads();
+  }
+
+  const int j = lane & 15;
+  const int h = lane >> 4;
+  const int g = j >> 3;
+  const int c = j & 7;
+  const int ngroups = N >> 6;
+  int ng = strip * 2 + g;
+  if (ng >= ngroups) ng = ngroups - 1;  // clamp (N % 128 == 64): loads stay legal, output dropped
+  const size_t rowbytes = (size_t)N * 8;
+  const unsigned char* bptr = B + (size_t)h * rowbytes + (size_t)ng * 512 + c * 64;
+
+  const int8_t* xptr[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    int row = mbase + 16 * mt + j;
+    if (row >= M) row = M - 1;
+    xptr[mt] = A + (size_t)row * K + 16 * h;
+  }
+  const _Float16* sptr = GROUPED ? (s3 + (size_t)ng * 64 + c * 8) : nullptr;
+
+  const int KS = K >> 6;  // 64-k steps
+  const int ks_begin = (int)(((long long)KS * sp) / ksplit);
+  const int ks_end = (int)(((long long)KS * (sp + 1)) / ksplit);
+
+  v4i acc[MT][4][2];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      acc[mt][jt][0] = (v4i){0, 0, 0, 0};
+      acc[mt][jt][1] = (v4i){0, 0, 0, 0};
+    }
+
+  auto load_step = [&](const int s, StreamStep<MT>& r) {
+    const unsigned char* p = bptr + (size_t)(4 * s) * rowbytes;
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) r.w[kq] = *reinterpret_cast<const v4u*>(p + 16 * kq);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) r.x[mt] = *reinterpret_cast<const v4i*>(xptr[mt] + 64 * s);
+    if constexpr (GROUPED) r.sc = *reinterpret_cast<const h8*>(sptr + (size_t)(s >> 1) * N);
+  };
+
+  auto compute_step = [&](const StreamStep<MT>& r) {
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      v4i a0, a1;
+      h2 sb0 = {(_Float16)0, (_Float16)0}, sb1 = sb0;
+      if constexpr (GROUPED) {
+        sb0 = (h2){r.sc[2 * jt], r.sc[2 * jt]};
+        sb1 = (h2){r.sc[2 * jt + 1], r.sc[2 * jt + 1]};
+      }
+#pragma unroll
+      for (int kq = 0; kq < 4; ++kq) {
+        int w0, w1;
+        unpack_pair<GROUPED>(r.w[kq][jt], sb0, sb1, w0, w1);
+        a0[kq] = w0;
+        a1[kq] = w1;
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        acc[mt][jt][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, r.x[mt], acc[mt][jt][0], 0, 0, 0);
+        acc[mt][jt][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, r.x[mt], acc[mt][jt][1], 0, 0, 0);
+      }
+    }
+  };
+
+  // software pipeline: PF steps in flight per wave (4 KiB of weights each)
+  constexpr int PF = (MT <= 2) ? 3 : 2;
+  StreamStep<MT> ring[PF];
+  const int s0 = ks_begin + wave;
+#pragma unroll
+  for (int p = 0; p < PF; ++p)
+    if (s0 + p * WAVES < ks_end) load_step(s0 + p * WAVES, ring[p]);
+  for (int s = s0; s < ks_end; s += PF * WAVES) {
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+      const int sc = s + p * WAVES;
+      if (sc < ks_end) {
+        compute_step(ring[p]);
+        const int sn = sc + PF * WAVES;
+        if (sn < ks_end) load_step(sn, ring[p]);
+      }
+    }
+  }
+
+  // ---- reduce the waves of this workgroup through LDS (int adds: order-independent) ----
+  if constexpr (WAVES > 1) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            __hip_atomic_fetch_add(&red[(((mt * 4 + jt) * 2 + b) * 4 + r) * 64 + lane],
+                                   acc[mt][jt][b][r], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+    __syncthreads();
+  } else {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            red[(((mt * 4 + jt) * 2 + b) * 4 + r) * 64 + lane] = acc[mt][jt][b][r];
+    __syncthreads();
+  }
+
+  // ---- write out: item = (q = (mt, jt, b), lane) -> 4 consecutive n of one token ----
+  auto item_coords = [&](const int it, int& m, int& n) {
+    const int q = it >> 6, ln = it & 63;
+    const int mt = q >> 3, jt = (q >> 1) & 3, b = q & 1;
+    const int qd = ln >> 4;
+    m = mbase + 16 * mt + (ln & 15);
+    n = strip * 128 + 64 * (qd >> 1) + 16 * jt + 8 * b + 4 * (qd & 1);
+  };
+
+  if (ksplit == 1) {
+    for (int it = tid; it < NQ * 64; it += WAVES * 64) {
+      int m, n;
+      item_coords(it, m, n);
+      if (m < M && n < N) {
+        const int q = it >> 6, ln = it & 63;
+        const int* rp = &red[(q * 4) * 64 + ln];
+        epilogue_store4(rp[0], rp[64], rp[128], rp[192], m, n, N, s1[m], s2, D, acc_out);
+      }
+    }
+    return;
+  }
+
+  // split-K: partial sums -> slab sp of C  (C[(sp*M + m)*N + n])
+  for (int it = tid; it < NQ * 64; it += WAVES * 64) {
+    int m, n;
+    item_coords(it, m, n);
+    if (m < M && n < N) {
+      const int q = it >> 6, ln = it & 63;
+      const int* rp = &red[(q * 4) * 64 + ln];
+      v4i v = {rp[0], rp[64], rp[128], rp[192]};
+      *reinterpret_cast<v4i*>(C + ((size_t)sp * M + m) * N + n) = v;
+    }
+  }
+  if (!fused) return;  // a separate reduce launch finishes the job
+
+  // in-launch reduction by the last-arriving workgroup of this (strip, m-block) tile:
+  // agent-scope release -> ticket -> agent-scope acquire (placement independent).
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int* flag = &red[NQ * 4 * 64];
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int* tk = tickets + (blockIdx.z * gridDim.x + strip);
+    const int t = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = (t == ksplit - 1);
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // workspace zero on return
+    }
+    *flag = last;
+  }
+  __syncthreads();
+  if (!*flag) return;
+  for (int it = tid; it < NQ * 64; it += WAVES * 64) {
+    int m, n;
+    item_coords(it, m, n);
+    if (m < M && n < N) {
+      v4i sum = {0, 0, 0, 0};
+      for (int p = 0; p < ksplit; ++p)
+        sum += *reinterpret_cast<const v4i*>(C + ((size_t)p * M + m) * N + n);
+      epilogue_store4(sum[0], sum[1], sum[2], sum[3], m, n, N, s1[m], s2, D, acc_out);
+    }
+  }
+}
+
+// Separate reduce + dequant launch for split-K partial sums: one thread = 4 consecutive n.
+__global__ __launch_bounds__(256) void qqq_reduce_kernel(const int32_t* __restrict__ C,
+                                                         _Float16* __restrict__ D,
+                                                         const float* __restrict__ s1,
+                                                         const float* __restrict__ s2,
+                                                         int32_t* __restrict__ acc_out, const int M,
+                                                         const int N, const int ksplit) {
+  const int nq = N >> 2;
+  const long long total = (long long)M * nq;
+  for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < total;
+       it += (long long)gridDim.x * 256) {
+    const int m = (int)(it / nq);
+    const int n = (int)(it % nq) * 4;
+    v4i sum = {0, 0, 0, 0};
+    for (int p = 0; p < ksplit; ++p)
+      sum += *reinterpret_cast<const v4i*>(C + ((size_t)p * M + m) * N + n);
+    epilogue_store4(sum[0], sum[1], sum[2], sum[3], m, n, N, s1[m], s2, D, acc_out);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// "tiled" kernel: large m, LDS-staged, MFMA 32x32x32
+// ------------------------------------------------------------------------------------------
+//
+// Workgroup tile = BM tokens x 256 weight columns (4 column groups ng0..ng0+3), BK = 128.
+// MFMA A operand lane l = (i = l & 31, h = l >> 5): i = 8*g + c <-> columns
+//     n = n0 + 64*g + 16*jt + 8*b + c,  k = 32*t + 16*h + [0,16)  (k-tile 2*t + h of the stage).
+// MFMA B operand lane l = (j = l & 31, h): token m0 + 32*mtile + j, same k.
+// MFMA D lane l: column j = l & 31 (token), rows i = (r & 3) + 8*(r >> 2) + 4*(l >> 5)
+//     -> g = r >> 2, c = 4*h + (r & 3): 4 consecutive n per (jt, b, g).
+// Waves: WM x WN; wave (wm, wn) owns tokens [32*MTW*wm, +32*MTW) and jt in [JW*wn, +JW).
+//
+// LDS stage: W region 8 k-tiles x 2048 B (raw packed words; 16-byte chunk (c, kq) of block
+// (kt, g) is stored at chunk position 4*c + (kq ^ g): the four 16-lane groups of a
+// ds_read_b128 then hit 16 distinct bank quads), X region BM rows x 128 B (chunk position
+// p ^ ((row >> 1) & 7)).  With global_load_lds the LDS image is lane-linear, so the swizzle is
+// applied to the per-lane SOURCE address; the register-staged variant writes the same image.
+
+template <int BM, int MTW, int JW, bool GROUPED, bool GLDS>
+__global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * 64) void qqq_tiled_kernel(
+    const int8_t* __restrict__ A, const unsigned char* __restrict__ B, int32_t* __restrict__ C,
+    _Float16* __restrict__ D, const float* __restrict__ s1, const float* __restrict__ s2,
+    const _Float16* __restrict__ s3, int32_t* __restrict__ acc_out, const int M, const int N,
+    const int K, const int ksplit, const int tiles_m, const int tiles_n) {
+  constexpr int WM = BM / (32 * MTW);
+  constexpr int WN = 4 / JW;
+  constexpr int NT = WM * WN * 64;
+  constexpr int W_BYTES = 8 * 2048;
+  constexpr int X_BYTES = BM * 128;
+  constexpr int STAGE = W_BYTES + X_BYTES;
+  constexpr int W_CHUNKS = W_BYTES / 16;  // 1024
+  constexpr int X_CHUNKS = X_BYTES / 16;
+  constexpr int WPT = W_CHUNKS / NT;  // chunks per thread
+  constexpr int XPT = X_CHUNKS / NT;
+  static_assert(W_CHUNKS % NT == 0 && X_CHUNKS % NT == 0, "tile/threads mismatch");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN;
+  const int wn = wave % WN;
+
+  // ---- XCD-aware tile order: block b runs on XCD b % 8; give each XCD a contiguous run of the
+  // panel-major tile sequence (panels of 4 strips x all m-tiles) so co-resident workgroups of one
+  // XCD share weight strips / activation rows in that XCD's L2.  Speed only, never correctness.
+  const int ntiles = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  int lin;
+  {
+    const int q = ntiles >> 3, rr = ntiles & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    lin = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+  }
+  int tile_m, tile_n;
+  {
+    constexpr int PW = 4;
+    const int full = (tiles_n / PW) * PW * tiles_m;
+    if (lin < full) {
+      const int panel = lin / (PW * tiles_m), within = lin % (PW * tiles_m);
+      tile_m = within / PW;
+      tile_n = panel * PW + within % PW;
+    } else {
+      const int rem = lin - full, pw = tiles_n % PW;
+      tile_m = rem / pw;
+      tile_n = (tiles_n / PW) * PW + rem % pw;
+    }
+  }
+  const int sp = blockIdx.y;
+  const int m0 = tile_m * BM;
+  const int ng0 = tile_n * 4;
+  const int ngroups = N >> 6;
+
+  const int NKB = K >> 7;  // 128-k blocks
+  const int kb_begin = (int)(((long long)NKB * sp) / ksplit);
+  const int kb_end = (int)(((long long)NKB * (sp + 1)) / ksplit);
+  const size_t rowbytes = (size_t)N * 8;
+
+  // ---- per-thread staging sources (offsets relative to the stage's first k-tile / k byte) ----
+  unsigned wsrc[WPT], xsrc[XPT];
+#pragma unroll
+  for (int i = 0; i < WPT; ++i) {
+    const int cw = tid + i * NT;  // LDS chunk index inside the W region
+    const int ktl = cw >> 7, gl = (cw >> 5) & 3, pos = cw & 31;
+    const int cc = pos >> 2, kq = (pos & 3) ^ gl;
+    int ngx = ng0 + gl;
+    if (ngx >= ngroups) ngx = ngroups - 1;
+    wsrc[i] = (unsigned)(ktl * rowbytes + (size_t)ngx * 512 + (4 * cc + kq) * 16);
+  }
+#pragma unroll
+  for (int i = 0; i < XPT; ++i) {
+    const int cx = tid + i * NT;
+    const int row = cx >> 3, pos = cx & 7;
+    const int chunk = pos ^ ((row >> 1) & 7);
+    int grow = m0 + row;
+    if (grow >= M) grow = M - 1;
+    xsrc[i] = (unsigned)((size_t)(grow - m0) * K + chunk * 16);
+  }
+  const unsigned char* Abase = reinterpret_cast<const unsigned char*>(A) + (size_t)m0 * K;
+
+  // ---- per-lane LDS read offsets ----
+  const int li = lane & 31, h = lane >> 5;
+  const int g = li >> 3, c = li & 7;
+  unsigned wrd[4];  // + t*4096
+#pragma unroll
+  for (int kq = 0; kq < 4; ++kq)
+    wrd[kq] = h * 2048 + g * 512 + (4 * c + (kq ^ g)) * 16 + wn * (JW * 4);  // this wave's jt only
+  unsigned xrd[4];  // per k-step t; + mt*32*128
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+    xrd[t] = W_BYTES + (wm * MTW * 32 + li) * 128 + (((2 * t + h) ^ ((li >> 1) & 7)) * 16);
+
+  const _Float16* sptr = nullptr;
+  if constexpr (GROUPED) {
+    int ngx = ng0 + g;
+    if (ngx >= ngroups) ngx = ngroups - 1;
+    sptr = s3 + (size_t)ngx * 64 + c * 8 + wn * (2 * JW);
+  }
+
+  v16i acc[MTW][JW][2];
+#pragma unroll
+  for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+    for (int jj = 0; jj < JW; ++jj)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][jj][b][r] = 0;
+
+  v4u wreg[WPT], xreg[XPT];  // register staging (unused with GLDS)
+
+  auto issue_loads = [&](const int kb, const int buf) {
+    const unsigned char* wb = B + (size_t)(kb * 8) * rowbytes;
+    const unsigned char* xb = Abase + (size_t)kb * 128;
+    if constexpr (GLDS) {
+      unsigned char* st = smem + buf * STAGE;
+#pragma unroll
+      for (int i = 0; i < WPT; ++i)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(wb + wsrc[i]),
+            (__attribute__((address_space(3))) void*)(st + (wave * 64 + i * NT) * 16), 16, 0, 0);
+#pragma unroll
+      for (int i = 0; i < XPT; ++i)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(xb + xsrc[i]),
+            (__attribute__((address_space(3))) void*)(st + W_BYTES + (wave * 64 + i * NT) * 16), 16,
+            0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < WPT; ++i) wreg[i] = *reinterpret_cast<const v4u*>(wb + wsrc[i]);
+#pragma unroll
+      for (int i = 0; i < XPT; ++i) xreg[i] = *reinterpret_cast<const v4u*>(xb + xsrc[i]);
+    }
+  };
+  auto commit_loads = [&](const int buf) {  // register-staged variant: write the LDS image
+    if constexpr (!GLDS) {
+      unsigned char* st = smem + buf * STAGE;
+#pragma unroll
+      for (int i = 0; i < WPT; ++i) *reinterpret_cast<v4u*>(st + (tid + i * NT) * 16) = wreg[i];
+#pragma unroll
+      for (int i = 0; i < XPT; ++i)
+        *reinterpret_cast<v4u*>(st + W_BYTES + (tid + i * NT) * 16) = xreg[i];
+    }
+  };
+
+  // per-group scales of this lane's (jt in [JW*wn, +JW), b) columns: 2*JW consecutive fp16
+  typedef _Float16 hsc __attribute__((ext_vector_type(2 * JW)));
+  hsc sc_cur = {}, sc_nxt = {};
+  if constexpr (GROUPED)
+    if (kb_begin < kb_end) sc_cur = *reinterpret_cast<const hsc*>(sptr + (size_t)kb_begin * N);
+
+  auto compute_stage = [&](const int buf) {
+    const unsigned char* st = smem + buf * STAGE;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      unsigned wq[4][JW];  // raw packed words [kq][jj]; only this wave's jt are read from LDS
+#pragma unroll
+      for (int kq = 0; kq < 4; ++kq) {
+        const unsigned char* p = st + wrd[kq] + t * 4096;
+        if constexpr (JW == 4) {
+          const v4u v = *reinterpret_cast<const v4u*>(p);
+          wq[kq][0] = v[0]; wq[kq][1] = v[1]; wq[kq][2] = v[2]; wq[kq][3] = v[3];
+        } else if constexpr (JW == 2) {
+          const uint2 v = *reinterpret_cast<const uint2*>(p);
+          wq[kq][0] = v.x; wq[kq][1] = v.y;
+        } else {
+          wq[kq][0] = *reinterpret_cast<const unsigned*>(p);
+        }
+      }
+      v4i xop[MTW];
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt)
+        xop[mt] = *reinterpret_cast<const v4i*>(st + xrd[t] + mt * (32 * 128));
+#pragma unroll
+      for (int jj = 0; jj < JW; ++jj) {
+        v4i a0, a1;
+        h2 sb0 = {(_Float16)0, (_Float16)0}, sb1 = sb0;
+        if constexpr (GROUPED) {
+          sb0 = (h2){sc_cur[2 * jj], sc_cur[2 * jj]};
+          sb1 = (h2){sc_cur[2 * jj + 1], sc_cur[2 * jj + 1]};
+        }
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) {
+          int w0, w1;
+          unpack_pair<GROUPED>(wq[kq][jj], sb0, sb1, w0, w1);
+          a0[kq] = w0;
+          a1[kq] = w1;
+        }
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) {
+          acc[mt][jj][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, xop[mt], acc[mt][jj][0], 0, 0, 0);
+          acc[mt][jj][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, xop[mt], acc[mt][jj][1], 0, 0, 0);
+        }
+      }
+    }
+  };
+
+  // ---- main loop: 2 LDS stages, one barrier per 128-k block ----
+  if (kb_begin < kb_end) {
+    issue_loads(kb_begin, 0);
+    if constexpr (GLDS) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      commit_loads(0);
+    }
+    __syncthreads();
+  }
+  for (int kb = kb_begin; kb < kb_end; ++kb) {
+    const int buf = (kb - kb_begin) & 1;
+    const bool more = (kb + 1 < kb_end);
+    if (more) {
+      issue_loads(kb + 1, buf ^ 1);
+      if constexpr (GROUPED) sc_nxt = *reinterpret_cast<const hsc*>(sptr + (size_t)(kb + 1) * N);
+    }
+    compute_stage(buf);
+    if (more) {
+      if constexpr (GLDS) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        commit_loads(buf ^ 1);
+      }
+    }
+    if constexpr (GROUPED) sc_cur = sc_nxt;
+    __syncthreads();
+  }
+
+  // ---- epilogue straight from the accumulators ----
+  int mrow[MTW];
+  float a_s[MTW];
+#pragma unroll
+  for (int mt = 0; mt < MTW; ++mt) {
+    mrow[mt] = m0 + (wm * MTW + mt) * 32 + li;
+    a_s[mt] = (mrow[mt] < M && ksplit == 1) ? s1[mrow[mt]] : 0.f;
+  }
+  const int n_lane = ng0 * 64 + 4 * h;  // + 64*g' + 16*jt + 8*b  (g' = r >> 2), + (r & 3)
+#pragma unroll
+  for (int jj = 0; jj < JW; ++jj) {
+    const int jt = wn * JW + jj;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int n = n_lane + 64 * gq + 16 * jt + 8 * b;
+        if (n >= N) continue;
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) {
+          const int m = mrow[mt];
+          if (m >= M) continue;
+          const int v0 = acc[mt][jj][b][4 * gq + 0], v1 = acc[mt][jj][b][4 * gq + 1];
+          const int v2 = acc[mt][jj][b][4 * gq + 2], v3 = acc[mt][jj][b][4 * gq + 3];
+          if (ksplit == 1) {
+            epilogue_store4(v0, v1, v2, v3, m, n, N, a_s[mt], s2, D, acc_out);
+          } else {
+            v4i v = {v0, v1, v2, v3};
+            *reinterpret_cast<v4i*>(C + ((size_t)sp * M + m) * N + n) = v;
+          }
+        }
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// fused per-token dynamic int8 quantisation (QuantLinear.dynamic_quant, qlinear_marlin.py:265-268)
+// one workgroup per token row; the row is kept in registers between the two passes.
+// ------------------------------------------------------------------------------------------
+template <int VPT>  // 16-byte vectors (8 halfs) per thread; covers K <= 256*8*VPT
+__global__ __launch_bounds__(256) void qqq_dynamic_quant_kernel(const _Float16* __restrict__ x,
+                                                                int8_t* __restrict__ xq,
+                                                                float* __restrict__ s1, const int K) {
+  __shared__ float wmax[4];
+  const int row = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int nvec = K >> 3;
+  const h8* xr = reinterpret_cast<const h8*>(x + (size_t)row * K);
+  h8 v[VPT];
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int idx = tid + i * 256;
+    if (idx < nvec) {
+      v[i] = xr[idx];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf((float)v[i][e]));
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+  if ((tid & 63) == 0) wmax[tid >> 6] = amax;
+  __syncthreads();
+  amax = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+  // torch on GPU lowers `.div(127.0)` to a multiply by the fp32 reciprocal; result kept in fp16
+  const float scale = (float)(_Float16)__fmul_rn(amax, 1.0f / 127.0f);
+  if (tid == 0) s1[row] = scale;
+  int2* qr = reinterpret_cast<int2*>(xq + (size_t)row * K);
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int idx = tid + i * 256;
+    if (idx < nvec) {
+      unsigned lo = 0, hi = 0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        // all-zero row: the reference computes 0/0 = NaN -> int8 (undefined); we emit 0
+        float q = (scale > 0.f) ? __fdiv_rn((float)v[i][e], scale) : 0.f;
+        q = rintf(q);
+        q = fminf(fmaxf(q, -128.f), 127.f);
+        const unsigned byte = (unsigned)((int)q) & 0xFFu;
+        if (e < 4)
+          lo |= byte << (8 * e);
+        else
+          hi |= byte << (8 * (e - 4));
+      }
+      qr[idx] = make_int2((int)lo, (int)hi);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void qqq_add_bias_kernel(_Float16* __restrict__ D,
+                                                           const _Float16* __restrict__ bias,
+                                                           const long long total_vec, const int nvec) {
+  for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < total_vec;
+       it += (long long)gridDim.x * 256) {
+    h8 d = reinterpret_cast<h8*>(D)[it];
+    const h8 b = reinterpret_cast<const h8*>(bias)[it % nvec];
+    d = d + b;  // fp16 add, RN -- same as torch's half + half
+    reinterpret_cast<h8*>(D)[it] = d;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// hardware probes (tests/test_gpu_probe.py)
+// ------------------------------------------------------------------------------------------
+__global__ void qqq_probe_mfma16_kernel(const v4i* a, const v4i* b, v4i* out) {
+  const int l = threadIdx.x;
+  v4i acc = {0, 0, 0, 0};
+  acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[l], b[l], acc, 0, 0, 0);
+  out[l] = acc;
+}
+__global__ void qqq_probe_mfma32_kernel(const v4i* a, const v4i* b, v16i* out) {
+  const int l = threadIdx.x;
+  v16i acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0;
+  acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[l], b[l], acc, 0, 0, 0);
+  out[l] = acc;
+}
+__global__ void qqq_probe_glds_kernel(const v4u* src, const int* perm, v4u* dst) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[1024];
+  const int l = threadIdx.x;
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + perm[l]),
+                                   (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  dst[l] = reinterpret_cast<const v4u*>(lds)[l];
+}
+
+// ------------------------------------------------------------------------------------------
+// host side: validation (mirrors the reference's), dispatch, C-ABI
+// ------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail_hip(hipError_t e, const char* what) {
+  snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+  return QQQ_ERR_HIP;
+}
+
+struct DeviceGuard {
+  int prev = -1;
+  bool changed = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != dev && dev >= 0) {
+      changed = (hipSetDevice(dev) == hipSuccess);
+    }
+  }
+  ~DeviceGuard() {
+    if (changed) (void)hipSetDevice(prev);
+  }
+};
+
+// reference: is_valid_config (csrc/qqq_gemm.cu:867-897)
+static bool ref_valid_config(int thread_k, int thread_n, int num_threads, int n, int k) {
+  if (thread_k == -1 || thread_n == -1 || num_threads == -1) return false;
+  if (k % thread_k != 0 || n % thread_n != 0) return false;
+  if (thread_k != 128 && thread_k != 64) return false;
+  if (thread_n < 64 || thread_k < 64) return false;
+  if (num_threads < 128) return false;
+  return true;
+}
+
+// reference: determine_thread_config + the CALL_IF table (csrc/qqq_gemm.cu:847-865, :899-945,
+// :1033-1036).  Returns 0 / ERR_PROB_SHAPE / ERR_KERN_SHAPE exactly when the reference does.
+static int ref_shape_check(int m, int n, int k, int groupsize, int thread_k, int thread_n) {
+  struct Cfg { int tk, tn, nt; };
+  static const Cfg small_cfgs[4] = {{128, 128, 256}, {128, 64, 128}, {64, 256, 256}, {64, 128, 128}};
+  static const Cfg large_cfgs[4] = {{64, 256, 256}, {128, 128, 256}, {64, 128, 128}, {128, 64, 128}};
+  Cfg cfg = {-1, -1, -1};
+  if (thread_k != -1 && thread_n != -1) {
+    cfg = {thread_k, thread_n, 256};
+  } else {
+    const Cfg* list = (m <= 16) ? small_cfgs : large_cfgs;
+    for (int i = 0; i < 4; ++i)
+      if (ref_valid_config(list[i].tk, list[i].tn, list[i].nt, n, k)) {
+        cfg = list[i];
+        break;
+      }
+  }
+  const int group_blocks = (groupsize == -1) ? -1 : groupsize / 16;
+  if (!ref_valid_config(cfg.tk, cfg.tn, cfg.nt, n, k) || (group_blocks != -1 && group_blocks != 0 && k % group_blocks != 0) ||
+      group_blocks == 0)
+    return QQQ_ERR_PROB_SHAPE;
+  if (m == 0 || n == 0 || k == 0) return QQQ_OK;
+  const int nb = cfg.tn / 16, kb = cfg.tk / 16;
+  const bool known = (nb == 8 && kb == 8 && cfg.nt == 256) || (nb == 16 && kb == 4 && cfg.nt == 256) ||
+                     (nb == 8 && kb == 4 && cfg.nt == 128) || (nb == 4 && kb == 8 && cfg.nt == 128);
+  if (!known || (group_blocks != -1 && group_blocks != 8)) return QQQ_ERR_KERN_SHAPE;
+  return QQQ_OK;
+}
+
+struct LaunchArgs {
+  const int8_t* A;
+  const unsigned char* B;
+  int32_t* C;
+  _Float16* D;
+  const float* s1;
+  const float* s2;
+  const _Float16* s3;
+  int32_t* acc_out;
+  int* tickets;
+  int M, N, K;
+  hipStream_t stream;
+};
+
+template <int MT, bool GROUPED, int WAVES>
+static hipError_t launch_stream_t(const LaunchArgs& a, int ksplit, int fused) {
+  dim3 grid((a.N + 127) / 128, ksplit, (a.M + 16 * MT - 1) / (16 * MT));
+  hipLaunchKernelGGL((qqq_stream_kernel<MT, GROUPED, WAVES>), grid, dim3(WAVES * 64), 0, a.stream, a.A,
+                     a.B, a.C, a.D, a.s1, a.s2, a.s3, a.acc_out, a.tickets, a.M, a.N, a.K, ksplit,
+                     fused);
+  return hipGetLastError();
+}
+
+template <bool GROUPED, int WAVES>
+static hipError_t launch_stream_mt(const LaunchArgs& a, int mt, int ksplit, int fused) {
+  switch (mt) {
+    case 1: return launch_stream_t<1, GROUPED, WAVES>(a, ksplit, fused);
+    case 2: return launch_stream_t<2, GROUPED, WAVES>(a, ksplit, fused);
+    case 3: return launch_stream_t<3, GROUPED, WAVES>(a, ksplit, fused);
+    default: return launch_stream_t<4, GROUPED, WAVES>(a, ksplit, fused);
+  }
+}
+
+static hipError_t launch_stream(const LaunchArgs& a, bool grouped, int mt, int waves, int ksplit,
+                                int fused) {
+  if (grouped) {
+    if (waves == 4) return launch_stream_mt<true, 4>(a, mt, ksplit, fused);
+    if (waves == 16) return launch_stream_mt<true, 16>(a, mt, ksplit, fused);
+    return launch_stream_mt<true, 8>(a, mt, ksplit, fused);
+  }
+  if (waves == 4) return launch_stream_mt<false, 4>(a, mt, ksplit, fused);
+  if (waves == 16) return launch_stream_mt<false, 16>(a, mt, ksplit, fused);
+  return launch_stream_mt<false, 8>(a, mt, ksplit, fused);
+}
+
+template <int BM, int MTW, int JW, bool GROUPED, bool GLDS>
+static hipError_t launch_tiled_t(const LaunchArgs& a, int ksplit) {
+  constexpr int NT = (BM / (32 * MTW)) * (4 / JW) * 64;
+  constexpr int LDS = 2 * (8 * 2048 + BM * 128);
+  static bool attr_set[64] = {};  // per instantiation, per device
+  auto kern = qqq_tiled_kernel<BM, MTW, JW, GROUPED, GLDS>;
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  if (cur < 0 || cur >= 64 || !attr_set[cur]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return e;
+    if (cur >= 0 && cur < 64) attr_set[cur] = true;
+  }
+  const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + 255) / 256;
+  dim3 grid(tiles_m * tiles_n, ksplit, 1);
+  hipLaunchKernelGGL(kern, grid, dim3(NT), LDS, a.stream, a.A, a.B, a.C, a.D, a.s1, a.s2, a.s3,
+                     a.acc_out, a.M, a.N, a.K, ksplit, tiles_m, tiles_n);
+  return hipGetLastError();
+}
+
+template <bool GROUPED, bool GLDS>
+static hipError_t launch_tiled_bm(const LaunchArgs& a, int bm, int ksplit) {
+  switch (bm) {
+    case 64: return launch_tiled_t<64, 1, 2, GROUPED, GLDS>(a, ksplit);
+    case 128: return launch_tiled_t<128, 2, 2, GROUPED, GLDS>(a, ksplit);
+    default: return launch_tiled_t<256, 2, 2, GROUPED, GLDS>(a, ksplit);
+  }
+}
+
+static hipError_t launch_tiled(const LaunchArgs& a, bool grouped, int bm, bool glds, int ksplit) {
+  if (grouped) return glds ? launch_tiled_bm<true, true>(a, bm, ksplit) : launch_tiled_bm<true, false>(a, bm, ksplit);
+  return glds ? launch_tiled_bm<false, true>(a, bm, ksplit) : launch_tiled_bm<false, false>(a, bm, ksplit);
+}
+
+static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, const void* s1,
+                                const void* s2, const void* s3, int prob_m, int prob_n, int prob_k,
+                                void* workspace, int groupsize, int dev, void* stream, int thread_k,
+                                int thread_n, int sms, int max_par, const qqq_tune_t* tune,
+                                int32_t* acc_out) {
+  (void)sms;
+  g_err[0] = 0;
+  const int rc = ref_shape_check(prob_m, prob_n, prob_k, groupsize, thread_k, thread_n);
+  if (rc != QQQ_OK) return rc;
+  if (prob_m == 0 || prob_n == 0 || prob_k == 0) return QQQ_OK;  // reference :1002-1003
+  if (!A || !B || !D || !s1 || !s2 || (groupsize != -1 && !s3)) {
+    snprintf(g_err, sizeof(g_err), "null pointer argument");
+    return QQQ_ERR_ARG;
+  }
+  const bool grouped = groupsize != -1;
+  qqq_tune_t t;
+  memset(&t, 0, sizeof(t));
+  if (tune) t = *tune;
+
+  const int M = prob_m, N = prob_n, K = prob_k;
+  const long long cap_rows = (long long)(max_par > 0 ? max_par : 0) * 64;  // rows of C we may use
+  const bool have_scratch = (C != nullptr) && cap_rows > 0;
+
+  // ---- kernel choice ----
+  int kernel = t.kernel;
+  if (kernel == 0) kernel = (M <= 64 || (K % 128) != 0) ? 1 : 2;
+  if (kernel == 2 && (K % 128) != 0) kernel = 1;
+
+  LaunchArgs a;
+  a.A = static_cast<const int8_t*>(A);
+  a.B = static_cast<const unsigned char*>(B);
+  a.C = static_cast<int32_t*>(C);
+  a.D = static_cast<_Float16*>(D);
+  a.s1 = static_cast<const float*>(s1);
+  a.s2 = static_cast<const float*>(s2);
+  a.s3 = static_cast<const _Float16*>(s3);
+  a.acc_out = acc_out;
+  a.tickets = static_cast<int*>(workspace);
+  a.M = M;
+  a.N = N;
+  a.K = K;
+  a.stream = static_cast<hipStream_t>(stream);
+
+  DeviceGuard guard(dev);
+  hipError_t e = hipSuccess;
+  int ksplit = 1;
+
+  if (kernel == 1) {
+    // rows are processed in m-blocks of 16*MT (grid.z); every m-block re-reads the weights, so this
+    // kernel is meant for m <= 64 (one m-block) but stays correct for any m.
+    const int mt = clampi((M + 15) / 16, 1, 4);
+    const int mblocks = (M + 16 * mt - 1) / (16 * mt);
+    const int strips = (N + 127) / 128;
+    const int KS = K / 64;
+    int waves = t.waves ? t.waves : 8;
+    if (waves != 4 && waves != 8 && waves != 16) waves = 8;
+    ksplit = t.ksplit;
+    if (ksplit <= 0) {
+      // fill ~256 CUs x 8 waves; keep >= 2 steps per wave
+      const long long want_wg = 256LL * 8 / waves;
+      ksplit = (int)((want_wg + (long long)strips * mblocks - 1) / ((long long)strips * mblocks));
+    }
+    ksplit = clampi(ksplit, 1, KS / (2 * waves) > 0 ? KS / (2 * waves) : 1);
+    if (!have_scratch) ksplit = 1;
+    if (ksplit > 1 && (long long)ksplit * M > cap_rows) ksplit = (int)(cap_rows / M);
+    if (ksplit < 1) ksplit = 1;
+    int fused = t.fused;
+    if (fused == 0) fused = 1;
+    // tickets: one int per (m-block, strip); the reference guarantees n/128*max_par ints
+    if (fused == 1 && (workspace == nullptr || (long long)mblocks * strips > (long long)(N / 128) * max_par))
+      fused = 2;
+    e = launch_stream(a, grouped, mt, waves, ksplit, fused == 1 ? 1 : 0);
+    if (e != hipSuccess) return fail_hip(e, "qqq_stream_kernel launch");
+    if (ksplit > 1 && fused != 1) {
+      const long long items = (long long)M * (N / 4);
+      const int blocks = (int)((items + 255) / 256 > 2048 ? 2048 : (items + 255) / 256);
+      hipLaunchKernelGGL(qqq_reduce_kernel, dim3(blocks), dim3(256), 0, a.stream, a.C, a.D, a.s1, a.s2,
+                         a.acc_out, M, N, ksplit);
+      e = hipGetLastError();
+      if (e != hipSuccess) return fail_hip(e, "qqq_reduce_kernel launch");
+    }
+    return QQQ_OK;
+  }
+
+  // ---- tiled ----
+  int bm = t.bm;
+  if (bm != 64 && bm != 128 && bm != 256) {
+    const long long t256 = (long long)((M + 255) / 256) * ((N + 255) / 256);
+    const long long t128 = (long long)((M + 127) / 128) * ((N + 255) / 256);
+    if (t256 >= 384)
+      bm = 256;
+    else if (t128 >= 192 || M > 64)
+      bm = 128;
+    else
+      bm = 64;
+  }
+  const bool glds = (t.glds == 0) ? true : (t.glds == 1);
+  const long long tiles = (long long)((M + bm - 1) / bm) * ((N + 255) / 256);
+  ksplit = t.ksplit;
+  if (ksplit <= 0) ksplit = tiles >= 192 ? 1 : (int)((256 + tiles - 1) / tiles);
+  ksplit = clampi(ksplit, 1, (K / 128) / 4 > 0 ? (K / 128) / 4 : 1);
+  if (!have_scratch) ksplit = 1;
+  if (ksplit > 1 && (long long)ksplit * M > cap_rows) ksplit = (int)(cap_rows / M);
+  if (ksplit < 1) ksplit = 1;
+  e = launch_tiled(a, grouped, bm, glds, ksplit);
+  if (e != hipSuccess) return fail_hip(e, "qqq_tiled_kernel launch");
+  if (ksplit > 1) {
+    const long long items = (long long)M * (N / 4);
+    const int blocks = (int)((items + 255) / 256 > 2048 ? 2048 : (items + 255) / 256);
+    hipLaunchKernelGGL(qqq_reduce_kernel, dim3(blocks), dim3(256), 0, a.stream, a.C, a.D, a.s1, a.s2,
+                       a.acc_out, M, N, ksplit);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "qqq_reduce_kernel launch");
+  }
+  return QQQ_OK;
+}
+
+extern "C" int qqq_w4a8_gemm(const void* A, const void* B, void* C, void* D, const void* s1,
+                             const void* s2, const void* s3, int prob_m, int prob_n, int prob_k,
+                             void* workspace, int groupsize, int dev, void* stream, int thread_k,
+                             int thread_n, int sms, int max_par) {
+  return qqq_w4a8_gemm_ex(A, B, C, D, s1, s2, s3, prob_m, prob_n, prob_k, workspace, groupsize, dev,
+                          stream, thread_k, thread_n, sms, max_par, nullptr, nullptr);
+}
+
+extern "C" int qqq_dynamic_quant(const void* x, void* xq, void* s1, int m, int k, int dev,
+                                 void* stream) {
+  g_err[0] = 0;
+  if (m == 0 || k == 0) return QQQ_OK;
+  if (!x || !xq || !s1 || (k % 8) != 0) {
+    snprintf(g_err, sizeof(g_err), "qqq_dynamic_quant: bad argument (k must be a multiple of 8)");
+    return QQQ_ERR_ARG;
+  }
+  DeviceGuard guard(dev);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const _Float16* xp = static_cast<const _Float16*>(x);
+  int8_t* qp = static_cast<int8_t*>(xq);
+  float* sp = static_cast<float*>(s1);
+  const int nvec = k / 8;
+  const int vpt = (nvec + 255) / 256;
+  if (vpt <= 2)
+    hipLaunchKernelGGL(qqq_dynamic_quant_kernel<2>, dim3(m), dim3(256), 0, st, xp, qp, sp, k);
+  else if (vpt <= 4)
+    hipLaunchKernelGGL(qqq_dynamic_quant_kernel<4>, dim3(m), dim3(256), 0, st, xp, qp, sp, k);
+  else if (vpt <= 8)
+    hipLaunchKernelGGL(qqq_dynamic_quant_kernel<8>, dim3(m), dim3(256), 0, st, xp, qp, sp, k);
+  else if (vpt <= 16)
+    hipLaunchKernelGGL(qqq_dynamic_quant_kernel<16>, dim3(m), dim3(256), 0, st, xp, qp, sp, k);
+  else if (vpt <= 32)
+    hipLaunchKernelGGL(qqq_dynamic_quant_kernel<32>, dim3(m), dim3(256), 0, st, xp, qp, sp, k);
+  else {
+    snprintf(g_err, sizeof(g_err), "qqq_dynamic_quant: k=%d too large (max 65536)", k);
+    return QQQ_ERR_ARG;
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail_hip(e, "qqq_dynamic_quant_kernel launch");
+  return QQQ_OK;
+}
+
+extern "C" int qqq_add_bias(void* D, const void* bias, int m, int n, int dev, void* stream) {
+  g_err[0] = 0;
+  if (m == 0 || n == 0) return QQQ_OK;
+  if (!D || !bias || (n % 8) != 0) {
+    snprintf(g_err, sizeof(g_err), "qqq_add_bias: bad argument");
+    return QQQ_ERR_ARG;
+  }
+  DeviceGuard guard(dev);
+  const long long total = (long long)m * (n / 8);
+  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(qqq_add_bias_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<_Float16*>(D), static_cast<const _Float16*>(bias), total, n / 8);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail_hip(e, "qqq_add_bias_kernel launch");
+  return QQQ_OK;
+}
+
+extern "C" int qqq_probe_mfma(int kind, const void* a, const void* b, void* out, int dev,
+                              void* stream) {
+  DeviceGuard guard(dev);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (kind == 16)
+    hipLaunchKernelGGL(qqq_probe_mfma16_kernel, dim3(1), dim3(64), 0, st, static_cast<const v4i*>(a),
+                       static_cast<const v4i*>(b), static_cast<v4i*>(out));
+  else if (kind == 32)
+    hipLaunchKernelGGL(qqq_probe_mfma32_kernel, dim3(1), dim3(64), 0, st, static_cast<const v4i*>(a),
+                       static_cast<const v4i*>(b), static_cast<v16i*>(out));
+  else
+    return QQQ_ERR_ARG;
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail_hip(e, "probe launch");
+  return QQQ_OK;
+}
+
+extern "C" int qqq_probe_glds(const void* src, const void* perm, void* dst, int dev, void* stream) {
+  DeviceGuard guard(dev);
+  hipLaunchKernelGGL(qqq_probe_glds_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const v4u*>(src), static_cast<const int*>(perm), static_cast<v4u*>(dst));
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail_hip(e, "probe launch");
+  return QQQ_OK;
+}
+
+extern "C" int qqq_amd_abi_version(void) { return QQQ_AMD_ABI_VERSION; }
+extern "C" const char* qqq_amd_last_error(void) { return g_err; }

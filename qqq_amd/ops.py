@@ -1,0 +1,172 @@
+"""Operator layer: the reference's `qqq_gemm` signature on top of the C-ABI (include/qqq_amd.h).
+
+`qqq_gemm` is positionally identical to `QQQ._CUDA.qqq_gemm` (csrc/pybind.cpp:3-5,
+csrc/qqq_gemm.cu:1048-1106, qqq_gemm.h:23-36) and raises RuntimeError in the same situations with
+the same messages.  It is also registered as the torch custom op `qqq_amd::qqq_gemm`
+(torch.library), so it does not graph-break under torch.compile.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+ERR_PROB_SHAPE = 1
+ERR_KERN_SHAPE = 2
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    if t is None or t.numel() == 0:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream_for(t: torch.Tensor):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _check_common(A, B, C, D, s1, s2, s3, workspace, max_par):
+    # the reference's own checks (csrc/qqq_gemm.cu:1062-1075) ...
+    prob_m, prob_n, prob_k = A.size(0), C.size(1), A.size(1)
+    groupsize = -1 if s3.numel() == 0 else prob_k // s3.size(0)
+    if groupsize != -1 and groupsize * s3.size(0) != prob_k:
+        raise RuntimeError(f"k={prob_k} not compatible with {s3.size(0)} groups.")
+    if workspace.numel() < prob_n // 128 * max_par:
+        raise RuntimeError(f"workspace must be of size at least {prob_n // 128 * max_par}.")
+    if s1.dtype != torch.float32:
+        raise RuntimeError(f"s1 dtype must be float32, but got {s1.dtype}.")
+    if s2.dtype != torch.float32:
+        raise RuntimeError(f"s2 dtype must be float32, but got {s2.dtype}.")
+    if s3.dtype != torch.float16:
+        raise RuntimeError(f"s3 dtype must be float16, but got {s3.dtype}.")
+    # ... plus the ones the reference leaves as undefined behaviour (SURVEY 8b "Errors")
+    if A.dtype != torch.int8 or B.dtype != torch.int32 or D.dtype != torch.float16 or C.dtype != torch.int32:
+        raise RuntimeError("qqq_gemm: expected A int8, B int32, C int32, D float16")
+    if workspace.dtype != torch.int32:
+        raise RuntimeError("qqq_gemm: workspace must be int32")
+    for name, t in (("A", A), ("B", B), ("C", C), ("D", D), ("s1", s1), ("s2", s2), ("workspace", workspace)):
+        if not t.is_contiguous():
+            raise RuntimeError(f"qqq_gemm: {name} must be contiguous")
+        if not t.is_cuda or t.device != A.device:
+            raise RuntimeError(f"qqq_gemm: {name} must live on the same GPU as A (there is no CPU path)")
+    if s3.numel() and (not s3.is_contiguous() or s3.device != A.device):
+        raise RuntimeError("qqq_gemm: s3 must be contiguous and on A's device")
+    if B.numel() != (prob_k // 16) * (prob_n * 2) or D.numel() != prob_m * prob_n:
+        raise RuntimeError("qqq_gemm: B must be [k/16, 2n] and D [m, n]")
+    if s1.numel() != prob_m or s2.numel() != prob_n:
+        raise RuntimeError("qqq_gemm: s1 must have m and s2 n elements")
+    if C.size(0) < max_par * 64:
+        raise RuntimeError(f"qqq_gemm: C must have at least max_par*64={max_par * 64} rows")
+    return prob_m, prob_n, prob_k, groupsize
+
+
+def _raise_for(err, prob_m, prob_n, prob_k, thread_k, thread_n, groupsize):
+    if err == 0:
+        return
+    if err == ERR_PROB_SHAPE:  # csrc/qqq_gemm.cu:1096-1100
+        raise RuntimeError(
+            f"Problem (m={prob_m}, n={prob_n}, k={prob_k}) not compatible with thread_k={thread_k}, thread_n={thread_n}."
+        )
+    if err == ERR_KERN_SHAPE:  # csrc/qqq_gemm.cu:1101-1105
+        raise RuntimeError(
+            f"No kernel implementation for thread_k={thread_k}, thread_n={thread_n}, groupsize={groupsize}."
+        )
+    raise RuntimeError(f"qqq_amd: error {err}: {_lib.last_error()}")
+
+
+def qqq_gemm_ex(A, B, C, D, s1, s2, s3, workspace, thread_k=-1, thread_n=-1, sms=-1, max_par=8,
+                tune: Optional[dict] = None, acc_out: Optional[torch.Tensor] = None) -> None:
+    """qqq_gemm with tuning / debug hooks (tests, bench).  `tune` keys: kernel, ksplit, waves, fused, bm, glds."""
+    L = _lib.lib()
+    prob_m, prob_n, prob_k, groupsize = _check_common(A, B, C, D, s1, s2, s3, workspace, max_par)
+    tn = None
+    if tune:
+        tn = _lib.QQQTune()
+        for k, v in tune.items():
+            setattr(tn, k, int(v))
+    if acc_out is not None:
+        if acc_out.dtype != torch.int32 or acc_out.numel() != prob_m * prob_n or not acc_out.is_contiguous():
+            raise RuntimeError("acc_out must be a contiguous int32 [m, n] tensor")
+    err = L.qqq_w4a8_gemm_ex(
+        _ptr(A), _ptr(B), _ptr(C), _ptr(D), _ptr(s1), _ptr(s2), _ptr(s3), prob_m, prob_n, prob_k,
+        _ptr(workspace), groupsize, A.device.index if A.device.index is not None else 0, _stream_for(A),
+        thread_k, thread_n, sms, max_par, ctypes.byref(tn) if tn is not None else None, _ptr(acc_out),
+    )
+    _raise_for(err, prob_m, prob_n, prob_k, thread_k, thread_n, groupsize)
+
+
+def _qqq_gemm_impl(A, B, C, D, s1, s2, s3, workspace, thread_k, thread_n, sms, max_par) -> None:
+    L = _lib.lib()
+    prob_m, prob_n, prob_k, groupsize = _check_common(A, B, C, D, s1, s2, s3, workspace, max_par)
+    err = L.qqq_w4a8_gemm(
+        _ptr(A), _ptr(B), _ptr(C), _ptr(D), _ptr(s1), _ptr(s2), _ptr(s3), prob_m, prob_n, prob_k,
+        _ptr(workspace), groupsize, A.device.index if A.device.index is not None else 0, _stream_for(A),
+        thread_k, thread_n, sms, max_par,
+    )
+    _raise_for(err, prob_m, prob_n, prob_k, thread_k, thread_n, groupsize)
+
+
+@torch.library.custom_op("qqq_amd::qqq_gemm", mutates_args=("C", "D", "workspace"))
+def _qqq_gemm_op(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, D: torch.Tensor, s1: torch.Tensor,
+                 s2: torch.Tensor, s3: torch.Tensor, workspace: torch.Tensor, thread_k: int, thread_n: int,
+                 sms: int, max_par: int) -> None:
+    _qqq_gemm_impl(A, B, C, D, s1, s2, s3, workspace, thread_k, thread_n, sms, max_par)
+
+
+def qqq_gemm(A, B, C, D, s1, s2, s3, workspace, thread_k=-1, thread_n=-1, sms=-1, max_par=8) -> None:
+    """Drop-in for `QQQ._CUDA.qqq_gemm` (qqq_gemm.h:23-36): writes fp16 `D` in place, returns None."""
+    _qqq_gemm_op(A, B, C, D, s1, s2, s3, workspace, thread_k, thread_n, sms, max_par)
+
+
+def mul(A, B, C, D, s1, s2, s3, workspace, thread_k=-1, thread_n=-1, sms=-1, max_par=16):
+    """Drop-in for qlinear_marlin.mul (qlinear_marlin.py:28-45)."""
+    qqq_gemm(A, B, C, D, s1, s2, s3, workspace, thread_k, thread_n, sms, max_par)
+
+
+def marlin_qqq_gemm(a, b_q_weight, s_tok, s_ch, s_group, workspace, size_m, size_n, size_k):
+    """vLLM-style wrapper (`ops.marlin_qqq_gemm`, external to the reference tree): allocates the
+    int32 reduce buffer and the fp16 output itself and returns the output."""
+    max_par = 16
+    C = torch.empty((max_par * 64, size_n), dtype=torch.int32, device=a.device)
+    D = torch.empty((size_m, size_n), dtype=torch.float16, device=a.device)
+    if s_group is None:
+        s_group = torch.empty(0, dtype=torch.float16, device=a.device)
+    qqq_gemm(a, b_q_weight, C, D, s_tok, s_ch, s_group, workspace, -1, -1, -1, max_par)
+    return D
+
+
+@torch.library.custom_op("qqq_amd::dynamic_quant", mutates_args=())
+def _dynamic_quant_op(x: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    L = _lib.lib()
+    if x.dtype != torch.float16 or not x.is_cuda or x.dim() != 2:
+        raise RuntimeError("dynamic_quant: expected a 2-D fp16 tensor on the GPU (there is no CPU path)")
+    x = x.contiguous()
+    m, k = x.shape
+    xq = torch.empty((m, k), dtype=torch.int8, device=x.device)
+    s1 = torch.empty((m, 1), dtype=torch.float32, device=x.device)
+    err = L.qqq_dynamic_quant(_ptr(x), _ptr(xq), _ptr(s1), m, k, x.device.index or 0, _stream_for(x))
+    if err:
+        raise RuntimeError(f"qqq_amd: dynamic_quant error {err}: {_lib.last_error()}")
+    return xq, s1
+
+
+@_dynamic_quant_op.register_fake
+def _(x):
+    return x.new_empty(x.shape, dtype=torch.int8), x.new_empty((x.shape[0], 1), dtype=torch.float32)
+
+
+def dynamic_quant(x: torch.Tensor):
+    """Fused replacement of QuantLinear.dynamic_quant (qlinear_marlin.py:265-268): (int8 [m,k], f32 [m,1])."""
+    return _dynamic_quant_op(x)
+
+
+def add_bias_(D: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    L = _lib.lib()
+    m, n = D.shape
+    err = L.qqq_add_bias(_ptr(D), _ptr(bias), m, n, D.device.index or 0, _stream_for(D))
+    if err:
+        raise RuntimeError(f"qqq_amd: add_bias error {err}: {_lib.last_error()}")
+    return D

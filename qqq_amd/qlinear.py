@@ -1,0 +1,122 @@
+"""QuantLinear: the MI355X counterpart of QQQ/gptq/qlinear/qlinear_marlin.py:48-288.
+
+Same constructor arguments, same registered buffer names / shapes / dtypes (B, s_channel, s_group,
+bias persistent; workspace, reduce_buffer non-persistent) so a QQQ checkpoint's state-dict loads
+unchanged, same pack() arguments, same forward() semantics.  Differences, all deliberate:
+  * no CUDA-only constructor guards (qlinear_marlin.py:56-63 reject ROCm);
+  * pack() is vectorised (qqq_amd/pack.py) instead of python loops, and runs on any device;
+  * forward() uses one fused HIP kernel for dynamic_quant instead of ~8 torch launches.
+"""
+from __future__ import annotations
+
+from logging import getLogger
+
+import torch
+import torch.nn as nn
+
+from . import ops, pack as _pack
+
+logger = getLogger(__name__)
+
+
+class QuantLinear(nn.Module):
+    QUANT_TYPE = "marlin"
+
+    def __init__(self, bits, group_size, infeatures, outfeatures, bias, trainable=False, **kwargs):
+        super().__init__()
+        # (thread_k, thread_n) -- the reference's shape admission rule (qlinear_marlin.py:65-77)
+        self.thread_config = [(64, 256), (128, 128), (128, 64), (64, 128)]
+        if not any(infeatures % tk == 0 and outfeatures % tn == 0 for tk, tn in self.thread_config):
+            raise ValueError("Not supported `infeatures`: {} and `outfeatures`: {}.".format(infeatures, outfeatures))
+        if bits not in [4]:
+            raise NotImplementedError("Only 4 bits are supported.")
+        if group_size not in [-1, 128] and group_size != infeatures:
+            raise ValueError("Only group_size -1 and 128 are supported.")
+        if trainable:
+            raise NotImplementedError("Marlin does not support train.")
+
+        self.infeatures = infeatures
+        self.outfeatures = outfeatures
+        self.group_size = group_size if group_size != -1 else infeatures
+        if self.infeatures % self.group_size != 0:
+            raise ValueError("`infeatures` must be divisible by `group_size`.")
+        self.bits = bits
+        self.tile = 16
+        self.maxq = 2**self.bits - 1 if self.group_size != self.infeatures else 2 ** (self.bits - 1) - 1
+        self.max_par = 16
+        self.register_buffer("B", torch.empty((self.infeatures // 16, self.outfeatures * 16 // 8), dtype=torch.int32))
+        self.register_buffer("s_channel", torch.empty((1, self.outfeatures), dtype=torch.float32))
+        if self.group_size != self.infeatures:
+            self.register_buffer(
+                "s_group", torch.empty((self.infeatures // self.group_size, self.outfeatures), dtype=torch.half)
+            )
+        else:
+            self.register_buffer("s_group", torch.tensor([], dtype=torch.half))
+        self.register_buffer("workspace", torch.zeros(self.outfeatures // 128 * 16, dtype=torch.int32), persistent=False)
+        self.register_buffer(
+            "reduce_buffer", torch.zeros((self.max_par * 16 * 4, self.outfeatures), dtype=torch.int), persistent=False
+        )
+        if bias:
+            self.register_buffer("bias", torch.zeros((outfeatures), dtype=torch.half))
+        else:
+            self.bias = None
+
+    def _apply(self, fn):
+        # keep scale dtypes pinned across .half()/.to() (qlinear_marlin.py:141-145)
+        super()._apply(fn)
+        self.s_group = self.s_group.to(torch.half)
+        self.s_channel = self.s_channel.to(torch.float32)
+        return self
+
+    def post_init(self):
+        pass
+
+    @torch.no_grad()
+    def pack(self, linear, scales, s_extra=None):
+        """Same contract as qlinear_marlin.py:181-262: `linear` fake-quantised fp16 nn.Linear,
+        `scales` [outfeatures, groups], `s_extra` [outfeatures, 1] (per-group only)."""
+        grouped = self.group_size != self.infeatures
+        if grouped:
+            assert s_extra is not None, "s_extra is needed"
+        if linear.weight.dtype != torch.half:
+            logger.warning("The dtype of weights is %s, while the w4a8 GEMM's output is torch.half.", linear.weight.dtype)
+        s = scales.t()
+        w = linear.weight.data.t()  # [K, N]
+        K, N = self.infeatures, self.outfeatures
+        if grouped:
+            G = K // self.group_size
+            s_full = s.reshape(G, 1, N).expand(G, self.group_size, N).reshape(K, N)
+            codes = torch.clamp(torch.round(w / s_full).int() + (self.maxq + 1) // 2, 0, self.maxq)
+            se = s_extra.reshape(1, -1).to(dtype=torch.float32)
+            s_group = (s.reshape(-1, N) / se).to(dtype=torch.half)
+            self.s_group[:, :] = _pack.permute_s_group(s_group).to(self.s_group.device)
+            self.s_channel[:, :] = _pack.permute_s_channel(se).to(self.s_channel.device)
+        else:
+            codes = torch.clamp(torch.round(w / s).int(), -self.maxq, self.maxq)
+            sc = (s / (2 ** (8 - self.bits))).reshape(1, N)
+            self.s_group = torch.tensor([], dtype=torch.half, device=self.s_channel.device)
+            self.s_channel[:, :] = _pack.permute_s_channel(sc).to(dtype=torch.float32, device=self.s_channel.device)
+        self.B[:, :] = _pack.pack_codes(codes, grouped).to(self.B.device)
+        if linear.bias is not None:
+            if self.bias is not None:
+                self.bias[:] = linear.bias.data.to(self.bias.device).to(torch.half)
+            else:
+                self.bias = linear.bias.clone().to(torch.half)
+
+    def dynamic_quant(self, x: torch.Tensor):
+        """Per-token int8 quantisation (qlinear_marlin.py:265-268), one fused HIP kernel."""
+        return ops.dynamic_quant(x)
+
+    def forward(self, A):
+        out_shape = A.shape[:-1] + (self.outfeatures,)
+        A = A.reshape(-1, A.shape[-1]).half()
+        quant_A, s1 = self.dynamic_quant(A)
+        D = torch.empty(A.shape[0], self.outfeatures, dtype=A.dtype, device=A.device)
+        ops.mul(quant_A, self.B, self.reduce_buffer, D, s1, self.s_channel, self.s_group, self.workspace,
+                max_par=self.max_par)
+        if self.bias is not None:
+            ops.add_bias_(D, self.bias)  # fp16 add after the fp16 round, as `D + self.bias` (:287)
+        return D.reshape(out_shape)
+
+
+__all__ = ["QuantLinear"]

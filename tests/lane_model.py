@@ -1,0 +1,234 @@
+"""Lane-level numpy model of the two HIP kernels' data movement (tests only).
+
+It mirrors, formula by formula, the address arithmetic of qqq_amd/csrc/qqq_w4a8.hip
+(`qqq_stream_kernel`, `qqq_tiled_kernel`): which bytes each lane loads, how the LDS image is
+swizzled, which MFMA operand slot they land in, and where each accumulator register is stored.
+The MFMA lane maps assumed here (and checked on the device by tests/test_gpu_probe.py):
+
+  v_mfma_i32_16x16x64_i8 : A lane l -> row i = l & 15, k-group h = l >> 4 (16 bytes = 16 k-slots)
+                           B lane l -> col j = l & 15, same h; slot s of A pairs with slot s of B
+                           D lane l -> col j = l & 15, rows i = 4*(l >> 4) + r, r = 0..3
+  v_mfma_i32_32x32x32_i8 : A lane l -> row i = l & 31, h = l >> 5; B lane l -> col j = l & 31, h
+                           D lane l -> col j = l & 31, rows i = (r & 3) + 8*(r >> 2) + 4*(l >> 5)
+"""
+import numpy as np
+
+MASK = np.uint32(0xF0F0F0F0)
+
+
+def _bytes_to_i8(words_u32):
+    """[..., 4] uint32 -> [..., 16] int8 in memory (little endian) order."""
+    return np.ascontiguousarray(words_u32.astype("<u4")).view(np.int8).reshape(*words_u32.shape[:-1], 16)
+
+
+def _dequant4(q, s_half):
+    """dequant_group4 of the kernel: nibbles p0,p4,p1,p5 -> 4 int8 packed in a uint32."""
+    from oracle.qqq_ref import dequant_per_group_faithful as dq
+
+    q = np.asarray(q, dtype=np.uint32)
+    nib = [(q >> np.uint32(4 * p)) & np.uint32(0xF) for p in (0, 4, 1, 5)]
+    out = np.zeros_like(q)
+    for byte, u in enumerate(nib):
+        w8 = dq(u.astype(np.int8), np.broadcast_to(s_half, u.shape)).view(np.uint8).astype(np.uint32)
+        out |= w8 << np.uint32(8 * byte)
+    return out
+
+
+def unpack_pair(q, grouped, s_b0=None, s_b1=None):
+    q = np.asarray(q, dtype=np.uint32)
+    if grouped:
+        return _dequant4(q, s_b0), _dequant4(q >> np.uint32(8), s_b1)
+    return q & MASK, (q << np.uint32(4)) & MASK
+
+
+def mfma_16x16x64(a_ops, b_ops):
+    """a_ops, b_ops: [64 lanes, 16] int8 -> D regs [64 lanes, 4] int32."""
+    l = np.arange(64)
+    A = np.zeros((16, 4, 16), np.int64)
+    Bm = np.zeros((16, 4, 16), np.int64)
+    A[l & 15, l >> 4] = a_ops
+    Bm[l & 15, l >> 4] = b_ops
+    Dm = np.einsum("ihs,jhs->ij", A, Bm)
+    out = np.zeros((64, 4), np.int64)
+    for r in range(4):
+        out[:, r] = Dm[4 * (l >> 4) + r, l & 15]
+    return out
+
+
+def mfma_32x32x32(a_ops, b_ops):
+    l = np.arange(64)
+    A = np.zeros((32, 2, 16), np.int64)
+    Bm = np.zeros((32, 2, 16), np.int64)
+    A[l & 31, l >> 5] = a_ops
+    Bm[l & 31, l >> 5] = b_ops
+    Dm = np.einsum("ihs,jhs->ij", A, Bm)
+    out = np.zeros((64, 16), np.int64)
+    for r in range(16):
+        out[:, r] = Dm[(r & 3) + 8 * (r >> 2) + 4 * (l >> 5), l & 31]
+    return out
+
+
+def stream_kernel_model(A, B, s3, M, N, K, MT, WAVES, ksplit, grouped):
+    """Returns acc[M,N] int64 as the stream kernel would produce it (all m-blocks, K slices summed)."""
+    Bb = np.ascontiguousarray(B).view(np.uint8).reshape(-1)  # bytes
+    Ab = np.ascontiguousarray(A).view(np.uint8).reshape(-1)
+    s3h = None if not grouped else np.ascontiguousarray(s3).reshape(-1)
+    rowbytes = N * 8
+    ngroups = N >> 6
+    KS = K >> 6
+    lane = np.arange(64)
+    j = lane & 15
+    h = lane >> 4
+    g = j >> 3
+    c = j & 7
+    out = np.zeros((M, N), np.int64)
+    strips = (N + 127) // 128
+    mblocks = (M + 16 * MT - 1) // (16 * MT)
+    for mb in range(mblocks):
+        mbase = mb * 16 * MT
+        for strip in range(strips):
+            ng = np.minimum(strip * 2 + g, ngroups - 1)
+            boff = h * rowbytes + ng * 512 + c * 64
+            for sp in range(ksplit):
+                ks_begin = (KS * sp) // ksplit
+                ks_end = (KS * (sp + 1)) // ksplit
+                red = np.zeros((MT * 8 * 4, 64), np.int64)
+                for wave in range(WAVES):
+                    acc = np.zeros((MT, 4, 2, 64, 4), np.int64)
+                    for s in range(ks_begin + wave, ks_end, WAVES):
+                        p = boff + 4 * s * rowbytes
+                        idx = p[:, None] + np.arange(64)[None, :]
+                        w = Bb[idx].reshape(64, 4, 4, 4).view(np.uint8)  # [lane, kq, jt, byte]
+                        w = (w.astype(np.uint32) << (8 * np.arange(4, dtype=np.uint32))).sum(-1).astype(np.uint32)
+                        xs = []
+                        for mt in range(MT):
+                            row = np.minimum(mbase + 16 * mt + j, M - 1)
+                            xo = row * K + 16 * h + 64 * s
+                            xs.append(Ab[xo[:, None] + np.arange(16)[None, :]].view(np.int8))
+                        if grouped:
+                            so = ng * 64 + c * 8 + (s >> 1) * N
+                            sc = s3h[so[:, None] + np.arange(8)[None, :]]  # [lane, 8]
+                        for jt in range(4):
+                            if grouped:
+                                w0, w1 = unpack_pair(w[:, :, jt], True, sc[:, 2 * jt][:, None], sc[:, 2 * jt + 1][:, None])
+                            else:
+                                w0, w1 = unpack_pair(w[:, :, jt], False)
+                            a0 = _bytes_to_i8(w0)
+                            a1 = _bytes_to_i8(w1)
+                            for mt in range(MT):
+                                acc[mt, jt, 0] += mfma_16x16x64(a0, xs[mt])
+                                acc[mt, jt, 1] += mfma_16x16x64(a1, xs[mt])
+                    for mt in range(MT):
+                        for jt in range(4):
+                            for b in range(2):
+                                for r in range(4):
+                                    red[((mt * 4 + jt) * 2 + b) * 4 + r] += acc[mt, jt, b, :, r]
+                # write-out: item_coords
+                for it in range(MT * 8 * 64):
+                    q, ln = it >> 6, it & 63
+                    mt, jt, b = q >> 3, (q >> 1) & 3, q & 1
+                    qd = ln >> 4
+                    m = mbase + 16 * mt + (ln & 15)
+                    n = strip * 128 + 64 * (qd >> 1) + 16 * jt + 8 * b + 4 * (qd & 1)
+                    if m < M and n < N:
+                        out[m, n : n + 4] += red[q * 4 : q * 4 + 4, ln]
+    return out
+
+
+def tiled_kernel_model(A, B, s3, M, N, K, BM, MTW, JW, ksplit, grouped, return_tile_order=False):
+    Bb = np.ascontiguousarray(B).view(np.uint8).reshape(-1)
+    Ab = np.ascontiguousarray(A).view(np.uint8).reshape(-1)
+    s3h = None if not grouped else np.ascontiguousarray(s3).reshape(-1)
+    WM, WN = BM // (32 * MTW), 4 // JW
+    NT = WM * WN * 64
+    W_BYTES, X_BYTES = 8 * 2048, BM * 128
+    W_CHUNKS, X_CHUNKS = W_BYTES // 16, X_BYTES // 16
+    rowbytes = N * 8
+    ngroups = N >> 6
+    NKB = K >> 7
+    tiles_m, tiles_n = (M + BM - 1) // BM, (N + 255) // 256
+    ntiles = tiles_m * tiles_n
+    out = np.zeros((M, N), np.int64)
+    seen = []
+    for bid in range(ntiles):
+        q, rr = ntiles >> 3, ntiles & 7
+        xcd, idx = bid & 7, bid >> 3
+        lin = (xcd * (q + 1) if xcd < rr else rr * (q + 1) + (xcd - rr) * q) + idx
+        PW = 4
+        full = (tiles_n // PW) * PW * tiles_m
+        if lin < full:
+            panel, within = lin // (PW * tiles_m), lin % (PW * tiles_m)
+            tile_m, tile_n = within // PW, panel * PW + within % PW
+        else:
+            rem, pw = lin - full, tiles_n % PW
+            tile_m, tile_n = rem // pw, (tiles_n // PW) * PW + rem % pw
+        seen.append((tile_m, tile_n))
+        m0, ng0 = tile_m * BM, tile_n * 4
+        for sp in range(ksplit):
+            kb_begin, kb_end = (NKB * sp) // ksplit, (NKB * (sp + 1)) // ksplit
+            acc = np.zeros((WM * WN, MTW, JW, 2, 64, 16), np.int64)
+            for kb in range(kb_begin, kb_end):
+                # ---- build the LDS stage image exactly as the staging threads do ----
+                lds = np.zeros(W_BYTES + X_BYTES, np.uint8)
+                tid = np.arange(NT)
+                for i in range(W_CHUNKS // NT):
+                    cw = tid + i * NT
+                    ktl, gl, pos = cw >> 7, (cw >> 5) & 3, cw & 31
+                    cc, kq = pos >> 2, (pos & 3) ^ gl
+                    ngx = np.minimum(ng0 + gl, ngroups - 1)
+                    src = kb * 8 * rowbytes + ktl * rowbytes + ngx * 512 + (4 * cc + kq) * 16
+                    lds[(cw[:, None] * 16 + np.arange(16)[None, :])] = Bb[src[:, None] + np.arange(16)[None, :]]
+                for i in range(X_CHUNKS // NT):
+                    cx = tid + i * NT
+                    row, pos = cx >> 3, cx & 7
+                    chunk = pos ^ ((row >> 1) & 7)
+                    grow = np.minimum(m0 + row, M - 1)
+                    src = grow * K + kb * 128 + chunk * 16
+                    lds[W_BYTES + cx[:, None] * 16 + np.arange(16)[None, :]] = Ab[src[:, None] + np.arange(16)[None, :]]
+                # ---- every wave reads its fragments ----
+                lane = np.arange(64)
+                li, h = lane & 31, lane >> 5
+                g, c = li >> 3, li & 7
+                for wave in range(WM * WN):
+                    wm, wn = wave // WN, wave % WN
+                    if grouped:
+                        ngx = np.minimum(ng0 + g, ngroups - 1)
+                        so = ngx * 64 + c * 8 + wn * 2 * JW + kb * N
+                        sc = s3h[so[:, None] + np.arange(2 * JW)[None, :]]
+                    for t in range(4):
+                        wq = np.zeros((64, 4, JW), np.uint32)
+                        for kq in range(4):
+                            off = h * 2048 + g * 512 + (4 * c + (kq ^ g)) * 16 + wn * JW * 4 + t * 4096
+                            raw = lds[off[:, None] + np.arange(4 * JW)[None, :]].reshape(64, JW, 4)
+                            wq[:, kq, :] = (raw.astype(np.uint32) << (8 * np.arange(4, dtype=np.uint32))).sum(-1)
+                        xops = []
+                        for mt in range(MTW):
+                            xo = W_BYTES + (wm * MTW * 32 + li) * 128 + (((2 * t + h) ^ ((li >> 1) & 7)) * 16) + mt * 32 * 128
+                            xops.append(lds[xo[:, None] + np.arange(16)[None, :]].view(np.int8))
+                        for jj in range(JW):
+                            if grouped:
+                                w0, w1 = unpack_pair(wq[:, :, jj], True, sc[:, 2 * jj][:, None], sc[:, 2 * jj + 1][:, None])
+                            else:
+                                w0, w1 = unpack_pair(wq[:, :, jj], False)
+                            a0, a1 = _bytes_to_i8(w0), _bytes_to_i8(w1)
+                            for mt in range(MTW):
+                                acc[wave, mt, jj, 0] += mfma_32x32x32(a0, xops[mt])
+                                acc[wave, mt, jj, 1] += mfma_32x32x32(a1, xops[mt])
+            # ---- epilogue mapping ----
+            lane = np.arange(64)
+            li, h = lane & 31, lane >> 5
+            for wave in range(WM * WN):
+                wm, wn = wave // WN, wave % WN
+                for jj in range(JW):
+                    jt = wn * JW + jj
+                    for b in range(2):
+                        for gq in range(4):
+                            n = ng0 * 64 + 4 * h + 64 * gq + 16 * jt + 8 * b
+                            for mt in range(MTW):
+                                m = m0 + (wm * MTW + mt) * 32 + li
+                                for ln in range(64):
+                                    if n[ln] < N and m[ln] < M:
+                                        out[m[ln], n[ln] : n[ln] + 4] += acc[wave, mt, jj, b, ln, 4 * gq : 4 * gq + 4]
+    if return_tile_order:
+        return out, seen
+    return out

@@ -1,0 +1,81 @@
+"""M-sharded GEMM + all-gather (qqq_amd/parallel.py) with world_size 2 on the gloo backend (CPU).
+The per-rank compute is injected (here: the CPU oracle -- test infrastructure); on the GPU bench the same
+ShardedGemm wraps qqq_amd.qqq_gemm over RCCL."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from qqq_amd.parallel import ShardedGemm, chunk_bounds, shard_rows
+
+
+def test_shard_rows_partition():
+    for M in (0, 1, 7, 16, 4096, 4097):
+        for P in (1, 2, 3, 8):
+            spans = [shard_rows(M, P, r) for r in range(P)]
+            assert spans[0][0] == 0 and spans[-1][1] == M
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(P - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert chunk_bounds(5, 2) == [(0, 2), (2, 5)]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, M, chunks, q):
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from oracle import c_oracle as C, qqq_ref as R
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        N, K = 128, 256
+        rng = np.random.default_rng(5)  # same data on every rank: weights replicated
+        codes = rng.integers(-8, 8, size=(K, N), dtype=np.int8)
+        B = R.pack_codes(codes, False)
+        A = rng.integers(-128, 128, size=(M, K), dtype=np.int8)
+        s1 = (rng.random((M, 1), dtype=np.float32) * 0.05 + 0.01)
+        s2 = (rng.random((1, N), dtype=np.float32) * 0.01 + 0.001)
+        full = C.qqq_gemm(A, B, s1, s2, None)
+
+        def gemm_fn(a_rows, s1_rows, d_out):
+            d = C.qqq_gemm(a_rows.numpy(), B, s1_rows.numpy(), s2, None)
+            d_out.copy_(torch.from_numpy(d.copy()))
+
+        r0, r1 = shard_rows(M, world, rank)
+        sg = ShardedGemm(gemm_fn, chunks=chunks)
+        D = sg(torch.from_numpy(A[r0:r1].copy()), torch.from_numpy(s1[r0:r1].copy()), M, N)
+        ok = np.array_equal(D.numpy().view(np.uint16), full.view(np.uint16))
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("M,chunks", [(64, 2), (37, 3), (1, 2)])
+def test_sharded_gemm_all_gather_gloo(M, chunks):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, M, chunks, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = dict(q.get(timeout=5) for _ in range(world))
+    assert res == {0: True, 1: True}
