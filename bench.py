@@ -1,0 +1,383 @@
+#!/usr/bin/env python3
+"""bench.py -- W4A8 GEMM throughput on MI355X behind QQQ's `qqq_gemm` (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One STEP = one pass of the hot path over the BASELINE sweep (configs[1]): five `qqq_gemm` calls,
+per-channel W4A8, M in {1,16,128,1024,4096}, N=8192, K=21760, on synthetic int8 activations (full int8
+range, produced by the fused dynamic_quant of N(0,1) fp16 tokens) and random int4 weights, all resident
+in HBM before the timed region.  Consecutive calls use DIFFERENT 89 MB weight buffers (5 of them, 445 MB
+> the 256 MiB Infinity Cache) so that "HBM GB/s" is not an L3 number.  `value` = sum(2*M*N*K) / time.
+
+N > 1 (BASELINE configs[4]): same sweep, rows of every point with M >= 64*N sharded over the ranks
+(weights replicated), output shards all-gathered over RCCL/xGMI, chunk-pipelined against the GEMM
+(qqq_amd/parallel.py); smaller points are computed redundantly on every rank (no collective).  Strong
+scaling: the total work is fixed.
+
+Extra objects on the JSON line: `roofline` (dominant kernel = the tiled MFMA kernel at M=4096, durations
+from HIP event pairs recorded on the launch stream inside this process), `roofline_hbm` (the HBM-bound
+stream kernel at M=16), `cpu_baseline` (the C oracle timed on the host cores, bounded sample) and
+`per_m` (per sweep point: us, TOPS, GB/s, speedup vs torch fp16 GEMM on the same GPU).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_FULL, K_FULL = 8192, 21760
+SWEEP_M = (1, 16, 128, 1024, 4096)
+NBUF = 5
+MAX_PAR = 16
+PEAK_MFMA_TOPS = 5033.0  # dense int8: 256 CU x 2.4 GHz x 8192 op/clk/CU (MI355X_MICROARCH.md, = 2x bf16 2.5 PF)
+PEAK_HBM_GBS = 8000.0    # HBM3E spec; ~6300 achievable (MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes(M, N, K, grouped=False):
+    b = M * K + K * N // 2 + 2 * M * N + 4 * M + 4 * N
+    if grouped:
+        b += 2 * (K // 128) * N
+    return b
+
+
+def algorithmic_ops(M, N, K):
+    return 2 * M * N * K
+
+
+def make_weights(dev, grouped, nbuf, seed=0, N=N_FULL, K=K_FULL):
+    from qqq_amd import pack as P
+
+    g = torch.Generator(device=dev).manual_seed(seed)
+    Bs = []
+    for i in range(nbuf):
+        if grouped:
+            codes = torch.randint(0, 16, (K, N), generator=g, dtype=torch.int8, device=dev)
+        else:
+            codes = torch.randint(-7, 8, (K, N), generator=g, dtype=torch.int8, device=dev)
+        Bs.append(P.pack_codes(codes, grouped))
+        del codes
+    s2 = (torch.rand((1, N), generator=g, device=dev) * 2e-4 + 1e-5).to(torch.float32)
+    s3 = None
+    if grouped:
+        s3 = (torch.rand((K // 128, N), generator=g, device=dev) * 15.0 + 0.5).to(torch.float16)
+    return Bs, s2, s3
+
+
+def make_tokens(dev, M, seed, K=K_FULL):
+    from qqq_amd import dynamic_quant
+
+    g = torch.Generator(device=dev).manual_seed(100 + seed)
+    x = torch.randn((M, K), generator=g, device=dev, dtype=torch.float32).to(torch.float16)
+    xq, s1 = dynamic_quant(x)
+    return xq, s1
+
+
+class Layer:
+    """device buffers of one QuantLinear-like layer + the rotating weight copies"""
+
+    def __init__(self, dev, grouped=False, nbuf=NBUF, N=N_FULL, K=K_FULL):
+        self.dev, self.N, self.K, self.grouped = dev, N, K, grouped
+        self.Bs, self.s2, s3 = make_weights(dev, grouped, nbuf, N=N, K=K)
+        self.s3 = s3 if s3 is not None else torch.empty(0, dtype=torch.float16, device=dev)
+        self.C = torch.zeros((MAX_PAR * 64, N), dtype=torch.int32, device=dev)
+        self.ws = torch.zeros(N // 128 * MAX_PAR, dtype=torch.int32, device=dev)
+        self.groupsize = 128 if grouped else -1
+
+    def time_calls(self, A, s1, D, iters, tune=None, rotate=True):
+        """per-call durations (ms) from HIP event pairs recorded natively around each launch"""
+        from qqq_amd import _lib
+
+        L = _lib.lib()
+        nb = len(self.Bs) if rotate else 1
+        arr = (ctypes.c_void_p * nb)(*[b.data_ptr() for b in self.Bs[:nb]])
+        out = (ctypes.c_float * iters)()
+        tn = None
+        if tune:
+            tn = _lib.QQQTune()
+            for k, v in tune.items():
+                setattr(tn, k, int(v))
+        st = torch.cuda.current_stream(self.dev).cuda_stream
+        rc = L.qqq_bench_gemm(
+            A.data_ptr(), arr, nb, self.C.data_ptr(), D.data_ptr(), s1.data_ptr(), self.s2.data_ptr(),
+            self.s3.data_ptr() if self.s3.numel() else None, A.shape[0], self.N, self.K, self.ws.data_ptr(),
+            self.groupsize, self.dev.index or 0, ctypes.c_void_p(st), MAX_PAR,
+            ctypes.byref(tn) if tn is not None else None, iters, out,
+        )
+        if rc:
+            raise RuntimeError(f"qqq_bench_gemm rc={rc}: {_lib.last_error()}")
+        return np.array(out[:], dtype=np.float64)
+
+
+def fp16_gemm_us(dev, M, iters=10, N=N_FULL, K=K_FULL):
+    """torch fp16 GEMM (hipBLASLt) on the same GPU, weights rotated over 2 x 356 MB buffers"""
+    Ws = [torch.randn((K, N), device=dev, dtype=torch.float16) * 0.02 for _ in range(2)]
+    x = torch.randn((M, K), device=dev, dtype=torch.float16)
+    for i in range(3):
+        torch.matmul(x, Ws[i % 2])
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for i, (a, b) in enumerate(evs):
+        a.record()
+        torch.matmul(x, Ws[i % 2])
+        b.record()
+    torch.cuda.synchronize()
+    t = np.array([a.elapsed_time(b) for a, b in evs]) * 1e3
+    del Ws
+    return float(np.median(t))
+
+
+def cpu_baseline(sample_rows=64, budget_s=12.0):
+    """The C oracle (restatement of the reference arithmetic, `kind: port`) on the host cores, on a bounded
+    sample of the same workload: `sample_rows` tokens x the full N x K weight matrix, repeated until
+    ~budget_s of CPU work.  Also times torch's fp16 CPU GEMM (north_star's "PyTorch fp16 CPU GEMM")."""
+    from oracle import c_oracle as C
+    from oracle import qqq_ref as R
+
+    rng = np.random.default_rng(0)
+    codes = rng.integers(-7, 8, size=(K_FULL, N_FULL), dtype=np.int8)
+    B = C.pack(codes, False)
+    A = rng.integers(-128, 128, size=(sample_rows, K_FULL), dtype=np.int8)
+    s1 = (rng.random((sample_rows, 1), dtype=np.float32) * 0.05 + 0.001)
+    s2 = (rng.random((1, N_FULL), dtype=np.float32) * 2e-4 + 1e-5)
+    C.qqq_gemm(A[:4], B, s1[:4], s2)  # warm (page-in, omp pool)
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        C.qqq_gemm(A, B, s1, s2)
+        reps += 1
+        if time.perf_counter() - t0 > budget_s or reps >= 20:
+            break
+    dt = (time.perf_counter() - t0) / reps
+    tops = algorithmic_ops(sample_rows, N_FULL, K_FULL) / dt / 1e12
+    cores = os.cpu_count() or 1
+    out = {
+        "value": tops, "unit": "TOPS", "cores": cores, "kind": "port",
+        "sample": f"C oracle (oracle/qqq_oracle.c, OpenMP, includes int4 unpack) M={sample_rows} N={N_FULL} K={K_FULL} per-channel, {reps} reps, {dt*1e3:.0f} ms each",
+    }
+    try:
+        torch.set_num_threads(cores)
+        W = (torch.randn((N_FULL, K_FULL)) * 0.02).to(torch.float16)
+        res = {}
+        for M in (1, 16, 128):
+            x = torch.randn((M, K_FULL)).to(torch.float16)
+            torch.matmul(x, W.t())
+            ts = []
+            for _ in range(3):
+                t1 = time.perf_counter()
+                torch.matmul(x, W.t())
+                ts.append(time.perf_counter() - t1)
+            res[str(M)] = {"ms": float(np.median(ts) * 1e3), "tflops": algorithmic_ops(M, N_FULL, K_FULL) / np.median(ts) / 1e12}
+        out["torch_fp16_cpu_gemm"] = {"threads": torch.get_num_threads(), "per_m": res}
+    except Exception as e:  # pragma: no cover
+        out["torch_fp16_cpu_gemm"] = {"error": str(e)}
+    return out
+
+
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-fp16", action="store_true", help="skip the torch fp16 GPU GEMM comparison")
+    ap.add_argument("--detail-iters", type=int, default=30)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+
+    from qqq_amd import ops
+    from qqq_amd.parallel import ShardedGemm, shard_rows
+
+    layer = Layer(dev, grouped=False)
+    toks = {M: make_tokens(dev, M, M) for M in SWEEP_M}
+    Dfull = {M: torch.empty((M, N_FULL), dtype=torch.float16, device=dev) for M in SWEEP_M}
+
+    # ---- one step = the 5-call sweep ----
+    if world == 1:
+        def step_body():
+            for j, M in enumerate(SWEEP_M):
+                A, s1 = toks[M]
+                ops.qqq_gemm(A, layer.Bs[j % NBUF], layer.C, Dfull[M], s1, layer.s2, layer.s3, layer.ws, -1, -1, -1, MAX_PAR)
+    else:
+        sharded = {}
+        for j, M in enumerate(SWEEP_M):
+            if M >= 64 * world:
+                r0, r1 = shard_rows(M, world, rank)
+                A, s1 = toks[M]
+                Bj = layer.Bs[j % NBUF]
+
+                def gemm_fn(a_rows, s1_rows, d_rows, Bj=Bj):
+                    ops.qqq_gemm(a_rows, Bj, layer.C, d_rows, s1_rows, layer.s2, layer.s3, layer.ws, -1, -1, -1, MAX_PAR)
+
+                sharded[M] = (ShardedGemm(gemm_fn, chunks=2), A[r0:r1].contiguous(), s1[r0:r1].contiguous())
+
+        def step_body():
+            for j, M in enumerate(SWEEP_M):
+                if M in sharded:
+                    sg, a_loc, s1_loc = sharded[M]
+                    sg(a_loc, s1_loc, M, N_FULL, Dfull[M])
+                else:
+                    A, s1 = toks[M]
+                    ops.qqq_gemm(A, layer.Bs[j % NBUF], layer.C, Dfull[M], s1, layer.s2, layer.s3, layer.ws, -1, -1, -1, MAX_PAR)
+
+    # launch-bound inner loop -> hipGraph (single GPU; collectives are left eager)
+    step_body()
+    torch.cuda.synchronize()
+    graph = None
+    if world == 1:
+        try:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                step_body()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                step_body()
+            g.replay()
+            torch.cuda.synchronize()
+            graph = g
+        except Exception as e:  # pragma: no cover
+            print(f"[bench] hipGraph capture unavailable ({e}); running eager", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+
+    def run_step():
+        if graph is not None:
+            graph.replay()
+        else:
+            step_body()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        run_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    total_ops = sum(algorithmic_ops(M, N_FULL, K_FULL) for M in SWEEP_M)
+    ms_per_step = dt / args.steps * 1e3
+    value = total_ops * args.steps / dt / 1e12
+
+    result = {
+        "metric": "W4A8 GEMM TOPS + speedup vs fp16, M in {1..4096} N=8192 K=21760",
+        "value": value, "unit": "TOPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "i8 x i4 -> i32 -> f16", "data": "synthetic",
+        "config": {
+            "workload": "qqq_gemm per-channel sweep M in {1,16,128,1024,4096}, N=8192, K=21760 (BASELINE configs[1]); one step = the 5 calls",
+            "weights": f"{NBUF} rotating packed-int4 buffers of 89 MB (cold Infinity Cache)",
+            "launch": "hipGraph replay" if graph is not None else "eager",
+            "parallelism": "single GPU" if world == 1 else f"M-sharded over {world} GPUs + RCCL all-gather of fp16 shards (points with M >= {64*world})",
+        },
+    }
+
+    if rank == 0 and world == 1:
+        # ---- per-point detail, HIP event pairs around every launch (cold = rotating weights) ----
+        per_m = {}
+        it = args.detail_iters
+        for M in SWEEP_M:
+            A, s1 = toks[M]
+            layer.time_calls(A, s1, Dfull[M], 3)
+            cold = layer.time_calls(A, s1, Dfull[M], it, rotate=True) * 1e3
+            warm = layer.time_calls(A, s1, Dfull[M], it, rotate=False) * 1e3
+            us = float(np.mean(cold))
+            entry = {
+                "us": us, "us_median": float(np.median(cold)), "us_min": float(np.min(cold)), "us_warm_l3": float(np.mean(warm)),
+                "tops": algorithmic_ops(M, N_FULL, K_FULL) / us / 1e6,
+                "gbs": algorithmic_bytes(M, N_FULL, K_FULL) / us / 1e3,
+            }
+            if not args.no_fp16:
+                f = fp16_gemm_us(dev, M)
+                entry["fp16_gemm_us"] = f
+                entry["speedup_vs_fp16"] = f / us
+            per_m[str(M)] = entry
+        result["per_m"] = per_m
+        a = per_m["4096"]
+        result["roofline"] = {
+            "kernel": "qqq_tiled_kernel (M=4096)", "bound": "mfma", "achieved": a["tops"], "peak": PEAK_MFMA_TOPS,
+            "unit": "TOPS", "frac": a["tops"] / PEAK_MFMA_TOPS, "traffic": None,
+            "avg_launch_us": a["us"],
+        }
+        h = per_m["16"]
+        result["roofline_hbm"] = {
+            "kernel": "qqq_stream_kernel (M=16)", "bound": "hbm", "achieved": h["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": h["gbs"] / PEAK_HBM_GBS, "traffic": None, "avg_launch_us": h["us"],
+        }
+        # per-group (BASELINE configs[2]) detail
+        try:
+            del layer.Bs
+            torch.cuda.empty_cache()
+            lg = Layer(dev, grouped=True)
+            pg = {}
+            for M in SWEEP_M:
+                A, s1 = toks[M]
+                lg.time_calls(A, s1, Dfull[M], 3)
+                cold = lg.time_calls(A, s1, Dfull[M], it, rotate=True) * 1e3
+                us = float(np.mean(cold))
+                pg[str(M)] = {"us": us, "tops": algorithmic_ops(M, N_FULL, K_FULL) / us / 1e6,
+                              "gbs": algorithmic_bytes(M, N_FULL, K_FULL, True) / us / 1e3}
+                if "fp16_gemm_us" in per_m[str(M)]:
+                    pg[str(M)]["speedup_vs_fp16"] = per_m[str(M)]["fp16_gemm_us"] / us
+            result["per_m_g128"] = pg
+        except Exception as e:  # pragma: no cover
+            result["per_m_g128"] = {"error": str(e)}
+        if not args.no_cpu:
+            result["cpu_baseline"] = cpu_baseline()
+            result["cpu_baseline"]["cpu_model"] = cpu_model_name()
+        result["device"] = torch.cuda.get_device_name(dev)
+
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

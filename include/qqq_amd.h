@@ -85,6 +85,15 @@ int qqq_dynamic_quant(const void* x, void* xq, void* s1, int m, int k, int dev, 
 /* out[i,j] += bias[j] in fp16 (the reference's `D + self.bias`, qlinear_marlin.py:287). */
 int qqq_add_bias(void* D, const void* bias, int m, int n, int dev, void* stream);
 
+/* Measurement helper for bench.py: runs `iters` calls of qqq_w4a8_gemm_ex back to back on `stream`,
+ * call i using the weight buffer Bs[i % nB] (rotate >= 4 x 89 MB buffers to defeat the 256 MiB
+ * Infinity Cache), each bracketed by its own hipEvent pair recorded on `stream`; synchronises the
+ * stream and writes the `iters` durations in milliseconds to ms_each (host memory). */
+int qqq_bench_gemm(const void* A, const void* const* Bs, int nB, void* C, void* D, const void* s1,
+                   const void* s2, const void* s3, int prob_m, int prob_n, int prob_k, void* workspace,
+                   int groupsize, int dev, void* stream, int max_par, const qqq_tune_t* tune, int iters,
+                   float* ms_each);
+
 int qqq_amd_abi_version(void);
 const char* qqq_amd_last_error(void);
 

@@ -47,6 +47,9 @@ def lib():
     L.qqq_probe_mfma.restype = ci
     L.qqq_probe_glds.argtypes = [vp, vp, vp, ci, vp]
     L.qqq_probe_glds.restype = ci
+    L.qqq_bench_gemm.argtypes = [vp, ctypes.POINTER(vp), ci, vp, vp, vp, vp, vp, ci, ci, ci, vp, ci, ci, vp, ci,
+                                 ctypes.POINTER(QQQTune), ci, ctypes.POINTER(ctypes.c_float)]
+    L.qqq_bench_gemm.restype = ci
     L.qqq_amd_abi_version.restype = ci
     L.qqq_amd_last_error.restype = ctypes.c_char_p
     if L.qqq_amd_abi_version() != 1:

@@ -928,13 +928,15 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
     const int KS = K / 64;
     int waves = t.waves ? t.waves : 8;
     if (waves != 4 && waves != 8 && waves != 16) waves = 8;
+    if (waves == 16 && mt > 1) waves = 8;  // 1024-thread blocks cap VGPRs at 128: only the MT=1 body fits
     ksplit = t.ksplit;
     if (ksplit <= 0) {
       // fill ~256 CUs x 8 waves; keep >= 2 steps per wave
       const long long want_wg = 256LL * 8 / waves;
       ksplit = (int)((want_wg + (long long)strips * mblocks - 1) / ((long long)strips * mblocks));
+      ksplit = clampi(ksplit, 1, KS / (2 * waves) > 0 ? KS / (2 * waves) : 1);
     }
-    ksplit = clampi(ksplit, 1, KS / (2 * waves) > 0 ? KS / (2 * waves) : 1);
+    ksplit = clampi(ksplit, 1, KS);
     if (!have_scratch) ksplit = 1;
     if (ksplit > 1 && (long long)ksplit * M > cap_rows) ksplit = (int)(cap_rows / M);
     if (ksplit < 1) ksplit = 1;
@@ -971,8 +973,11 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
   const bool glds = (t.glds == 0) ? true : (t.glds == 1);
   const long long tiles = (long long)((M + bm - 1) / bm) * ((N + 255) / 256);
   ksplit = t.ksplit;
-  if (ksplit <= 0) ksplit = tiles >= 192 ? 1 : (int)((256 + tiles - 1) / tiles);
-  ksplit = clampi(ksplit, 1, (K / 128) / 4 > 0 ? (K / 128) / 4 : 1);
+  if (ksplit <= 0) {
+    ksplit = tiles >= 192 ? 1 : (int)((256 + tiles - 1) / tiles);
+    ksplit = clampi(ksplit, 1, (K / 128) / 4 > 0 ? (K / 128) / 4 : 1);
+  }
+  ksplit = clampi(ksplit, 1, K / 128);
   if (!have_scratch) ksplit = 1;
   if (ksplit > 1 && (long long)ksplit * M > cap_rows) ksplit = (int)(cap_rows / M);
   if (ksplit < 1) ksplit = 1;
@@ -1072,6 +1077,42 @@ extern "C" int qqq_probe_glds(const void* src, const void* perm, void* dst, int 
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail_hip(e, "probe launch");
   return QQQ_OK;
+}
+
+extern "C" int qqq_bench_gemm(const void* A, const void* const* Bs, int nB, void* C, void* D,
+                              const void* s1, const void* s2, const void* s3, int prob_m, int prob_n,
+                              int prob_k, void* workspace, int groupsize, int dev, void* stream,
+                              int max_par, const qqq_tune_t* tune, int iters, float* ms_each) {
+  g_err[0] = 0;
+  if (iters <= 0 || nB <= 0 || !Bs || !ms_each) return QQQ_ERR_ARG;
+  DeviceGuard guard(dev);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipEvent_t* ev = new hipEvent_t[2 * iters];
+  int made = 0, rc = QQQ_OK;
+  for (; made < 2 * iters; ++made)
+    if (hipEventCreate(&ev[made]) != hipSuccess) {
+      rc = fail_hip(hipGetLastError(), "hipEventCreate");
+      break;
+    }
+  if (rc == QQQ_OK) {
+    for (int i = 0; i < iters && rc == QQQ_OK; ++i) {
+      (void)hipEventRecord(ev[2 * i], st);
+      rc = qqq_w4a8_gemm_ex(A, Bs[i % nB], C, D, s1, s2, s3, prob_m, prob_n, prob_k, workspace, groupsize,
+                            dev, stream, -1, -1, -1, max_par, tune, nullptr);
+      (void)hipEventRecord(ev[2 * i + 1], st);
+    }
+    hipError_t e = hipStreamSynchronize(st);
+    if (e != hipSuccess && rc == QQQ_OK) rc = fail_hip(e, "hipStreamSynchronize");
+    if (rc == QQQ_OK)
+      for (int i = 0; i < iters; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]) != hipSuccess) ms = -1.f;
+        ms_each[i] = ms;
+      }
+  }
+  for (int i = 0; i < made; ++i) (void)hipEventDestroy(ev[i]);
+  delete[] ev;
+  return rc;
 }
 
 extern "C" int qqq_amd_abi_version(void) { return QQQ_AMD_ABI_VERSION; }

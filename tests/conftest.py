@@ -17,3 +17,22 @@ def golden():
     import numpy as np
 
     return np.load(os.path.join(ROOT, "tests", "golden", "qqq_golden.npz"))
+
+
+def gpu_dump(name, **arrays):
+    """Save diagnostics under gpurun_out/ (merged back from the GPU box) so a failing GPU test can be
+    analysed offline."""
+    import numpy as np
+
+    d = os.path.join(ROOT, "gpurun_out", "diag")
+    os.makedirs(d, exist_ok=True)
+    np.savez_compressed(os.path.join(d, name + ".npz"), **arrays)
+
+
+@pytest.fixture(scope="session")
+def dev():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")

@@ -1,0 +1,67 @@
+"""Shared helpers for the -m gpu parity tests (call the product through its C-ABI / operator layer)."""
+import numpy as np
+import torch
+
+from qqq_amd import ops
+
+
+def ulp_distance(a: np.ndarray, b: np.ndarray) -> int:
+    """max distance in fp16 ulps between two fp16 arrays (monotone integer mapping)."""
+    def key(x):
+        u = x.view(np.uint16).astype(np.int32)
+        return np.where(u & 0x8000, 0x8000 - u, u)
+    if a.size == 0:
+        return 0
+    return int(np.abs(key(a) - key(b)).max())
+
+
+class GemmHarness:
+    """Owns the device buffers of one layer (as QuantLinear would) and runs qqq_gemm variants."""
+
+    def __init__(self, B, s2, s3, dev, max_par=16):
+        self.dev = dev
+        self.B = torch.from_numpy(np.ascontiguousarray(B)).to(dev) if isinstance(B, np.ndarray) else B
+        self.s2 = torch.from_numpy(np.ascontiguousarray(s2, dtype=np.float32)).to(dev) if isinstance(s2, np.ndarray) else s2
+        if s3 is None or (isinstance(s3, np.ndarray) and s3.size == 0):
+            self.s3 = torch.empty(0, dtype=torch.float16, device=dev)
+        else:
+            self.s3 = torch.from_numpy(np.ascontiguousarray(s3)).to(dev) if isinstance(s3, np.ndarray) else s3
+        self.N = self.B.shape[1] // 2
+        self.K = self.B.shape[0] * 16
+        self.max_par = max_par
+        # poison the scratch: the kernels must not depend on its previous contents
+        self.C = torch.full((max_par * 64, self.N), 0x7B7B7B7B, dtype=torch.int32, device=dev)
+        self.ws = torch.zeros(max(self.N // 128, 1) * max_par, dtype=torch.int32, device=dev)
+
+    def run(self, A, s1, tune=None, want_acc=True):
+        A = torch.from_numpy(np.ascontiguousarray(A)).to(self.dev) if isinstance(A, np.ndarray) else A
+        s1 = torch.from_numpy(np.ascontiguousarray(s1, dtype=np.float32)).to(self.dev) if isinstance(s1, np.ndarray) else s1
+        M = A.shape[0]
+        D = torch.full((M, self.N), float("nan"), dtype=torch.float16, device=self.dev)
+        acc = torch.full((M, self.N), -1, dtype=torch.int32, device=self.dev) if want_acc else None
+        ops.qqq_gemm_ex(A, self.B, self.C, D, s1, self.s2, self.s3, self.ws, -1, -1, -1, self.max_par,
+                        tune=tune, acc_out=acc)
+        torch.cuda.synchronize()
+        assert int(self.ws.abs().sum().item()) == 0, "workspace must be all-zero on return"
+        return D.cpu().numpy(), (acc.cpu().numpy() if want_acc else None)
+
+
+def variants(M, K, N):
+    """tuning variants that are valid for this problem"""
+    v = [dict(kernel=1, ksplit=1, waves=4), dict(kernel=1, ksplit=1, waves=8)]
+    if K // 64 >= 4:
+        v += [dict(kernel=1, ksplit=2, waves=4, fused=1), dict(kernel=1, ksplit=2, waves=4, fused=2)]
+    if K // 64 >= 8:
+        v += [dict(kernel=1, ksplit=3, waves=8, fused=1)]
+    if M <= 16:
+        v += [dict(kernel=1, ksplit=1, waves=16)]
+    v += [dict(kernel=1)]  # auto split
+    if K % 128 == 0:
+        for bm in (64, 128, 256):
+            for glds in (1, 2):
+                v.append(dict(kernel=2, bm=bm, glds=glds, ksplit=1))
+        if K // 128 >= 8:
+            v.append(dict(kernel=2, bm=128, glds=1, ksplit=2))
+            v.append(dict(kernel=2, bm=64, glds=2, ksplit=2))
+    v.append(dict())  # fully automatic (== qqq_w4a8_gemm)
+    return v

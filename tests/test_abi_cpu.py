@@ -22,7 +22,7 @@ def test_exports_every_declared_symbol(L):
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     names = set(re.findall(r"\b(qqq_[a-z0-9_]+)\s*\(", hdr))
     assert {"qqq_w4a8_gemm", "qqq_w4a8_gemm_ex", "qqq_dynamic_quant", "qqq_add_bias", "qqq_amd_abi_version",
-            "qqq_amd_last_error", "qqq_probe_mfma", "qqq_probe_glds"} <= names
+            "qqq_amd_last_error", "qqq_probe_mfma", "qqq_probe_glds", "qqq_bench_gemm"} <= names
     for n in names:
         assert hasattr(L, n), n
     assert L.qqq_amd_abi_version() == 1

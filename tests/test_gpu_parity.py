@@ -1,0 +1,161 @@
+"""Parity of the HIP path (through the C-ABI) with the CPU oracle: int32 accumulators bit-exact,
+fp16 outputs within 1 ulp (tolerance from BASELINE.json north_star; 0 ulp is what we expect and
+report).  Small cases: committed golden fixtures, every kernel variant.  BASELINE sizes: C oracle on
+full outputs (m <= 128) or a row subsample (rows are independent), plus size-independent properties."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import gpu_dump
+from gpu_util import GemmHarness, ulp_distance, variants
+
+pytestmark = pytest.mark.gpu
+MAX_ULP = 1  # north_star: "fp16 outputs within 1 ulp of the reference dequant"
+
+
+def _cases(golden):
+    for tag in golden["cases"]:
+        yield str(tag)
+
+
+def test_golden_fixtures_all_variants(golden, dev):
+    worst = 0
+    failures = []
+    for tag in _cases(golden):
+        h = GemmHarness(golden[f"{tag}/ref_B"], golden[f"{tag}/ref_s_channel"], golden[f"{tag}/ref_s_group"], dev)
+        for M in golden[f"{tag}/Ms"]:
+            xq, s1 = golden[f"{tag}/m{M}/ref_xq"], golden[f"{tag}/m{M}/ref_s1"]
+            eacc, eD = golden[f"{tag}/m{M}/oracle_acc"], golden[f"{tag}/m{M}/oracle_D"]
+            for tune in variants(int(M), h.K, h.N):
+                D, acc = h.run(xq, s1, tune)
+                ok_acc = np.array_equal(acc, eacc)
+                ulp = ulp_distance(D, eD) if not np.isnan(D.astype(np.float32)).any() else 10**6
+                worst = max(worst, ulp if ok_acc else 0)
+                if not ok_acc or ulp > MAX_ULP:
+                    failures.append((tag, int(M), tune, bool(ok_acc), ulp))
+                    if len(failures) <= 6:
+                        gpu_dump(f"parity_{tag}_m{M}_{len(failures)}", acc=acc, eacc=eacc, D=D, eD=eD,
+                                 tune=np.array(str(tune)))
+    print("golden parity: worst fp16 ulp distance =", worst, "failures =", len(failures))
+    assert not failures, failures[:12]
+    assert worst == 0  # stronger than the stated tolerance: the epilogue is bit-identical
+
+
+def test_scratch_reuse_and_repeated_calls(golden, dev):
+    """Same layer buffers (C, workspace) reused across calls with different tokens, split-K in-launch
+    reduction included: no call may see stale partial sums of the previous one."""
+    tag = "g-1_n128_k256"
+    h = GemmHarness(golden[f"{tag}/ref_B"], golden[f"{tag}/ref_s_channel"], golden[f"{tag}/ref_s_group"], dev)
+    Ms = [int(m) for m in golden[f"{tag}/Ms"]]
+    for rep in range(3):
+        for M in Ms + Ms[::-1]:
+            for tune in (dict(kernel=1, ksplit=2, waves=4, fused=1), dict(kernel=1, ksplit=2, waves=4, fused=2),
+                         dict(kernel=2, bm=64, glds=1, ksplit=2)):
+                D, acc = h.run(golden[f"{tag}/m{M}/ref_xq"], golden[f"{tag}/m{M}/ref_s1"], tune)
+                assert np.array_equal(acc, golden[f"{tag}/m{M}/oracle_acc"]), (rep, M, tune)
+                assert ulp_distance(D, golden[f"{tag}/m{M}/oracle_D"]) == 0
+
+
+def test_empty_and_error_behaviour(golden, dev):
+    from qqq_amd import qqq_gemm
+
+    tag = "g-1_n128_k256"
+    h = GemmHarness(golden[f"{tag}/ref_B"], golden[f"{tag}/ref_s_channel"], golden[f"{tag}/ref_s_group"], dev)
+    A = torch.zeros((0, h.K), dtype=torch.int8, device=dev)
+    D = torch.zeros((0, h.N), dtype=torch.float16, device=dev)
+    s1 = torch.zeros((0, 1), dtype=torch.float32, device=dev)
+    qqq_gemm(A, h.B, h.C, D, s1, h.s2, h.s3, h.ws, -1, -1, -1, 16)  # m == 0: success, nothing launched
+    A = torch.zeros((4, h.K), dtype=torch.int8, device=dev)
+    D = torch.zeros((4, h.N), dtype=torch.float16, device=dev)
+    s1 = torch.ones((4, 1), dtype=torch.float32, device=dev)
+    with pytest.raises(RuntimeError, match="not compatible with thread_k=32"):
+        qqq_gemm(A, h.B, h.C, D, s1, h.s2, h.s3, h.ws, 32, 128, -1, 16)
+    with pytest.raises(RuntimeError, match="No kernel implementation for thread_k=64, thread_n=128"):
+        qqq_gemm(A, h.B, h.C, D, s1, h.s2, h.s3, h.ws, 64, 128, -1, 16)
+    qqq_gemm(A, h.B, h.C, D, s1, h.s2, h.s3, h.ws, 128, 128, -1, 16)  # a reference-valid user config
+    torch.cuda.synchronize()
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE sizes: N=8192, K=21760
+# ------------------------------------------------------------------------------------------------
+N_FULL, K_FULL = 8192, 21760
+
+
+def _full_layer(dev, grouped, seed=0):
+    from qqq_amd import pack as P
+
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    if grouped:
+        codes = torch.randint(0, 16, (K_FULL, N_FULL), generator=g, dtype=torch.int8)
+        s3 = (torch.rand((K_FULL // 128, N_FULL), generator=g) * 15.0 + 0.5).to(torch.float16)  # |(u-8)*s| <= 124
+    else:
+        codes = torch.randint(-7, 8, (K_FULL, N_FULL), generator=g, dtype=torch.int8)
+        s3 = None
+    s2 = (torch.rand((1, N_FULL), generator=g) * 2e-4 + 1e-5).to(torch.float32)
+    B = P.pack_codes(codes.to(dev), grouped)
+    return B, s2, s3
+
+
+def _tokens(M, seed):
+    g = torch.Generator(device="cpu").manual_seed(1000 + seed)
+    A = torch.randint(-128, 128, (M, K_FULL), generator=g, dtype=torch.int8)
+    s1 = (torch.rand((M, 1), generator=g) * 0.05 + 0.001).to(torch.float32)
+    return A, s1
+
+
+@pytest.mark.parametrize("grouped", [False, True])
+def test_baseline_sizes_against_oracle(grouped, dev):
+    from oracle import c_oracle as C
+
+    B, s2, s3 = _full_layer(dev, grouped)
+    h = GemmHarness(B, s2, None if s3 is None else s3.to(dev), dev)
+    Bn = B.cpu().numpy()
+    s2n = s2.numpy()
+    s3n = None if s3 is None else s3.numpy()
+    ref_rows = {}
+    for M in (1, 16, 128, 1024, 4096):
+        A, s1 = _tokens(M, M)
+        D, acc = h.run(A.numpy(), s1.numpy(), None)  # fully automatic dispatch, as a caller would
+        rows = np.arange(M) if M <= 128 else np.unique(np.r_[0, M - 1, np.random.default_rng(M).integers(0, M, 46)])
+        eD, eacc = C.qqq_gemm(A.numpy()[rows], Bn, s1.numpy()[rows], s2n, s3n, return_acc=True)
+        assert np.array_equal(acc[rows], eacc), (grouped, M)
+        assert ulp_distance(D[rows], eD) == 0, (grouped, M)
+        assert not np.isnan(D.astype(np.float32)).any()
+        ref_rows[M] = (A, s1, D, acc)
+    # property: the two kernel families agree bit-for-bit on the same tokens at full size
+    A, s1, D, acc = ref_rows[4096]
+    for lo in (0, 2048, 4096 - 16):
+        Ds, accs = h.run(A[lo : lo + 16].numpy(), s1[lo : lo + 16].numpy(), dict(kernel=1))
+        assert np.array_equal(accs, acc[lo : lo + 16]) and np.array_equal(Ds.view(np.uint16), D[lo : lo + 16].view(np.uint16))
+    # property: token order does not matter (rows independent) -- permute the M=128 batch
+    A, s1, D, acc = ref_rows[128]
+    perm = np.random.default_rng(3).permutation(128)
+    Dp, accp = h.run(A.numpy()[perm], s1.numpy()[perm], None)
+    assert np.array_equal(accp, acc[perm]) and np.array_equal(Dp.view(np.uint16), D[perm].view(np.uint16))
+    # property: power-of-two rescaling of the token scales is exact in fp16 away from overflow/subnormals
+    A, s1, D, acc = ref_rows[16]
+    D2, _ = h.run(A.numpy(), (s1 * 0.5).numpy(), None)
+    fin = np.abs(D.astype(np.float32)) > 2e-4
+    assert np.array_equal((D2.astype(np.float32) * 2)[fin], D.astype(np.float32)[fin])
+
+
+def test_llama7b_linear_shapes(dev):
+    """BASELINE config 4 shapes (llama-2-7b linears), batch*seq rows subsampled for the CPU oracle."""
+    from oracle import c_oracle as C
+    from qqq_amd import pack as P
+
+    for (N, K) in ((4096, 4096), (11008, 4096), (4096, 11008)):
+        g = torch.Generator(device="cpu").manual_seed(N + K)
+        codes = torch.randint(-7, 8, (K, N), generator=g, dtype=torch.int8)
+        B = P.pack_codes(codes.to(dev), False)
+        s2 = (torch.rand((1, N), generator=g) * 2e-4 + 1e-5).to(torch.float32)
+        h = GemmHarness(B, s2, None, dev)
+        for M in (8, 1024):
+            A = torch.randint(-128, 128, (M, K), generator=g, dtype=torch.int8)
+            s1 = (torch.rand((M, 1), generator=g) * 0.05 + 0.001).to(torch.float32)
+            D, acc = h.run(A.numpy(), s1.numpy(), None)
+            rows = np.arange(M) if M <= 64 else np.random.default_rng(M).integers(0, M, 32)
+            eD, eacc = C.qqq_gemm(A.numpy()[rows], B.cpu().numpy(), s1.numpy()[rows], s2.numpy(), None, return_acc=True)
+            assert np.array_equal(acc[rows], eacc), (N, K, M)
+            assert ulp_distance(D[rows], eD) == 0

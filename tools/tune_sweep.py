@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Times every kernel variant at the BASELINE sizes (cold: rotating weight buffers) and prints a table.
+Used to pick the host dispatch heuristics in qqq_w4a8.hip; output is kept under profiles/."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench as Bn  # noqa: E402
+
+
+def variants(M, grouped):
+    v = []
+    if M <= 128:
+        for waves in (4, 8, 16):
+            if waves == 16 and M > 16:
+                continue
+            for ks in (1, 2, 4, 8, 16, 32):
+                if ks * M > 1024:
+                    continue
+                for fused in ((1, 2) if ks > 1 else (1,)):
+                    v.append(dict(kernel=1, waves=waves, ksplit=ks, fused=fused))
+    if M >= 16:
+        for bm in (64, 128, 256):
+            if bm > 64 and M < bm // 2:
+                continue
+            for glds in (1, 2):
+                for ks in (1, 2, 4, 8, 16):
+                    if ks > 1 and ks * M > 1024:
+                        continue
+                    tiles = -(-M // bm) * 32
+                    if tiles * ks > 4096 or (ks > 1 and tiles >= 512):
+                        continue
+                    v.append(dict(kernel=2, bm=bm, glds=glds, ksplit=ks))
+    return v
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=8)
+    ap.add_argument("--ms", type=str, default="1,16,64,128,256,1024,4096")
+    ap.add_argument("--modes", type=str, default="pc,g128")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    Ms = [int(x) for x in args.ms.split(",")]
+    for mode in args.modes.split(","):
+        grouped = mode == "g128"
+        layer = Bn.Layer(dev, grouped=grouped)
+        for M in Ms:
+            A, s1 = Bn.make_tokens(dev, M, M)
+            D = torch.empty((M, Bn.N_FULL), dtype=torch.float16, device=dev)
+            rows = []
+            for tune in [None] + variants(M, grouped):
+                try:
+                    layer.time_calls(A, s1, D, 2, tune=tune)
+                    t = layer.time_calls(A, s1, D, args.iters, tune=tune) * 1e3
+                    rows.append((float(np.mean(t)), float(np.min(t)), tune))
+                except Exception as e:
+                    rows.append((float("inf"), float("inf"), dict(error=str(e), tune=tune)))
+            ops = Bn.algorithmic_ops(M, Bn.N_FULL, Bn.K_FULL)
+            byts = Bn.algorithmic_bytes(M, Bn.N_FULL, Bn.K_FULL, grouped)
+            auto = rows[0]
+            print(f"== mode={mode} M={M}: auto {auto[0]:.1f} us  ({ops/auto[0]/1e6:.1f} TOPS, {byts/auto[0]/1e3:.0f} GB/s)")
+            for mean, mn, tune in sorted(rows[1:], key=lambda r: r[0])[:12]:
+                print(f"   {mean:9.1f} us (min {mn:8.1f})  {ops/mean/1e6:8.1f} TOPS {byts/mean/1e3:7.0f} GB/s  {tune}")
+            sys.stdout.flush()
+        del layer
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
