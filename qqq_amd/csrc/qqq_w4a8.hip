@@ -103,6 +103,21 @@ __device__ __forceinline__ unsigned dequant_group4(const unsigned q, const h2 s)
          0x80808080u;
 }
 
+// LDS-DMA of 16 bytes per lane: LDS destination = lds_dst (wave-uniform byte address) + 16*lane, the
+// global source is per lane.  Issued through inline asm on purpose: hipcc cannot prove that the LDS
+// image being filled (stage buf^1) does not alias the ds_reads of the stage being consumed, and would
+// drain it with s_waitcnt vmcnt(0) before the first ds_read -- serialising load and compute.  Being asm,
+// these loads are invisible to the compiler's wait-count bookkeeping: the kernel waits for them itself
+// (one explicit vmcnt(0) in front of the stage barrier).  M0 is saved/restored around the DMA.
+__device__ __forceinline__ void glds16(const void* gsrc, const unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+
 template <bool GROUPED>
 __device__ __forceinline__ void unpack_pair(const unsigned q, const h2 s_b0, const h2 s_b1,
                                             int& w_b0, int& w_b1) {
@@ -220,14 +235,34 @@ __global__ __launch_bounds__(WAVES * 64) void qqq_stream_kernel(
     }
   };
 
-  // software pipeline: PF steps in flight per wave (4 KiB of weights each)
+  // software pipeline: PF steps (4 KiB of weights each) in flight per wave.  The steady-state loop is
+  // branch-free so that hipcc can place COUNTED s_waitcnt vmcnt(N) (loads of the younger ring slots
+  // stay in flight while the oldest slot is consumed); the ragged tail takes the checked path.
   constexpr int PF = (MT <= 2) ? 3 : 2;
   StreamStep<MT> ring[PF];
-  const int s0 = ks_begin + wave;
+  int s = ks_begin + wave;
+  if (s + (2 * PF - 1) * WAVES < ks_end) {
+    // unconditional prologue + branch-free loop: the wait counters are exact on every path
 #pragma unroll
-  for (int p = 0; p < PF; ++p)
-    if (s0 + p * WAVES < ks_end) load_step(s0 + p * WAVES, ring[p]);
-  for (int s = s0; s < ks_end; s += PF * WAVES) {
+    for (int p = 0; p < PF; ++p) {
+      load_step(s + p * WAVES, ring[p]);
+      __builtin_amdgcn_sched_barrier(0);  // ring order == issue order, so vmcnt(N) can be counted
+    }
+    for (; s + (2 * PF - 1) * WAVES < ks_end; s += PF * WAVES) {
+#pragma unroll
+      for (int p = 0; p < PF; ++p) {
+        compute_step(ring[p]);
+        __builtin_amdgcn_sched_barrier(0);  // keep the refill right behind its consumer (hipcc would
+        load_step(s + (p + PF) * WAVES, ring[p]);  // otherwise sink all loads to the loop end)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int p = 0; p < PF; ++p)
+      if (s + p * WAVES < ks_end) load_step(s + p * WAVES, ring[p]);
+  }
+  for (; s < ks_end; s += PF * WAVES) {
 #pragma unroll
     for (int p = 0; p < PF; ++p) {
       const int sc = s + p * WAVES;
@@ -389,6 +424,7 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * 64) void qqq_tiled_k
   static_assert(W_CHUNKS % NT == 0 && X_CHUNKS % NT == 0, "tile/threads mismatch");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -488,18 +524,11 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * 64) void qqq_tiled_k
     const unsigned char* wb = B + (size_t)(kb * 8) * rowbytes;
     const unsigned char* xb = Abase + (size_t)kb * 128;
     if constexpr (GLDS) {
-      unsigned char* st = smem + buf * STAGE;
+      const unsigned st = lds_base + buf * STAGE + wave * 1024;
 #pragma unroll
-      for (int i = 0; i < WPT; ++i)
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(wb + wsrc[i]),
-            (__attribute__((address_space(3))) void*)(st + (wave * 64 + i * NT) * 16), 16, 0, 0);
+      for (int i = 0; i < WPT; ++i) glds16(wb + wsrc[i], st + i * (NT * 16));
 #pragma unroll
-      for (int i = 0; i < XPT; ++i)
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(xb + xsrc[i]),
-            (__attribute__((address_space(3))) void*)(st + W_BYTES + (wave * 64 + i * NT) * 16), 16,
-            0, 0);
+      for (int i = 0; i < XPT; ++i) glds16(xb + xsrc[i], st + W_BYTES + i * (NT * 16));
     } else {
 #pragma unroll
       for (int i = 0; i < WPT; ++i) wreg[i] = *reinterpret_cast<const v4u*>(wb + wsrc[i]);
@@ -719,13 +748,14 @@ __global__ void qqq_probe_mfma32_kernel(const v4i* a, const v4i* b, v16i* out) {
   out[l] = acc;
 }
 __global__ void qqq_probe_glds_kernel(const v4u* src, const int* perm, v4u* dst) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[1024];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2048];
   const int l = threadIdx.x;
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + perm[l]),
-                                   (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+  // same helper the tiled kernel uses; destination deliberately not at the start of the array
+  glds16(src + perm[l], lds_base + 1024);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  dst[l] = reinterpret_cast<const v4u*>(lds)[l];
+  dst[l] = reinterpret_cast<const v4u*>(lds + 1024)[l];
 }
 
 // ------------------------------------------------------------------------------------------
