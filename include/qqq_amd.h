@@ -63,7 +63,9 @@ typedef struct qqq_tune {
                   workspace), 2 = separate reduce launch; 0 auto                             */
   int bm;      /* tiled: rows per workgroup tile (64, 128, 256); 0 auto                      */
   int glds;    /* tiled: 1 = direct global->LDS loads, 2 = register staged; 0 auto          */
-  int reserved[6];
+  int pf;      /* stream: prefetch depth in 4 KiB steps per wave (3, 5, 7); 0 auto               */
+  int stages;  /* tiled + LDS-DMA: ring depth 2..4 (0 auto)                                      */
+  int reserved[4];
 } qqq_tune_t;
 
 /* As qqq_w4a8_gemm; `tune` may be NULL; if `acc_out` != NULL the raw int32 accumulators

@@ -11,7 +11,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(_HERE, "csrc", "qqq_w4a8.hip")
 HDR = os.path.join(os.path.dirname(_HERE), "include", "qqq_amd.h")
-LIB = os.path.join(_HERE, "libqqq_amd.so")
+LIB = os.environ.get("QQQ_AMD_LIB") or os.path.join(_HERE, "libqqq_amd.so")  # override: tuning builds only
 ARCH = "gfx950"
 
 
@@ -35,7 +35,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     cmd = [
         hipcc_path(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
         "-Wall", "-Wno-unused-function", "-o", LIB + ".tmp", SRC,
-    ]
+    ] + os.environ.get("QQQ_AMD_CXXFLAGS", "").split()
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -149,7 +149,7 @@ struct StreamStep {
   h8 sc;      // per-group scales [2*jt + b]
 };
 
-template <int MT, bool GROUPED, int WAVES>
+template <int MT, bool GROUPED, int WAVES, int PF>
 __global__ __launch_bounds__(WAVES * 64) void qqq_stream_kernel(
     const int8_t* __restrict__ A, const unsigned char* __restrict__ B, int32_t* __restrict__ C,
     _Float16* __restrict__ D, const float* __restrict__ s1, const float* __restrict__ s2,
@@ -205,7 +205,13 @@ __global__ __launch_bounds__(WAVES * 64) void qqq_stream_kernel(
   auto load_step = [&](const int s, StreamStep<MT>& r) {
     const unsigned char* p = bptr + (size_t)(4 * s) * rowbytes;
 #pragma unroll
-    for (int kq = 0; kq < 4; ++kq) r.w[kq] = *reinterpret_cast<const v4u*>(p + 16 * kq);
+    for (int kq = 0; kq < 4; ++kq) {
+#ifdef QQQ_STREAM_NT
+      r.w[kq] = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(p + 16 * kq));  // streamed once
+#else
+      r.w[kq] = *reinterpret_cast<const v4u*>(p + 16 * kq);
+#endif
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) r.x[mt] = *reinterpret_cast<const v4i*>(xptr[mt] + 64 * s);
     if constexpr (GROUPED) r.sc = *reinterpret_cast<const h8*>(sptr + (size_t)(s >> 1) * N);
@@ -238,7 +244,6 @@ __global__ __launch_bounds__(WAVES * 64) void qqq_stream_kernel(
   // software pipeline: PF steps (4 KiB of weights each) in flight per wave.  The steady-state loop is
   // branch-free so that hipcc can place COUNTED s_waitcnt vmcnt(N) (loads of the younger ring slots
   // stay in flight while the oldest slot is consumed); the ragged tail takes the checked path.
-  constexpr int PF = (MT <= 2) ? 3 : 2;
   StreamStep<MT> ring[PF];
   int s = ks_begin + wave;
   if (s + (2 * PF - 1) * WAVES < ks_end) {
@@ -405,7 +410,7 @@ __global__ __launch_bounds__(256) void qqq_reduce_kernel(const int32_t* __restri
 // p ^ ((row >> 1) & 7)).  With global_load_lds the LDS image is lane-linear, so the swizzle is
 // applied to the per-lane SOURCE address; the register-staged variant writes the same image.
 
-template <int BM, int MTW, int JW, bool GROUPED, bool GLDS>
+template <int BM, int MTW, int JW, bool GROUPED, int NS>
 __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * 64) void qqq_tiled_kernel(
     const int8_t* __restrict__ A, const unsigned char* __restrict__ B, int32_t* __restrict__ C,
     _Float16* __restrict__ D, const float* __restrict__ s1, const float* __restrict__ s2,
@@ -416,7 +421,11 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * 64) void qqq_tiled_k
   constexpr int NT = WM * WN * 64;
   constexpr int W_BYTES = 8 * 2048;
   constexpr int X_BYTES = BM * 128;
-  constexpr int STAGE = W_BYTES + X_BYTES;
+  // NS == 0: register-staged, 2 LDS buffers (simple reference variant)
+  // NS >= 2: LDS-DMA (global_load_lds) ring of NS stages, NS-1 stages of loads in flight
+  constexpr bool GLDS = NS > 0;
+  constexpr int SC_BYTES = (GLDS && GROUPED) ? WM * WN * 512 : 0;  // per-wave slot of group scales
+  constexpr int STAGE = W_BYTES + X_BYTES + SC_BYTES;
   constexpr int W_CHUNKS = W_BYTES / 16;  // 1024
   constexpr int X_CHUNKS = X_BYTES / 16;
   constexpr int WPT = W_CHUNKS / NT;  // chunks per thread
@@ -501,11 +510,17 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * 64) void qqq_tiled_k
   for (int t = 0; t < 4; ++t)
     xrd[t] = W_BYTES + (wm * MTW * 32 + li) * 128 + (((2 * t + h) ^ ((li >> 1) & 7)) * 16);
 
-  const _Float16* sptr = nullptr;
+  const _Float16* sptr = nullptr;  // register path (NS == 0)
+  unsigned scsrc = 0;              // LDS-DMA path: byte offset of this lane's 16 B inside the group row
+  unsigned scrd = 0;               // LDS byte offset (inside the stage) of this lane's 2*JW scales
   if constexpr (GROUPED) {
     int ngx = ng0 + g;
     if (ngx >= ngroups) ngx = ngroups - 1;
     sptr = s3 + (size_t)ngx * 64 + c * 8 + wn * (2 * JW);
+    int ngl = ng0 + ((lane & 31) >> 3);
+    if (ngl >= ngroups) ngl = ngroups - 1;
+    scsrc = (unsigned)((ngl * 64 + (lane & 7) * 8) * 2);
+    scrd = W_BYTES + X_BYTES + wave * 512 + (g * 64 + c * 8 + wn * (2 * JW)) * 2;
   }
 
   v16i acc[MTW][JW][2];
@@ -529,6 +544,13 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * 64) void qqq_tiled_k
       for (int i = 0; i < WPT; ++i) glds16(wb + wsrc[i], st + i * (NT * 16));
 #pragma unroll
       for (int i = 0; i < XPT; ++i) glds16(xb + xsrc[i], st + W_BYTES + i * (NT * 16));
+      if constexpr (GROUPED) {
+        // this wave's private copy of the tile's 256 group scales (512 B): lanes 0..31, 16 B each
+        const unsigned scdst =
+            __builtin_amdgcn_readfirstlane(lds_base + buf * STAGE + W_BYTES + X_BYTES + wave * 512);
+        if (lane < 32)  // exec-masked DMA: only 32 x 16 B are written
+          glds16(reinterpret_cast<const unsigned char*>(s3 + (size_t)kb * N) + scsrc, scdst);
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < WPT; ++i) wreg[i] = *reinterpret_cast<const v4u*>(wb + wsrc[i]);
@@ -553,79 +575,131 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * 64) void qqq_tiled_k
   if constexpr (GROUPED)
     if (kb_begin < kb_end) sc_cur = *reinterpret_cast<const hsc*>(sptr + (size_t)kb_begin * N);
 
-  auto compute_stage = [&](const int buf) {
-    const unsigned char* st = smem + buf * STAGE;
+  // One k-step (32 k) of fragments: raw packed weight words [kq][jj] (only this wave's jt are read
+  // from LDS) + the activation operands of this wave's m-tiles.
+  struct Frag {
+    unsigned wq[4][JW];
+    v4i xop[MTW];
+  };
+  auto read_frag = [&](const unsigned char* st, const int t, Frag& f) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      unsigned wq[4][JW];  // raw packed words [kq][jj]; only this wave's jt are read from LDS
+    for (int kq = 0; kq < 4; ++kq) {
+      const unsigned char* p = st + wrd[kq] + t * 4096;
+      if constexpr (JW == 4) {
+        const v4u v = *reinterpret_cast<const v4u*>(p);
+        f.wq[kq][0] = v[0]; f.wq[kq][1] = v[1]; f.wq[kq][2] = v[2]; f.wq[kq][3] = v[3];
+      } else if constexpr (JW == 2) {
+        const uint2 v = *reinterpret_cast<const uint2*>(p);
+        f.wq[kq][0] = v.x; f.wq[kq][1] = v.y;
+      } else {
+        f.wq[kq][0] = *reinterpret_cast<const unsigned*>(p);
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt)
+      f.xop[mt] = *reinterpret_cast<const v4i*>(st + xrd[t] + mt * (32 * 128));
+  };
+  auto mma_frag = [&](const Frag& f) {
+#pragma unroll
+    for (int jj = 0; jj < JW; ++jj) {
+      v4i a0, a1;
+      h2 sb0 = {(_Float16)0, (_Float16)0}, sb1 = sb0;
+      if constexpr (GROUPED) {
+        sb0 = (h2){sc_cur[2 * jj], sc_cur[2 * jj]};
+        sb1 = (h2){sc_cur[2 * jj + 1], sc_cur[2 * jj + 1]};
+      }
 #pragma unroll
       for (int kq = 0; kq < 4; ++kq) {
-        const unsigned char* p = st + wrd[kq] + t * 4096;
-        if constexpr (JW == 4) {
-          const v4u v = *reinterpret_cast<const v4u*>(p);
-          wq[kq][0] = v[0]; wq[kq][1] = v[1]; wq[kq][2] = v[2]; wq[kq][3] = v[3];
-        } else if constexpr (JW == 2) {
-          const uint2 v = *reinterpret_cast<const uint2*>(p);
-          wq[kq][0] = v.x; wq[kq][1] = v.y;
-        } else {
-          wq[kq][0] = *reinterpret_cast<const unsigned*>(p);
-        }
+        int w0, w1;
+        unpack_pair<GROUPED>(f.wq[kq][jj], sb0, sb1, w0, w1);
+        a0[kq] = w0;
+        a1[kq] = w1;
       }
-      v4i xop[MTW];
 #pragma unroll
-      for (int mt = 0; mt < MTW; ++mt)
-        xop[mt] = *reinterpret_cast<const v4i*>(st + xrd[t] + mt * (32 * 128));
-#pragma unroll
-      for (int jj = 0; jj < JW; ++jj) {
-        v4i a0, a1;
-        h2 sb0 = {(_Float16)0, (_Float16)0}, sb1 = sb0;
-        if constexpr (GROUPED) {
-          sb0 = (h2){sc_cur[2 * jj], sc_cur[2 * jj]};
-          sb1 = (h2){sc_cur[2 * jj + 1], sc_cur[2 * jj + 1]};
-        }
-#pragma unroll
-        for (int kq = 0; kq < 4; ++kq) {
-          int w0, w1;
-          unpack_pair<GROUPED>(wq[kq][jj], sb0, sb1, w0, w1);
-          a0[kq] = w0;
-          a1[kq] = w1;
-        }
-#pragma unroll
-        for (int mt = 0; mt < MTW; ++mt) {
-          acc[mt][jj][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, xop[mt], acc[mt][jj][0], 0, 0, 0);
-          acc[mt][jj][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, xop[mt], acc[mt][jj][1], 0, 0, 0);
-        }
+      for (int mt = 0; mt < MTW; ++mt) {
+        acc[mt][jj][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, f.xop[mt], acc[mt][jj][0], 0, 0, 0);
+        acc[mt][jj][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, f.xop[mt], acc[mt][jj][1], 0, 0, 0);
       }
     }
   };
+  // software pipeline inside a stage: the LDS reads of k-step t+1 are issued before the MFMAs of
+  // k-step t, so their latency hides under the matrix pipe instead of stalling the (in-order) wave
+  auto compute_stage = [&](const int buf) {
+    const unsigned char* st = smem + buf * STAGE;
+    Frag f0, f1;
+    read_frag(st, 0, f0);
+    read_frag(st, 1, f1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_frag(f0);
+    __builtin_amdgcn_sched_barrier(0);
+    read_frag(st, 2, f0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_frag(f1);
+    __builtin_amdgcn_sched_barrier(0);
+    read_frag(st, 3, f1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_frag(f0);
+    mma_frag(f1);
+  };
 
-  // ---- main loop: 2 LDS stages, one barrier per 128-k block ----
-  if (kb_begin < kb_end) {
-    issue_loads(kb_begin, 0);
-    if constexpr (GLDS) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
+  if constexpr (!GLDS) {
+    // ---- register-staged variant: 2 LDS buffers, one barrier per 128-k block ----
+    if (kb_begin < kb_end) {
+      issue_loads(kb_begin, 0);
       commit_loads(0);
+      __syncthreads();
     }
-    __syncthreads();
-  }
-  for (int kb = kb_begin; kb < kb_end; ++kb) {
-    const int buf = (kb - kb_begin) & 1;
-    const bool more = (kb + 1 < kb_end);
-    if (more) {
-      issue_loads(kb + 1, buf ^ 1);
-      if constexpr (GROUPED) sc_nxt = *reinterpret_cast<const hsc*>(sptr + (size_t)(kb + 1) * N);
+    for (int kb = kb_begin; kb < kb_end; ++kb) {
+      const int buf = (kb - kb_begin) & 1;
+      const bool more = (kb + 1 < kb_end);
+      if (more) {
+        issue_loads(kb + 1, buf ^ 1);
+        if constexpr (GROUPED) sc_nxt = *reinterpret_cast<const hsc*>(sptr + (size_t)(kb + 1) * N);
+      }
+      compute_stage(buf);
+      if (more) commit_loads(buf ^ 1);
+      if constexpr (GROUPED) sc_cur = sc_nxt;
+      __syncthreads();
     }
-    compute_stage(buf);
-    if (more) {
-      if constexpr (GLDS) {
+  } else {
+    // ---- LDS-DMA ring: NS stages, NS-1 stages of loads in flight, one barrier per 128-k block.
+    // The DMA loads are inline asm (invisible to hipcc's counters): we count them ourselves.  Every
+    // thread issues exactly NL wave-instructions per stage, in stage order, so "stage j has landed"
+    // == "at most NL * (number of younger stages issued) loads outstanding".
+    constexpr int NL = WPT + XPT + (GROUPED ? 1 : 0);
+    static_assert(NL * (NS - 2) <= 63, "vmcnt is a 6-bit counter");
+    auto wait_younger = [&](const int younger) {  // wave-uniform
+      if (younger <= 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else if (younger == 1) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
+      } else if (younger == 2) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NL > 63 ? 63 : 2 * NL) : "memory");
       } else {
-        commit_loads(buf ^ 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NL > 63 ? 63 : 3 * NL) : "memory");
+      }
+    };
+    const int nkb = kb_end - kb_begin;
+    int issued = 0;  // stages issued so far (relative index)
+    for (; issued < NS - 1 && issued < nkb; ++issued) issue_loads(kb_begin + issued, issued % NS);
+    if (nkb > 0) {
+      wait_younger(issued - 1);
+      __syncthreads();
+    }
+    for (int i = 0; i < nkb; ++i) {
+      // refill the buffer consumed in iteration i-1 (every wave has passed that iteration's barrier)
+      if (issued < nkb) {
+        issue_loads(kb_begin + issued, issued % NS);
+        ++issued;
+      }
+      if constexpr (GROUPED)
+        sc_cur = *reinterpret_cast<const hsc*>(smem + (i % NS) * STAGE + scrd);
+      compute_stage(i % NS);
+      if (i + 1 < nkb) {
+        wait_younger(issued - (i + 2));  // stage i+1 must have landed; stages i+2.. may stay in flight
+        __syncthreads();
       }
     }
-    if constexpr (GROUPED) sc_cur = sc_nxt;
-    __syncthreads();
   }
 
   // ---- epilogue straight from the accumulators ----
@@ -834,43 +908,60 @@ struct LaunchArgs {
   hipStream_t stream;
 };
 
-template <int MT, bool GROUPED, int WAVES>
+template <int MT, bool GROUPED, int WAVES, int PF>
 static hipError_t launch_stream_t(const LaunchArgs& a, int ksplit, int fused) {
   dim3 grid((a.N + 127) / 128, ksplit, (a.M + 16 * MT - 1) / (16 * MT));
-  hipLaunchKernelGGL((qqq_stream_kernel<MT, GROUPED, WAVES>), grid, dim3(WAVES * 64), 0, a.stream, a.A,
-                     a.B, a.C, a.D, a.s1, a.s2, a.s3, a.acc_out, a.tickets, a.M, a.N, a.K, ksplit,
+  hipLaunchKernelGGL((qqq_stream_kernel<MT, GROUPED, WAVES, PF>), grid, dim3(WAVES * 64), 0, a.stream,
+                     a.A, a.B, a.C, a.D, a.s1, a.s2, a.s3, a.acc_out, a.tickets, a.M, a.N, a.K, ksplit,
                      fused);
   return hipGetLastError();
 }
 
+// prefetch depth PF (ring slots of 4 KiB weights per wave): deeper for the small-m bodies
 template <bool GROUPED, int WAVES>
-static hipError_t launch_stream_mt(const LaunchArgs& a, int mt, int ksplit, int fused) {
-  switch (mt) {
-    case 1: return launch_stream_t<1, GROUPED, WAVES>(a, ksplit, fused);
-    case 2: return launch_stream_t<2, GROUPED, WAVES>(a, ksplit, fused);
-    case 3: return launch_stream_t<3, GROUPED, WAVES>(a, ksplit, fused);
-    default: return launch_stream_t<4, GROUPED, WAVES>(a, ksplit, fused);
+static hipError_t launch_stream_mt(const LaunchArgs& a, int mt, int pf, int ksplit, int fused) {
+  if constexpr (WAVES == 16) {
+    // 1024-thread blocks cap VGPRs at 128: only the MT=1 / PF=3 body fits (host never asks otherwise)
+    return launch_stream_t<1, GROUPED, 16, 3>(a, ksplit, fused);
+  } else {
+    switch (mt) {
+      case 1:
+        if (pf >= 7) return launch_stream_t<1, GROUPED, WAVES, 7>(a, ksplit, fused);
+        if (pf >= 5) return launch_stream_t<1, GROUPED, WAVES, 5>(a, ksplit, fused);
+        return launch_stream_t<1, GROUPED, WAVES, 3>(a, ksplit, fused);
+      case 2:
+        if (pf >= 5) return launch_stream_t<2, GROUPED, WAVES, 5>(a, ksplit, fused);
+        return launch_stream_t<2, GROUPED, WAVES, 3>(a, ksplit, fused);
+      case 3:
+        return launch_stream_t<3, GROUPED, WAVES, 2>(a, ksplit, fused);
+      default:
+        if (pf >= 3) return launch_stream_t<4, GROUPED, WAVES, 3>(a, ksplit, fused);
+        return launch_stream_t<4, GROUPED, WAVES, 2>(a, ksplit, fused);
+    }
   }
 }
 
-static hipError_t launch_stream(const LaunchArgs& a, bool grouped, int mt, int waves, int ksplit,
+static hipError_t launch_stream(const LaunchArgs& a, bool grouped, int mt, int waves, int pf, int ksplit,
                                 int fused) {
   if (grouped) {
-    if (waves == 4) return launch_stream_mt<true, 4>(a, mt, ksplit, fused);
-    if (waves == 16) return launch_stream_mt<true, 16>(a, mt, ksplit, fused);
-    return launch_stream_mt<true, 8>(a, mt, ksplit, fused);
+    if (waves == 4) return launch_stream_mt<true, 4>(a, mt, pf, ksplit, fused);
+    if (waves == 16) return launch_stream_mt<true, 16>(a, mt, pf, ksplit, fused);
+    return launch_stream_mt<true, 8>(a, mt, pf, ksplit, fused);
   }
-  if (waves == 4) return launch_stream_mt<false, 4>(a, mt, ksplit, fused);
-  if (waves == 16) return launch_stream_mt<false, 16>(a, mt, ksplit, fused);
-  return launch_stream_mt<false, 8>(a, mt, ksplit, fused);
+  if (waves == 4) return launch_stream_mt<false, 4>(a, mt, pf, ksplit, fused);
+  if (waves == 16) return launch_stream_mt<false, 16>(a, mt, pf, ksplit, fused);
+  return launch_stream_mt<false, 8>(a, mt, pf, ksplit, fused);
 }
 
-template <int BM, int MTW, int JW, bool GROUPED, bool GLDS>
+template <int BM, int MTW, int JW, bool GROUPED, int NS>
 static hipError_t launch_tiled_t(const LaunchArgs& a, int ksplit) {
-  constexpr int NT = (BM / (32 * MTW)) * (4 / JW) * 64;
-  constexpr int LDS = 2 * (8 * 2048 + BM * 128);
+  constexpr int WAVES = (BM / (32 * MTW)) * (4 / JW);
+  constexpr int NT = WAVES * 64;
+  constexpr int STAGE = 8 * 2048 + BM * 128 + ((NS > 0 && GROUPED) ? WAVES * 512 : 0);
+  constexpr int LDS = (NS > 0 ? NS : 2) * STAGE;
+  static_assert(LDS <= 160 * 1024, "LDS budget");
   static bool attr_set[64] = {};  // per instantiation, per device
-  auto kern = qqq_tiled_kernel<BM, MTW, JW, GROUPED, GLDS>;
+  auto kern = qqq_tiled_kernel<BM, MTW, JW, GROUPED, NS>;
   int cur = 0;
   (void)hipGetDevice(&cur);
   if (cur < 0 || cur >= 64 || !attr_set[cur]) {
@@ -886,18 +977,29 @@ static hipError_t launch_tiled_t(const LaunchArgs& a, int ksplit) {
   return hipGetLastError();
 }
 
-template <bool GROUPED, bool GLDS>
-static hipError_t launch_tiled_bm(const LaunchArgs& a, int bm, int ksplit) {
+// stages: 0 = register-staged; 2..4 = LDS-DMA ring depth (clamped to what fits in 160 KiB of LDS)
+template <bool GROUPED>
+static hipError_t launch_tiled_bm(const LaunchArgs& a, int bm, int stages, int ksplit) {
   switch (bm) {
-    case 64: return launch_tiled_t<64, 1, 2, GROUPED, GLDS>(a, ksplit);
-    case 128: return launch_tiled_t<128, 2, 2, GROUPED, GLDS>(a, ksplit);
-    default: return launch_tiled_t<256, 2, 2, GROUPED, GLDS>(a, ksplit);
+    case 64:
+      if (stages == 0) return launch_tiled_t<64, 1, 2, GROUPED, 0>(a, ksplit);
+      if (stages == 2) return launch_tiled_t<64, 1, 2, GROUPED, 2>(a, ksplit);
+      if (stages == 3) return launch_tiled_t<64, 1, 2, GROUPED, 3>(a, ksplit);
+      return launch_tiled_t<64, 1, 2, GROUPED, 4>(a, ksplit);
+    case 128:
+      if (stages == 0) return launch_tiled_t<128, 2, 2, GROUPED, 0>(a, ksplit);
+      if (stages == 2) return launch_tiled_t<128, 2, 2, GROUPED, 2>(a, ksplit);
+      if (stages == 3) return launch_tiled_t<128, 2, 2, GROUPED, 3>(a, ksplit);
+      return launch_tiled_t<128, 2, 2, GROUPED, 4>(a, ksplit);
+    default:
+      if (stages == 0) return launch_tiled_t<256, 2, 2, GROUPED, 0>(a, ksplit);
+      if (stages == 2) return launch_tiled_t<256, 2, 2, GROUPED, 2>(a, ksplit);
+      return launch_tiled_t<256, 2, 2, GROUPED, 3>(a, ksplit);
   }
 }
 
-static hipError_t launch_tiled(const LaunchArgs& a, bool grouped, int bm, bool glds, int ksplit) {
-  if (grouped) return glds ? launch_tiled_bm<true, true>(a, bm, ksplit) : launch_tiled_bm<true, false>(a, bm, ksplit);
-  return glds ? launch_tiled_bm<false, true>(a, bm, ksplit) : launch_tiled_bm<false, false>(a, bm, ksplit);
+static hipError_t launch_tiled(const LaunchArgs& a, bool grouped, int bm, int stages, int ksplit) {
+  return grouped ? launch_tiled_bm<true>(a, bm, stages, ksplit) : launch_tiled_bm<false>(a, bm, stages, ksplit);
 }
 
 static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -925,9 +1027,10 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
   const long long cap_rows = (long long)(max_par > 0 ? max_par : 0) * 64;  // rows of C we may use
   const bool have_scratch = (C != nullptr) && cap_rows > 0;
 
-  // ---- kernel choice ----
+  // ---- kernel choice (measured on MI355X, profiles/tune_r01.txt) ----
+  // m <= 128: the HBM-bound "stream" kernel wins (weights straight to VGPRs); above, LDS tiles.
   int kernel = t.kernel;
-  if (kernel == 0) kernel = (M <= 64 || (K % 128) != 0) ? 1 : 2;
+  if (kernel == 0) kernel = (M <= 128 || (K % 128) != 0) ? 1 : 2;
   if (kernel == 2 && (K % 128) != 0) kernel = 1;
 
   LaunchArgs a;
@@ -956,14 +1059,14 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
     const int mblocks = (M + 16 * mt - 1) / (16 * mt);
     const int strips = (N + 127) / 128;
     const int KS = K / 64;
-    int waves = t.waves ? t.waves : 8;
+    int waves = t.waves ? t.waves : (mt == 1 ? 4 : 8);
     if (waves != 4 && waves != 8 && waves != 16) waves = 8;
     if (waves == 16 && mt > 1) waves = 8;  // 1024-thread blocks cap VGPRs at 128: only the MT=1 body fits
     ksplit = t.ksplit;
     if (ksplit <= 0) {
-      // fill ~256 CUs x 8 waves; keep >= 2 steps per wave
-      const long long want_wg = 256LL * 8 / waves;
-      ksplit = (int)((want_wg + (long long)strips * mblocks - 1) / ((long long)strips * mblocks));
+      // one workgroup per CU: (strips x m-blocks x K-slices) ~ 256, at least 2 steps per wave
+      const long long base = (long long)strips * mblocks;
+      ksplit = (int)((256 + base / 2) / base);
       ksplit = clampi(ksplit, 1, KS / (2 * waves) > 0 ? KS / (2 * waves) : 1);
     }
     ksplit = clampi(ksplit, 1, KS);
@@ -971,11 +1074,12 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
     if (ksplit > 1 && (long long)ksplit * M > cap_rows) ksplit = (int)(cap_rows / M);
     if (ksplit < 1) ksplit = 1;
     int fused = t.fused;
-    if (fused == 0) fused = 1;
+    if (fused == 0) fused = 2;  // separate reduce launch measured ~2 us faster than the in-launch ticket path
     // tickets: one int per (m-block, strip); the reference guarantees n/128*max_par ints
     if (fused == 1 && (workspace == nullptr || (long long)mblocks * strips > (long long)(N / 128) * max_par))
       fused = 2;
-    e = launch_stream(a, grouped, mt, waves, ksplit, fused == 1 ? 1 : 0);
+    const int pf = t.pf > 0 ? t.pf : (mt <= 2 ? 3 : 2);
+    e = launch_stream(a, grouped, mt, waves, pf, ksplit, fused == 1 ? 1 : 0);
     if (e != hipSuccess) return fail_hip(e, "qqq_stream_kernel launch");
     if (ksplit > 1 && fused != 1) {
       const long long items = (long long)M * (N / 4);
@@ -1000,7 +1104,13 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
     else
       bm = 64;
   }
-  const bool glds = (t.glds == 0) ? true : (t.glds == 1);
+  // glds: 2 = register-staged, 1 = LDS-DMA ring with `stages` buffers; auto: the DMA ring pays at the
+  // 8-wave 256-row tile, register staging is faster for the 4-wave tiles (measured)
+  int stages;
+  if (t.glds == 2) stages = 0;
+  else if (t.glds == 1) stages = (t.stages >= 2 && t.stages <= 4) ? t.stages : (bm == 256 ? 3 : 4);
+  else stages = (bm == 256) ? 2 : 0;
+  if (bm == 256 && stages > 3) stages = 3;
   const long long tiles = (long long)((M + bm - 1) / bm) * ((N + 255) / 256);
   ksplit = t.ksplit;
   if (ksplit <= 0) {
@@ -1011,7 +1121,7 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
   if (!have_scratch) ksplit = 1;
   if (ksplit > 1 && (long long)ksplit * M > cap_rows) ksplit = (int)(cap_rows / M);
   if (ksplit < 1) ksplit = 1;
-  e = launch_tiled(a, grouped, bm, glds, ksplit);
+  e = launch_tiled(a, grouped, bm, stages, ksplit);
   if (e != hipSuccess) return fail_hip(e, "qqq_tiled_kernel launch");
   if (ksplit > 1) {
     const long long items = (long long)M * (N / 4);

@@ -20,12 +20,17 @@ class GemmHarness:
 
     def __init__(self, B, s2, s3, dev, max_par=16):
         self.dev = dev
-        self.B = torch.from_numpy(np.ascontiguousarray(B)).to(dev) if isinstance(B, np.ndarray) else B
-        self.s2 = torch.from_numpy(np.ascontiguousarray(s2, dtype=np.float32)).to(dev) if isinstance(s2, np.ndarray) else s2
-        if s3 is None or (isinstance(s3, np.ndarray) and s3.size == 0):
+        def dv(t, dtype=None):
+            if isinstance(t, np.ndarray):
+                t = torch.from_numpy(np.ascontiguousarray(t, dtype=dtype))
+            return t.to(dev).contiguous()
+
+        self.B = dv(B)
+        self.s2 = dv(s2, np.float32)
+        if s3 is None or (isinstance(s3, np.ndarray) and s3.size == 0) or (torch.is_tensor(s3) and s3.numel() == 0):
             self.s3 = torch.empty(0, dtype=torch.float16, device=dev)
         else:
-            self.s3 = torch.from_numpy(np.ascontiguousarray(s3)).to(dev) if isinstance(s3, np.ndarray) else s3
+            self.s3 = dv(s3)
         self.N = self.B.shape[1] // 2
         self.K = self.B.shape[0] * 16
         self.max_par = max_par
@@ -34,8 +39,8 @@ class GemmHarness:
         self.ws = torch.zeros(max(self.N // 128, 1) * max_par, dtype=torch.int32, device=dev)
 
     def run(self, A, s1, tune=None, want_acc=True):
-        A = torch.from_numpy(np.ascontiguousarray(A)).to(self.dev) if isinstance(A, np.ndarray) else A
-        s1 = torch.from_numpy(np.ascontiguousarray(s1, dtype=np.float32)).to(self.dev) if isinstance(s1, np.ndarray) else s1
+        A = (torch.from_numpy(np.ascontiguousarray(A)) if isinstance(A, np.ndarray) else A).to(self.dev).contiguous()
+        s1 = (torch.from_numpy(np.ascontiguousarray(s1, dtype=np.float32)) if isinstance(s1, np.ndarray) else s1).to(self.dev).contiguous()
         M = A.shape[0]
         D = torch.full((M, self.N), float("nan"), dtype=torch.float16, device=self.dev)
         acc = torch.full((M, self.N), -1, dtype=torch.int32, device=self.dev) if want_acc else None
@@ -58,10 +63,13 @@ def variants(M, K, N):
     v += [dict(kernel=1)]  # auto split
     if K % 128 == 0:
         for bm in (64, 128, 256):
-            for glds in (1, 2):
-                v.append(dict(kernel=2, bm=bm, glds=glds, ksplit=1))
-        if K // 128 >= 8:
-            v.append(dict(kernel=2, bm=128, glds=1, ksplit=2))
+            v.append(dict(kernel=2, bm=bm, glds=2, ksplit=1))
+            for stages in (2, 3, 4):
+                v.append(dict(kernel=2, bm=bm, glds=1, stages=stages, ksplit=1))
+        if K // 128 >= 2:
+            v.append(dict(kernel=2, bm=128, glds=1, stages=3, ksplit=2))
             v.append(dict(kernel=2, bm=64, glds=2, ksplit=2))
+        if K // 128 >= 4:
+            v.append(dict(kernel=2, bm=64, glds=1, stages=4, ksplit=3))
     v.append(dict())  # fully automatic (== qqq_w4a8_gemm)
     return v

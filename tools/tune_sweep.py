@@ -19,23 +19,28 @@ def variants(M, grouped):
         for waves in (4, 8, 16):
             if waves == 16 and M > 16:
                 continue
-            for ks in (1, 2, 4, 8, 16, 32):
+            for ks in (1, 2, 3, 4, 5, 6, 8, 16):
                 if ks * M > 1024:
                     continue
-                for fused in ((1, 2) if ks > 1 else (1,)):
-                    v.append(dict(kernel=1, waves=waves, ksplit=ks, fused=fused))
+                for pf in ((3, 5, 7) if M <= 16 else (3, 5) if M <= 32 else (0,)):
+                    if waves == 16 and pf != 3:
+                        continue
+                    for fused in ((1, 2) if ks > 1 else (1,)):
+                        v.append(dict(kernel=1, waves=waves, ksplit=ks, fused=fused, pf=pf))
     if M >= 16:
         for bm in (64, 128, 256):
             if bm > 64 and M < bm // 2:
                 continue
-            for glds in (1, 2):
+            for stages in (0, 2, 3, 4):
+                if bm == 256 and stages == 4:
+                    continue
                 for ks in (1, 2, 4, 8, 16):
                     if ks > 1 and ks * M > 1024:
                         continue
                     tiles = -(-M // bm) * 32
                     if tiles * ks > 4096 or (ks > 1 and tiles >= 512):
                         continue
-                    v.append(dict(kernel=2, bm=bm, glds=glds, ksplit=ks))
+                    v.append(dict(kernel=2, bm=bm, glds=(2 if stages == 0 else 1), stages=stages, ksplit=ks))
     return v
 
 
