@@ -373,22 +373,33 @@ __global__ __launch_bounds__(WAVES * 64) void qqq_stream_kernel(
 }
 
 // Separate reduce + dequant launch for split-K partial sums: one thread = 4 consecutive n.
-__global__ __launch_bounds__(256) void qqq_reduce_kernel(const int32_t* __restrict__ C,
-                                                         _Float16* __restrict__ D,
-                                                         const float* __restrict__ s1,
-                                                         const float* __restrict__ s2,
-                                                         int32_t* __restrict__ acc_out, const int M,
-                                                         const int N, const int ksplit) {
+// Latency-bound (a few MB): all slab loads of a thread are issued before the first add.
+__global__ __launch_bounds__(64) void qqq_reduce_kernel(const int32_t* __restrict__ C,
+                                                        _Float16* __restrict__ D,
+                                                        const float* __restrict__ s1,
+                                                        const float* __restrict__ s2,
+                                                        int32_t* __restrict__ acc_out, const int M,
+                                                        const int N, const int ksplit) {
   const int nq = N >> 2;
   const long long total = (long long)M * nq;
-  for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < total;
-       it += (long long)gridDim.x * 256) {
+  const size_t slab = (size_t)M * N;
+  for (long long it = (long long)blockIdx.x * 64 + threadIdx.x; it < total;
+       it += (long long)gridDim.x * 64) {
     const int m = (int)(it / nq);
     const int n = (int)(it % nq) * 4;
+    const int32_t* p0 = C + (size_t)m * N + n;
+    const float a_s = s1[m];
     v4i sum = {0, 0, 0, 0};
-    for (int p = 0; p < ksplit; ++p)
-      sum += *reinterpret_cast<const v4i*>(C + ((size_t)p * M + m) * N + n);
-    epilogue_store4(sum[0], sum[1], sum[2], sum[3], m, n, N, s1[m], s2, D, acc_out);
+    int p = 0;
+    for (; p + 4 <= ksplit; p += 4) {
+      const v4i v0 = *reinterpret_cast<const v4i*>(p0 + (size_t)(p + 0) * slab);
+      const v4i v1 = *reinterpret_cast<const v4i*>(p0 + (size_t)(p + 1) * slab);
+      const v4i v2 = *reinterpret_cast<const v4i*>(p0 + (size_t)(p + 2) * slab);
+      const v4i v3 = *reinterpret_cast<const v4i*>(p0 + (size_t)(p + 3) * slab);
+      sum += (v0 + v1) + (v2 + v3);
+    }
+    for (; p < ksplit; ++p) sum += *reinterpret_cast<const v4i*>(p0 + (size_t)p * slab);
+    epilogue_store4(sum[0], sum[1], sum[2], sum[3], m, n, N, a_s, s2, D, acc_out);
   }
 }
 
@@ -423,7 +434,10 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * 64) void qqq_tiled_k
   constexpr int X_BYTES = BM * 128;
   // NS == 0: register-staged, 2 LDS buffers (simple reference variant)
   // NS >= 2: LDS-DMA (global_load_lds) ring of NS stages, NS-1 stages of loads in flight
+  // NS == 5: LDS-DMA ring of 3 stages driven by the staggered two-group ("ping-pong") schedule
   constexpr bool GLDS = NS > 0;
+  constexpr bool PINGPONG = (NS == 5);
+  constexpr int NSTAGE = PINGPONG ? 3 : NS;
   constexpr int SC_BYTES = (GLDS && GROUPED) ? WM * WN * 512 : 0;  // per-wave slot of group scales
   constexpr int STAGE = W_BYTES + X_BYTES + SC_BYTES;
   constexpr int W_CHUNKS = W_BYTES / 16;  // 1024
@@ -501,10 +515,16 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * 64) void qqq_tiled_k
   // ---- per-lane LDS read offsets ----
   const int li = lane & 31, h = lane >> 5;
   const int g = li >> 3, c = li & 7;
+  // Which jt of the 16-byte chunk this lane consumes.  With JW == 2 a lane reads 8 of the 16 bytes; lanes
+  // c < 4 take the half `wn`, lanes c >= 4 the OTHER half: the 32 lanes of a ds_read_b64 group then
+  // cover all 64 banks exactly once (a fixed half would be a 2-way conflict).  This is only another
+  // row<->column permutation of the MFMA tile (the sibling wave wn^1 takes the complementary halves);
+  // the epilogue and the group-scale addresses use the same lane-dependent jt.
+  const int wsel = (JW == 2) ? (wn ^ (c >> 2)) : wn;
   unsigned wrd[4];  // + t*4096
 #pragma unroll
   for (int kq = 0; kq < 4; ++kq)
-    wrd[kq] = h * 2048 + g * 512 + (4 * c + (kq ^ g)) * 16 + wn * (JW * 4);  // this wave's jt only
+    wrd[kq] = h * 2048 + g * 512 + (4 * c + (kq ^ g)) * 16 + wsel * (JW * 4);  // this lane's jt only
   unsigned xrd[4];  // per k-step t; + mt*32*128
 #pragma unroll
   for (int t = 0; t < 4; ++t)
@@ -516,11 +536,11 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * 64) void qqq_tiled_k
   if constexpr (GROUPED) {
     int ngx = ng0 + g;
     if (ngx >= ngroups) ngx = ngroups - 1;
-    sptr = s3 + (size_t)ngx * 64 + c * 8 + wn * (2 * JW);
+    sptr = s3 + (size_t)ngx * 64 + c * 8 + wsel * (2 * JW);
     int ngl = ng0 + ((lane & 31) >> 3);
     if (ngl >= ngroups) ngl = ngroups - 1;
     scsrc = (unsigned)((ngl * 64 + (lane & 7) * 8) * 2);
-    scrd = W_BYTES + X_BYTES + wave * 512 + (g * 64 + c * 8 + wn * (2 * JW)) * 2;
+    scrd = W_BYTES + X_BYTES + wave * 512 + (g * 64 + c * 8 + wsel * (2 * JW)) * 2;
   }
 
   v16i acc[MTW][JW][2];
@@ -538,6 +558,9 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * 64) void qqq_tiled_k
   auto issue_loads = [&](const int kb, const int buf) {
     const unsigned char* wb = B + (size_t)(kb * 8) * rowbytes;
     const unsigned char* xb = Abase + (size_t)kb * 128;
+#if defined(QQQ_ABLATE) && (QQQ_ABLATE & 2)  // ablation: no global->LDS traffic
+    if (kb >= 0) return;
+#endif
     if constexpr (GLDS) {
       const unsigned st = lds_base + buf * STAGE + wave * 1024;
 #pragma unroll
@@ -582,6 +605,17 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * 64) void qqq_tiled_k
     v4i xop[MTW];
   };
   auto read_frag = [&](const unsigned char* st, const int t, Frag& f) {
+#if defined(QQQ_ABLATE) && (QQQ_ABLATE & 1)  // ablation: no LDS fragment reads
+    if (t >= 0) {
+#pragma unroll
+      for (int kq = 0; kq < 4; ++kq)
+#pragma unroll
+        for (int jj = 0; jj < JW; ++jj) asm volatile("" : "+v"(f.wq[kq][jj]));
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt) asm volatile("" : "+v"(f.xop[mt]));
+      return;
+    }
+#endif
 #pragma unroll
     for (int kq = 0; kq < 4; ++kq) {
       const unsigned char* p = st + wrd[kq] + t * 4096;
@@ -611,7 +645,12 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * 64) void qqq_tiled_k
 #pragma unroll
       for (int kq = 0; kq < 4; ++kq) {
         int w0, w1;
+#if defined(QQQ_ABLATE) && (QQQ_ABLATE & 4)  // ablation: no unpack VALU
+        w0 = (int)f.wq[kq][jj];
+        w1 = (int)f.wq[kq][jj];
+#else
         unpack_pair<GROUPED>(f.wq[kq][jj], sb0, sb1, w0, w1);
+#endif
         a0[kq] = w0;
         a1[kq] = w1;
       }
@@ -622,11 +661,46 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * 64) void qqq_tiled_k
       }
     }
   };
+  // the same work split in two halves for the ping-pong schedule
+  struct Ops {
+    v4i a[JW][2];
+  };
+  auto unpack_frag = [&](const Frag& f, Ops& o) {
+#pragma unroll
+    for (int jj = 0; jj < JW; ++jj) {
+      h2 sb0 = {(_Float16)0, (_Float16)0}, sb1 = sb0;
+      if constexpr (GROUPED) {
+        sb0 = (h2){sc_cur[2 * jj], sc_cur[2 * jj]};
+        sb1 = (h2){sc_cur[2 * jj + 1], sc_cur[2 * jj + 1]};
+      }
+#pragma unroll
+      for (int kq = 0; kq < 4; ++kq) {
+        int w0, w1;
+#if defined(QQQ_ABLATE) && (QQQ_ABLATE & 4)
+        w0 = (int)f.wq[kq][jj];
+        w1 = (int)f.wq[kq][jj];
+#else
+        unpack_pair<GROUPED>(f.wq[kq][jj], sb0, sb1, w0, w1);
+#endif
+        o.a[jj][0][kq] = w0;
+        o.a[jj][1][kq] = w1;
+      }
+    }
+  };
+  auto mfma_ops = [&](const Ops& o, const Frag& f) {
+#pragma unroll
+    for (int jj = 0; jj < JW; ++jj)
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt) {
+        acc[mt][jj][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.a[jj][0], f.xop[mt], acc[mt][jj][0], 0, 0, 0);
+        acc[mt][jj][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.a[jj][1], f.xop[mt], acc[mt][jj][1], 0, 0, 0);
+      }
+  };
   // software pipeline inside a stage: the LDS reads of k-step t+1 are issued before the MFMAs of
   // k-step t, so their latency hides under the matrix pipe instead of stalling the (in-order) wave
   auto compute_stage = [&](const int buf) {
     const unsigned char* st = smem + buf * STAGE;
-    Frag f0, f1;
+    Frag f0 = {}, f1 = {};
     read_frag(st, 0, f0);
     read_frag(st, 1, f1);
     __builtin_amdgcn_sched_barrier(0);
@@ -667,7 +741,7 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * 64) void qqq_tiled_k
     // thread issues exactly NL wave-instructions per stage, in stage order, so "stage j has landed"
     // == "at most NL * (number of younger stages issued) loads outstanding".
     constexpr int NL = WPT + XPT + (GROUPED ? 1 : 0);
-    static_assert(NL * (NS - 2) <= 63, "vmcnt is a 6-bit counter");
+    static_assert(NL * (NSTAGE - 2) <= 63, "vmcnt is a 6-bit counter");
     auto wait_younger = [&](const int younger) {  // wave-uniform
       if (younger <= 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -680,25 +754,75 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * 64) void qqq_tiled_k
       }
     };
     const int nkb = kb_end - kb_begin;
-    int issued = 0;  // stages issued so far (relative index)
-    for (; issued < NS - 1 && issued < nkb; ++issued) issue_loads(kb_begin + issued, issued % NS);
-    if (nkb > 0) {
-      wait_younger(issued - 1);
-      __syncthreads();
-    }
-    for (int i = 0; i < nkb; ++i) {
-      // refill the buffer consumed in iteration i-1 (every wave has passed that iteration's barrier)
-      if (issued < nkb) {
-        issue_loads(kb_begin + issued, issued % NS);
-        ++issued;
-      }
-      if constexpr (GROUPED)
-        sc_cur = *reinterpret_cast<const hsc*>(smem + (i % NS) * STAGE + scrd);
-      compute_stage(i % NS);
-      if (i + 1 < nkb) {
-        wait_younger(issued - (i + 2));  // stage i+1 must have landed; stages i+2.. may stay in flight
+    if constexpr (!PINGPONG) {
+      int issued = 0;  // stages issued so far (relative index)
+      for (; issued < NSTAGE - 1 && issued < nkb; ++issued) issue_loads(kb_begin + issued, issued % NSTAGE);
+      if (nkb > 0) {
+        wait_younger(issued - 1);
         __syncthreads();
       }
+      for (int i = 0; i < nkb; ++i) {
+        // refill the buffer consumed in iteration i-1 (every wave has passed that iteration's barrier)
+        if (issued < nkb) {
+          issue_loads(kb_begin + issued, issued % NSTAGE);
+          ++issued;
+        }
+        if constexpr (GROUPED)
+          sc_cur = *reinterpret_cast<const hsc*>(smem + (i % NSTAGE) * STAGE + scrd);
+        compute_stage(i % NSTAGE);
+        if (i + 1 < nkb) {
+          wait_younger(issued - (i + 2));  // stage i+1 must have landed; stages i+2.. may stay in flight
+          __syncthreads();
+        }
+      }
+    } else {
+      // ---- staggered two-group schedule ("ping-pong").  Every k-step is cut in a LOAD phase (LDS
+      // fragment reads for the NEXT k-step, int4 unpack of the current one, DMA issue / landing waits)
+      // and an MFMA phase (8 matrix instructions), each closed by a workgroup barrier.  The second half
+      // of the waves runs one phase behind the first, so on every SIMD one wave's MFMA burst overlaps
+      // its partner's LOAD phase instead of both stalling on LDS at the same time.
+      //   DMA of stage j is issued in LOAD(j-2, t=0) into buffer j % 3 (last read two barriers ago);
+      //   its landing is awaited by every wave in LOAD(j-1, t=2); first read is in LOAD(j-1, t=3).
+      const bool late = wave >= (WM * WN) / 2;  // wave-uniform
+      auto phase_barrier = [&]() {
+        __builtin_amdgcn_sched_barrier(0);  // register-only MFMAs would otherwise drift across it
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      Frag fr[2] = {};
+      Ops ops;
+      if (nkb > 0) {
+        issue_loads(kb_begin, 0);
+        if (nkb > 1) issue_loads(kb_begin + 1, 1);
+        wait_younger(nkb > 1 ? 1 : 0);
+        __syncthreads();
+        read_frag(smem, 0, fr[0]);
+        if (late) phase_barrier();
+      }
+      for (int i = 0; i < nkb; ++i) {
+        const unsigned char* st = smem + (i % 3) * STAGE;
+        const unsigned char* stn = smem + ((i + 1) % 3) * STAGE;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          // ---------------- LOAD phase ----------------
+          if (t == 0) {
+            if (i + 2 < nkb) issue_loads(kb_begin + i + 2, (i + 2) % 3);
+            if constexpr (GROUPED) sc_cur = *reinterpret_cast<const hsc*>(st + scrd);
+          }
+          if (t == 2 && i + 1 < nkb) wait_younger(i + 2 < nkb ? 1 : 0);
+          if (t < 3) {
+            read_frag(st, t + 1, fr[(t + 1) & 1]);
+          } else if (i + 1 < nkb) {
+            read_frag(stn, 0, fr[0]);
+          }
+          unpack_frag(fr[t & 1], ops);
+          phase_barrier();
+          // ---------------- MFMA phase ----------------
+          mfma_ops(ops, fr[t & 1]);
+          phase_barrier();
+        }
+      }
+      if (nkb > 0 && !late) phase_barrier();  // both groups execute the same number of barriers
     }
   }
 
@@ -713,7 +837,8 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * 64) void qqq_tiled_k
   const int n_lane = ng0 * 64 + 4 * h;  // + 64*g' + 16*jt + 8*b  (g' = r >> 2), + (r & 3)
 #pragma unroll
   for (int jj = 0; jj < JW; ++jj) {
-    const int jt = wn * JW + jj;
+    // D-tile rows of this lane have c = 4*h + (r & 3): c >> 2 == h, so the lane's jt is uniform over r
+    const int jt = ((JW == 2) ? (wn ^ h) : wn) * JW + jj;
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -958,7 +1083,7 @@ static hipError_t launch_tiled_t(const LaunchArgs& a, int ksplit) {
   constexpr int WAVES = (BM / (32 * MTW)) * (4 / JW);
   constexpr int NT = WAVES * 64;
   constexpr int STAGE = 8 * 2048 + BM * 128 + ((NS > 0 && GROUPED) ? WAVES * 512 : 0);
-  constexpr int LDS = (NS > 0 ? NS : 2) * STAGE;
+  constexpr int LDS = (NS == 5 ? 3 : (NS > 0 ? NS : 2)) * STAGE;
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static bool attr_set[64] = {};  // per instantiation, per device
   auto kern = qqq_tiled_kernel<BM, MTW, JW, GROUPED, NS>;
@@ -991,9 +1116,14 @@ static hipError_t launch_tiled_bm(const LaunchArgs& a, int bm, int stages, int k
       if (stages == 2) return launch_tiled_t<128, 2, 2, GROUPED, 2>(a, ksplit);
       if (stages == 3) return launch_tiled_t<128, 2, 2, GROUPED, 3>(a, ksplit);
       return launch_tiled_t<128, 2, 2, GROUPED, 4>(a, ksplit);
+    case 257:  // experimental: 256-row tile as 4 waves x (128 x 128), one wave per SIMD
+      if (stages == 0) return launch_tiled_t<256, 4, 2, GROUPED, 0>(a, ksplit);
+      if (stages == 2) return launch_tiled_t<256, 4, 2, GROUPED, 2>(a, ksplit);
+      return launch_tiled_t<256, 4, 2, GROUPED, 3>(a, ksplit);
     default:
       if (stages == 0) return launch_tiled_t<256, 2, 2, GROUPED, 0>(a, ksplit);
       if (stages == 2) return launch_tiled_t<256, 2, 2, GROUPED, 2>(a, ksplit);
+      if (stages == 5) return launch_tiled_t<256, 2, 2, GROUPED, 5>(a, ksplit);
       return launch_tiled_t<256, 2, 2, GROUPED, 3>(a, ksplit);
   }
 }
@@ -1083,8 +1213,8 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
     if (e != hipSuccess) return fail_hip(e, "qqq_stream_kernel launch");
     if (ksplit > 1 && fused != 1) {
       const long long items = (long long)M * (N / 4);
-      const int blocks = (int)((items + 255) / 256 > 2048 ? 2048 : (items + 255) / 256);
-      hipLaunchKernelGGL(qqq_reduce_kernel, dim3(blocks), dim3(256), 0, a.stream, a.C, a.D, a.s1, a.s2,
+      const int blocks = (int)((items + 63) / 64 > 8192 ? 8192 : (items + 63) / 64);
+      hipLaunchKernelGGL(qqq_reduce_kernel, dim3(blocks), dim3(64), 0, a.stream, a.C, a.D, a.s1, a.s2,
                          a.acc_out, M, N, ksplit);
       e = hipGetLastError();
       if (e != hipSuccess) return fail_hip(e, "qqq_reduce_kernel launch");
@@ -1094,7 +1224,7 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
 
   // ---- tiled ----
   int bm = t.bm;
-  if (bm != 64 && bm != 128 && bm != 256) {
+  if (bm != 64 && bm != 128 && bm != 256 && bm != 257) {
     const long long t256 = (long long)((M + 255) / 256) * ((N + 255) / 256);
     const long long t128 = (long long)((M + 127) / 128) * ((N + 255) / 256);
     if (t256 >= 384)
@@ -1108,10 +1238,11 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
   // 8-wave 256-row tile, register staging is faster for the 4-wave tiles (measured)
   int stages;
   if (t.glds == 2) stages = 0;
-  else if (t.glds == 1) stages = (t.stages >= 2 && t.stages <= 4) ? t.stages : (bm == 256 ? 3 : 4);
-  else stages = (bm == 256) ? 2 : 0;
-  if (bm == 256 && stages > 3) stages = 3;
-  const long long tiles = (long long)((M + bm - 1) / bm) * ((N + 255) / 256);
+  else if (t.glds == 1) stages = ((t.stages >= 2 && t.stages <= 4) || (t.stages == 5 && bm == 256)) ? t.stages : (bm == 256 ? 3 : 4);
+  else stages = (bm == 256) ? 5 : 0;  // 256-row tile: 3-stage DMA ring + ping-pong schedule
+  if (bm == 256 && stages == 4) stages = 3;
+  const int bm_rows = (bm == 257) ? 256 : bm;
+  const long long tiles = (long long)((M + bm_rows - 1) / bm_rows) * ((N + 255) / 256);
   ksplit = t.ksplit;
   if (ksplit <= 0) {
     ksplit = tiles >= 192 ? 1 : (int)((256 + tiles - 1) / tiles);
@@ -1125,8 +1256,8 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
   if (e != hipSuccess) return fail_hip(e, "qqq_tiled_kernel launch");
   if (ksplit > 1) {
     const long long items = (long long)M * (N / 4);
-    const int blocks = (int)((items + 255) / 256 > 2048 ? 2048 : (items + 255) / 256);
-    hipLaunchKernelGGL(qqq_reduce_kernel, dim3(blocks), dim3(256), 0, a.stream, a.C, a.D, a.s1, a.s2,
+    const int blocks = (int)((items + 63) / 64 > 8192 ? 8192 : (items + 63) / 64);
+    hipLaunchKernelGGL(qqq_reduce_kernel, dim3(blocks), dim3(64), 0, a.stream, a.C, a.D, a.s1, a.s2,
                        a.acc_out, M, N, ksplit);
     e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "qqq_reduce_kernel launch");

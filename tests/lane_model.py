@@ -193,12 +193,14 @@ def tiled_kernel_model(A, B, s3, M, N, K, BM, MTW, JW, ksplit, grouped, return_t
                     wm, wn = wave // WN, wave % WN
                     if grouped:
                         ngx = np.minimum(ng0 + g, ngroups - 1)
-                        so = ngx * 64 + c * 8 + wn * 2 * JW + kb * N
+                        wsel_s = (wn ^ (c >> 2)) if JW == 2 else wn
+                        so = ngx * 64 + c * 8 + wsel_s * 2 * JW + kb * N
                         sc = s3h[so[:, None] + np.arange(2 * JW)[None, :]]
                     for t in range(4):
                         wq = np.zeros((64, 4, JW), np.uint32)
+                        wsel = (wn ^ (c >> 2)) if JW == 2 else wn
                         for kq in range(4):
-                            off = h * 2048 + g * 512 + (4 * c + (kq ^ g)) * 16 + wn * JW * 4 + t * 4096
+                            off = h * 2048 + g * 512 + (4 * c + (kq ^ g)) * 16 + wsel * JW * 4 + t * 4096
                             raw = lds[off[:, None] + np.arange(4 * JW)[None, :]].reshape(64, JW, 4)
                             wq[:, kq, :] = (raw.astype(np.uint32) << (8 * np.arange(4, dtype=np.uint32))).sum(-1)
                         xops = []
@@ -220,7 +222,7 @@ def tiled_kernel_model(A, B, s3, M, N, K, BM, MTW, JW, ksplit, grouped, return_t
             for wave in range(WM * WN):
                 wm, wn = wave // WN, wave % WN
                 for jj in range(JW):
-                    jt = wn * JW + jj
+                    jt = ((wn ^ h) if JW == 2 else wn) * JW + jj
                     for b in range(2):
                         for gq in range(4):
                             n = ng0 * 64 + 4 * h + 64 * gq + 16 * jt + 8 * b

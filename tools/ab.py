@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Interleaved A/B timing of library builds x tuning variants (within one process, rotating weights).
+usage: LIBS="a.so,b.so" TUNES="[dict(...),...]" MS="4096" MODE=pc python tools/ab.py"""
+import ctypes, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench as Bn
+from qqq_amd import _lib
+
+def load(path):
+    L = ctypes.CDLL(path)
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    L.qqq_bench_gemm.argtypes = [vp, ctypes.POINTER(vp), ci, vp, vp, vp, vp, vp, ci, ci, ci, vp, ci, ci, vp, ci,
+                                 ctypes.POINTER(_lib.QQQTune), ci, ctypes.POINTER(ctypes.c_float)]
+    L.qqq_bench_gemm.restype = ci
+    L.qqq_amd_last_error.restype = ctypes.c_char_p
+    return L
+
+dev = torch.device("cuda:0")
+libs = [p for p in os.environ.get("LIBS", "qqq_amd/libqqq_amd.so").split(",")]
+Ls = [load(os.path.join(ROOT, p) if not os.path.isabs(p) else p) for p in libs]
+tunes = eval(os.environ.get("TUNES", "[None]"))
+Ms = [int(x) for x in os.environ.get("MS", "4096").split(",")]
+grouped = os.environ.get("MODE", "pc") == "g128"
+rounds = int(os.environ.get("ROUNDS", "5"))
+iters = int(os.environ.get("ITERS", "4"))
+layer = Bn.Layer(dev, grouped=grouped, nbuf=int(os.environ.get("NBUF", "4")))
+arr = (ctypes.c_void_p * len(layer.Bs))(*[b.data_ptr() for b in layer.Bs])
+for M in Ms:
+    A, s1 = Bn.make_tokens(dev, M, M)
+    D = torch.empty((M, Bn.N_FULL), dtype=torch.float16, device=dev)
+    res = {}
+    def run(L, tune, n):
+        out = (ctypes.c_float * n)()
+        tn = None
+        if tune:
+            tn = _lib.QQQTune()
+            for k, v in tune.items(): setattr(tn, k, int(v))
+        st = torch.cuda.current_stream(dev).cuda_stream
+        rc = L.qqq_bench_gemm(A.data_ptr(), arr, len(layer.Bs), layer.C.data_ptr(), D.data_ptr(), s1.data_ptr(), layer.s2.data_ptr(),
+                              layer.s3.data_ptr() if layer.s3.numel() else None, M, layer.N, layer.K, layer.ws.data_ptr(),
+                              layer.groupsize, 0, ctypes.c_void_p(st), 16, ctypes.byref(tn) if tn is not None else None, n, out)
+        assert rc == 0, (rc, L.qqq_amd_last_error())
+        return np.array(out[:]) * 1e3
+    for li, L in enumerate(Ls):
+        for tune in tunes: run(L, tune, 2)
+    for r in range(rounds):
+        for li, L in enumerate(Ls):
+            for ti, tune in enumerate(tunes):
+                res.setdefault((li, ti), []).extend(run(L, tune, iters))
+    ops = Bn.algorithmic_ops(M, Bn.N_FULL, Bn.K_FULL); byts = Bn.algorithmic_bytes(M, Bn.N_FULL, Bn.K_FULL, grouped)
+    for (li, ti), v in sorted(res.items()):
+        v = np.array(v)
+        print(f"M={M} {os.path.basename(libs[li]):24s} {str(tunes[ti]):60s} med {np.median(v):8.1f} us  min {v.min():8.1f}  {ops/np.median(v)/1e6:7.0f} TOPS {byts/np.median(v)/1e3:6.0f} GB/s")
