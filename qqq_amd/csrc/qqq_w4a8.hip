@@ -421,14 +421,19 @@ __global__ __launch_bounds__(64) void qqq_reduce_kernel(const int32_t* __restric
 // p ^ ((row >> 1) & 7)).  With global_load_lds the LDS image is lane-linear, so the swizzle is
 // applied to the per-lane SOURCE address; the register-staged variant writes the same image.
 
-template <int BM, int MTW, int JW, bool GROUPED, int NS>
-__global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * 64) void qqq_tiled_kernel(
+template <int BM, int MTW, int JW, int NB, bool GROUPED, int NS>
+__global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * (2 / NB) * 64) void qqq_tiled_kernel(
     const int8_t* __restrict__ A, const unsigned char* __restrict__ B, int32_t* __restrict__ C,
     _Float16* __restrict__ D, const float* __restrict__ s1, const float* __restrict__ s2,
     const _Float16* __restrict__ s3, int32_t* __restrict__ acc_out, const int M, const int N,
     const int K, const int ksplit, const int tiles_m, const int tiles_n) {
+  // wave tile: MTW m-tiles of 32 tokens x JW column tiles (jt) x NB column halves (b).  NB == 1: the two
+  // b halves of a packed word go to two different waves (per-group mode: every weight is re-quantised
+  // by exactly one wave of the workgroup).
+  static_assert(NB == 1 || NB == 2, "NB");
+  static_assert(JW == 1 || JW == 2 || JW == 4, "JW");
   constexpr int WM = BM / (32 * MTW);
-  constexpr int WN = 4 / JW;
+  constexpr int WN = (4 / JW) * (2 / NB);
   constexpr int NT = WM * WN * 64;
   constexpr int W_BYTES = 8 * 2048;
   constexpr int X_BYTES = BM * 128;
@@ -453,7 +458,8 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * 64) void qqq_tiled_k
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN;
-  const int wn = wave % WN;
+  const int wn = (wave % WN) / (2 / NB);    // which jt set
+  const int bsel = (wave % WN) % (2 / NB);  // which b half (NB == 1 only; 0 otherwise)
 
   // ---- XCD-aware tile order: block b runs on XCD b % 8; give each XCD a contiguous run of the
   // panel-major tile sequence (panels of 4 strips x all m-tiles) so co-resident workgroups of one
@@ -515,16 +521,20 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * 64) void qqq_tiled_k
   // ---- per-lane LDS read offsets ----
   const int li = lane & 31, h = lane >> 5;
   const int g = li >> 3, c = li & 7;
-  // Which jt of the 16-byte chunk this lane consumes.  With JW == 2 a lane reads 8 of the 16 bytes; lanes
-  // c < 4 take the half `wn`, lanes c >= 4 the OTHER half: the 32 lanes of a ds_read_b64 group then
-  // cover all 64 banks exactly once (a fixed half would be a 2-way conflict).  This is only another
-  // row<->column permutation of the MFMA tile (the sibling wave wn^1 takes the complementary halves);
-  // the epilogue and the group-scale addresses use the same lane-dependent jt.
-  const int wsel = (JW == 2) ? (wn ^ (c >> 2)) : wn;
+  // Which jt of the 16-byte chunk this lane consumes.  A lane reads 8 of the 16 bytes (JW <= 2); lanes
+  // c < 4 take one half, lanes c >= 4 the OTHER half: the 32 lanes of a ds_read_b64 group then cover
+  // all 64 banks exactly once (a fixed half would be a 2-way conflict).  This is only another
+  // row<->column permutation of the MFMA tile (a sibling wave takes the complementary halves); the
+  // epilogue and the group-scale addresses use the same lane-dependent jt.
+  //   JW == 2: half = wn ^ (c >> 2), jt = 2*half + jj
+  //   JW == 1: half = (wn >> 1) ^ (c >> 2), jt = 2*half + (wn & 1)   (8 bytes read, one dword used)
+  const int half = (JW == 2) ? (wn ^ (c >> 2)) : (JW == 1) ? ((wn >> 1) ^ (c >> 2)) : 0;
+  const int esel = (JW == 1) ? (wn & 1) : 0;
+  const int jt0 = (JW == 4) ? 0 : 2 * half + esel;  // first jt of this lane
   unsigned wrd[4];  // + t*4096
 #pragma unroll
   for (int kq = 0; kq < 4; ++kq)
-    wrd[kq] = h * 2048 + g * 512 + (4 * c + (kq ^ g)) * 16 + wsel * (JW * 4);  // this lane's jt only
+    wrd[kq] = h * 2048 + g * 512 + (4 * c + (kq ^ g)) * 16 + ((JW == 4) ? 0 : half * 8);
   unsigned xrd[4];  // per k-step t; + mt*32*128
 #pragma unroll
   for (int t = 0; t < 4; ++t)
@@ -536,20 +546,20 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * 64) void qqq_tiled_k
   if constexpr (GROUPED) {
     int ngx = ng0 + g;
     if (ngx >= ngroups) ngx = ngroups - 1;
-    sptr = s3 + (size_t)ngx * 64 + c * 8 + wsel * (2 * JW);
+    sptr = s3 + (size_t)ngx * 64 + c * 8 + 2 * jt0;
     int ngl = ng0 + ((lane & 31) >> 3);
     if (ngl >= ngroups) ngl = ngroups - 1;
     scsrc = (unsigned)((ngl * 64 + (lane & 7) * 8) * 2);
-    scrd = W_BYTES + X_BYTES + wave * 512 + (g * 64 + c * 8 + wsel * (2 * JW)) * 2;
+    scrd = W_BYTES + X_BYTES + wave * 512 + (g * 64 + c * 8 + 2 * jt0) * 2;
   }
 
-  v16i acc[MTW][JW][2];
+  v16i acc[MTW][JW][NB];
 #pragma unroll
   for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
     for (int jj = 0; jj < JW; ++jj)
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
+      for (int b = 0; b < NB; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mt][jj][b][r] = 0;
 
@@ -626,44 +636,17 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * 64) void qqq_tiled_k
         const uint2 v = *reinterpret_cast<const uint2*>(p);
         f.wq[kq][0] = v.x; f.wq[kq][1] = v.y;
       } else {
-        f.wq[kq][0] = *reinterpret_cast<const unsigned*>(p);
+        const uint2 v = *reinterpret_cast<const uint2*>(p);  // conflict-free b64, one dword used
+        f.wq[kq][0] = esel ? v.y : v.x;
       }
     }
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt)
       f.xop[mt] = *reinterpret_cast<const v4i*>(st + xrd[t] + mt * (32 * 128));
   };
-  auto mma_frag = [&](const Frag& f) {
-#pragma unroll
-    for (int jj = 0; jj < JW; ++jj) {
-      v4i a0, a1;
-      h2 sb0 = {(_Float16)0, (_Float16)0}, sb1 = sb0;
-      if constexpr (GROUPED) {
-        sb0 = (h2){sc_cur[2 * jj], sc_cur[2 * jj]};
-        sb1 = (h2){sc_cur[2 * jj + 1], sc_cur[2 * jj + 1]};
-      }
-#pragma unroll
-      for (int kq = 0; kq < 4; ++kq) {
-        int w0, w1;
-#if defined(QQQ_ABLATE) && (QQQ_ABLATE & 4)  // ablation: no unpack VALU
-        w0 = (int)f.wq[kq][jj];
-        w1 = (int)f.wq[kq][jj];
-#else
-        unpack_pair<GROUPED>(f.wq[kq][jj], sb0, sb1, w0, w1);
-#endif
-        a0[kq] = w0;
-        a1[kq] = w1;
-      }
-#pragma unroll
-      for (int mt = 0; mt < MTW; ++mt) {
-        acc[mt][jj][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, f.xop[mt], acc[mt][jj][0], 0, 0, 0);
-        acc[mt][jj][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, f.xop[mt], acc[mt][jj][1], 0, 0, 0);
-      }
-    }
-  };
-  // the same work split in two halves for the ping-pong schedule
+  // unpacked MFMA weight operands of one k-step
   struct Ops {
-    v4i a[JW][2];
+    v4i a[JW][NB];
   };
   auto unpack_frag = [&](const Frag& f, Ops& o) {
 #pragma unroll
@@ -675,15 +658,22 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * 64) void qqq_tiled_k
       }
 #pragma unroll
       for (int kq = 0; kq < 4; ++kq) {
-        int w0, w1;
-#if defined(QQQ_ABLATE) && (QQQ_ABLATE & 4)
-        w0 = (int)f.wq[kq][jj];
-        w1 = (int)f.wq[kq][jj];
+        const unsigned q = f.wq[kq][jj];
+#if defined(QQQ_ABLATE) && (QQQ_ABLATE & 4)  // ablation: no unpack VALU
+#pragma unroll
+        for (int bi = 0; bi < NB; ++bi) o.a[jj][bi][kq] = (int)q;
 #else
-        unpack_pair<GROUPED>(f.wq[kq][jj], sb0, sb1, w0, w1);
+        if constexpr (NB == 2) {
+          int w0, w1;
+          unpack_pair<GROUPED>(q, sb0, sb1, w0, w1);
+          o.a[jj][0][kq] = w0;
+          o.a[jj][1][kq] = w1;
+        } else if constexpr (GROUPED) {  // one b half per wave (bsel is wave-uniform)
+          o.a[jj][0][kq] = (int)dequant_group4(q >> (8 * bsel), bsel ? sb1 : sb0);
+        } else {
+          o.a[jj][0][kq] = (int)((q << (4 * bsel)) & QQQ_NIB_MASK);
+        }
 #endif
-        o.a[jj][0][kq] = w0;
-        o.a[jj][1][kq] = w1;
       }
     }
   };
@@ -691,10 +681,15 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * 64) void qqq_tiled_k
 #pragma unroll
     for (int jj = 0; jj < JW; ++jj)
 #pragma unroll
-      for (int mt = 0; mt < MTW; ++mt) {
-        acc[mt][jj][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.a[jj][0], f.xop[mt], acc[mt][jj][0], 0, 0, 0);
-        acc[mt][jj][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.a[jj][1], f.xop[mt], acc[mt][jj][1], 0, 0, 0);
-      }
+      for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int bi = 0; bi < NB; ++bi)
+          acc[mt][jj][bi] = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.a[jj][bi], f.xop[mt], acc[mt][jj][bi], 0, 0, 0);
+  };
+  auto mma_frag = [&](const Frag& f) {
+    Ops o;
+    unpack_frag(f, o);
+    mfma_ops(o, f);
   };
   // software pipeline inside a stage: the LDS reads of k-step t+1 are issued before the MFMAs of
   // k-step t, so their latency hides under the matrix pipe instead of stalling the (in-order) wave
@@ -838,19 +833,19 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * 64) void qqq_tiled_k
 #pragma unroll
   for (int jj = 0; jj < JW; ++jj) {
     // D-tile rows of this lane have c = 4*h + (r & 3): c >> 2 == h, so the lane's jt is uniform over r
-    const int jt = ((JW == 2) ? (wn ^ h) : wn) * JW + jj;
+    const int jt = (JW == 4) ? jj : (JW == 2) ? 2 * (wn ^ h) + jj : 2 * ((wn >> 1) ^ h) + (wn & 1);
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int bi = 0; bi < NB; ++bi)
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
-        const int n = n_lane + 64 * gq + 16 * jt + 8 * b;
+        const int n = n_lane + 64 * gq + 16 * jt + 8 * ((NB == 2) ? bi : bsel);
         if (n >= N) continue;
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt) {
           const int m = mrow[mt];
           if (m >= M) continue;
-          const int v0 = acc[mt][jj][b][4 * gq + 0], v1 = acc[mt][jj][b][4 * gq + 1];
-          const int v2 = acc[mt][jj][b][4 * gq + 2], v3 = acc[mt][jj][b][4 * gq + 3];
+          const int v0 = acc[mt][jj][bi][4 * gq + 0], v1 = acc[mt][jj][bi][4 * gq + 1];
+          const int v2 = acc[mt][jj][bi][4 * gq + 2], v3 = acc[mt][jj][bi][4 * gq + 3];
           if (ksplit == 1) {
             epilogue_store4(v0, v1, v2, v3, m, n, N, a_s[mt], s2, D, acc_out);
           } else {
@@ -1078,15 +1073,15 @@ static hipError_t launch_stream(const LaunchArgs& a, bool grouped, int mt, int w
   return launch_stream_mt<false, 8>(a, mt, pf, ksplit, fused);
 }
 
-template <int BM, int MTW, int JW, bool GROUPED, int NS>
+template <int BM, int MTW, int JW, int NB, bool GROUPED, int NS>
 static hipError_t launch_tiled_t(const LaunchArgs& a, int ksplit) {
-  constexpr int WAVES = (BM / (32 * MTW)) * (4 / JW);
+  constexpr int WAVES = (BM / (32 * MTW)) * (4 / JW) * (2 / NB);
   constexpr int NT = WAVES * 64;
   constexpr int STAGE = 8 * 2048 + BM * 128 + ((NS > 0 && GROUPED) ? WAVES * 512 : 0);
   constexpr int LDS = (NS == 5 ? 3 : (NS > 0 ? NS : 2)) * STAGE;
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static bool attr_set[64] = {};  // per instantiation, per device
-  auto kern = qqq_tiled_kernel<BM, MTW, JW, GROUPED, NS>;
+  auto kern = qqq_tiled_kernel<BM, MTW, JW, NB, GROUPED, NS>;
   int cur = 0;
   (void)hipGetDevice(&cur);
   if (cur < 0 || cur >= 64 || !attr_set[cur]) {
@@ -1107,24 +1102,46 @@ template <bool GROUPED>
 static hipError_t launch_tiled_bm(const LaunchArgs& a, int bm, int stages, int ksplit) {
   switch (bm) {
     case 64:
-      if (stages == 0) return launch_tiled_t<64, 1, 2, GROUPED, 0>(a, ksplit);
-      if (stages == 2) return launch_tiled_t<64, 1, 2, GROUPED, 2>(a, ksplit);
-      if (stages == 3) return launch_tiled_t<64, 1, 2, GROUPED, 3>(a, ksplit);
-      return launch_tiled_t<64, 1, 2, GROUPED, 4>(a, ksplit);
+      if (stages == 0) return launch_tiled_t<64, 1, 2, 2, GROUPED, 0>(a, ksplit);
+      if (stages == 2) return launch_tiled_t<64, 1, 2, 2, GROUPED, 2>(a, ksplit);
+      if (stages == 3) return launch_tiled_t<64, 1, 2, 2, GROUPED, 3>(a, ksplit);
+      return launch_tiled_t<64, 1, 2, 2, GROUPED, 4>(a, ksplit);
     case 128:
-      if (stages == 0) return launch_tiled_t<128, 2, 2, GROUPED, 0>(a, ksplit);
-      if (stages == 2) return launch_tiled_t<128, 2, 2, GROUPED, 2>(a, ksplit);
-      if (stages == 3) return launch_tiled_t<128, 2, 2, GROUPED, 3>(a, ksplit);
-      return launch_tiled_t<128, 2, 2, GROUPED, 4>(a, ksplit);
+      if (stages == 0) return launch_tiled_t<128, 2, 2, 2, GROUPED, 0>(a, ksplit);
+      if (stages == 2) return launch_tiled_t<128, 2, 2, 2, GROUPED, 2>(a, ksplit);
+      if (stages == 3) return launch_tiled_t<128, 2, 2, 2, GROUPED, 3>(a, ksplit);
+      return launch_tiled_t<128, 2, 2, 2, GROUPED, 4>(a, ksplit);
+    case 130:  // 128-row tile, 8 waves, each wave owns ONE (jt, b) column set over all 128 rows
+      if (stages == 0) return launch_tiled_t<128, 4, 1, 1, GROUPED, 0>(a, ksplit);
+      if (stages == 2) return launch_tiled_t<128, 4, 1, 1, GROUPED, 2>(a, ksplit);
+      if (stages == 3) return launch_tiled_t<128, 4, 1, 1, GROUPED, 3>(a, ksplit);
+      if (stages == 5) return launch_tiled_t<128, 4, 1, 1, GROUPED, 5>(a, ksplit);
+      return launch_tiled_t<128, 4, 1, 1, GROUPED, 4>(a, ksplit);
+    case 131:  // 128-row tile, 8 waves as 2 (m) x 4 (jt): wave = 64 rows x one jt, both b
+      if (stages == 0) return launch_tiled_t<128, 2, 1, 2, GROUPED, 0>(a, ksplit);
+      if (stages == 2) return launch_tiled_t<128, 2, 1, 2, GROUPED, 2>(a, ksplit);
+      if (stages == 3) return launch_tiled_t<128, 2, 1, 2, GROUPED, 3>(a, ksplit);
+      if (stages == 5) return launch_tiled_t<128, 2, 1, 2, GROUPED, 5>(a, ksplit);
+      return launch_tiled_t<128, 2, 1, 2, GROUPED, 4>(a, ksplit);
+    case 258:  // 256-row tile, 8 waves, each wave owns ONE (jt, b) column set over all 256 rows
+      if (stages == 0) return launch_tiled_t<256, 8, 1, 1, GROUPED, 0>(a, ksplit);
+      if (stages == 2) return launch_tiled_t<256, 8, 1, 1, GROUPED, 2>(a, ksplit);
+      if (stages == 5) return launch_tiled_t<256, 8, 1, 1, GROUPED, 5>(a, ksplit);
+      return launch_tiled_t<256, 8, 1, 1, GROUPED, 3>(a, ksplit);
+    case 259:  // 256-row tile, 8 waves as 2 (m) x 4 (jt): wave = 128 rows x one jt, both b
+      if (stages == 0) return launch_tiled_t<256, 4, 1, 2, GROUPED, 0>(a, ksplit);
+      if (stages == 2) return launch_tiled_t<256, 4, 1, 2, GROUPED, 2>(a, ksplit);
+      if (stages == 5) return launch_tiled_t<256, 4, 1, 2, GROUPED, 5>(a, ksplit);
+      return launch_tiled_t<256, 4, 1, 2, GROUPED, 3>(a, ksplit);
     case 257:  // experimental: 256-row tile as 4 waves x (128 x 128), one wave per SIMD
-      if (stages == 0) return launch_tiled_t<256, 4, 2, GROUPED, 0>(a, ksplit);
-      if (stages == 2) return launch_tiled_t<256, 4, 2, GROUPED, 2>(a, ksplit);
-      return launch_tiled_t<256, 4, 2, GROUPED, 3>(a, ksplit);
+      if (stages == 0) return launch_tiled_t<256, 4, 2, 2, GROUPED, 0>(a, ksplit);
+      if (stages == 2) return launch_tiled_t<256, 4, 2, 2, GROUPED, 2>(a, ksplit);
+      return launch_tiled_t<256, 4, 2, 2, GROUPED, 3>(a, ksplit);
     default:
-      if (stages == 0) return launch_tiled_t<256, 2, 2, GROUPED, 0>(a, ksplit);
-      if (stages == 2) return launch_tiled_t<256, 2, 2, GROUPED, 2>(a, ksplit);
-      if (stages == 5) return launch_tiled_t<256, 2, 2, GROUPED, 5>(a, ksplit);
-      return launch_tiled_t<256, 2, 2, GROUPED, 3>(a, ksplit);
+      if (stages == 0) return launch_tiled_t<256, 2, 2, 2, GROUPED, 0>(a, ksplit);
+      if (stages == 2) return launch_tiled_t<256, 2, 2, 2, GROUPED, 2>(a, ksplit);
+      if (stages == 5) return launch_tiled_t<256, 2, 2, 2, GROUPED, 5>(a, ksplit);
+      return launch_tiled_t<256, 2, 2, 2, GROUPED, 3>(a, ksplit);
   }
 }
 
@@ -1224,13 +1241,16 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
 
   // ---- tiled ----
   int bm = t.bm;
-  if (bm != 64 && bm != 128 && bm != 256 && bm != 257) {
+  if (bm != 64 && bm != 128 && bm != 256 && bm != 257 && bm != 258 && bm != 259 && bm != 130 && bm != 131) {
     const long long t256 = (long long)((M + 255) / 256) * ((N + 255) / 256);
     const long long t128 = (long long)((M + 127) / 128) * ((N + 255) / 256);
+    // wave shapes per mode (measured, profiles/): per-channel keeps 64x128 wave tiles (least LDS traffic);
+    // per-group uses the column-owner shape (258 / 130) so that every weight is re-quantised once per
+    // workgroup instead of once per wave row.
     if (t256 >= 384)
-      bm = 256;
+      bm = grouped ? 258 : 256;
     else if (t128 >= 192 || M > 64)
-      bm = 128;
+      bm = grouped ? 130 : 131;
     else
       bm = 64;
   }
@@ -1238,10 +1258,10 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
   // 8-wave 256-row tile, register staging is faster for the 4-wave tiles (measured)
   int stages;
   if (t.glds == 2) stages = 0;
-  else if (t.glds == 1) stages = ((t.stages >= 2 && t.stages <= 4) || (t.stages == 5 && bm == 256)) ? t.stages : (bm == 256 ? 3 : 4);
-  else stages = (bm == 256) ? 5 : 0;  // 256-row tile: 3-stage DMA ring + ping-pong schedule
-  if (bm == 256 && stages == 4) stages = 3;
-  const int bm_rows = (bm == 257) ? 256 : bm;
+  else if (t.glds == 1) stages = ((t.stages >= 2 && t.stages <= 4) || (t.stages == 5 && bm != 64 && bm != 128)) ? t.stages : (bm >= 256 ? 3 : 4);
+  else stages = (bm == 256) ? 5 : (bm == 258) ? 3 : (bm == 130) ? 4 : 0;  // measured best per shape
+  if (bm >= 256 && stages == 4) stages = 3;
+  const int bm_rows = (bm >= 256) ? 256 : (bm >= 128 ? 128 : bm);
   const long long tiles = (long long)((M + bm_rows - 1) / bm_rows) * ((N + 255) / 256);
   ksplit = t.ksplit;
   if (ksplit <= 0) {

@@ -135,11 +135,11 @@ def stream_kernel_model(A, B, s3, M, N, K, MT, WAVES, ksplit, grouped):
     return out
 
 
-def tiled_kernel_model(A, B, s3, M, N, K, BM, MTW, JW, ksplit, grouped, return_tile_order=False):
+def tiled_kernel_model(A, B, s3, M, N, K, BM, MTW, JW, ksplit, grouped, return_tile_order=False, NB=2):
     Bb = np.ascontiguousarray(B).view(np.uint8).reshape(-1)
     Ab = np.ascontiguousarray(A).view(np.uint8).reshape(-1)
     s3h = None if not grouped else np.ascontiguousarray(s3).reshape(-1)
-    WM, WN = BM // (32 * MTW), 4 // JW
+    WM, WN = BM // (32 * MTW), (4 // JW) * (2 // NB)
     NT = WM * WN * 64
     W_BYTES, X_BYTES = 8 * 2048, BM * 128
     W_CHUNKS, X_CHUNKS = W_BYTES // 16, X_BYTES // 16
@@ -166,7 +166,7 @@ def tiled_kernel_model(A, B, s3, M, N, K, BM, MTW, JW, ksplit, grouped, return_t
         m0, ng0 = tile_m * BM, tile_n * 4
         for sp in range(ksplit):
             kb_begin, kb_end = (NKB * sp) // ksplit, (NKB * (sp + 1)) // ksplit
-            acc = np.zeros((WM * WN, MTW, JW, 2, 64, 16), np.int64)
+            acc = np.zeros((WM * WN, MTW, JW, NB, 64, 16), np.int64)
             for kb in range(kb_begin, kb_end):
                 # ---- build the LDS stage image exactly as the staging threads do ----
                 lds = np.zeros(W_BYTES + X_BYTES, np.uint8)
@@ -190,19 +190,26 @@ def tiled_kernel_model(A, B, s3, M, N, K, BM, MTW, JW, ksplit, grouped, return_t
                 li, h = lane & 31, lane >> 5
                 g, c = li >> 3, li & 7
                 for wave in range(WM * WN):
-                    wm, wn = wave // WN, wave % WN
+                    wm = wave // WN
+                    wn, bsel = (wave % WN) // (2 // NB), (wave % WN) % (2 // NB)
+                    half = (wn ^ (c >> 2)) if JW == 2 else (((wn >> 1) ^ (c >> 2)) if JW == 1 else 0 * c)
+                    esel = (wn & 1) if JW == 1 else 0
+                    jt0 = 0 * c if JW == 4 else 2 * half + esel
                     if grouped:
                         ngx = np.minimum(ng0 + g, ngroups - 1)
-                        wsel_s = (wn ^ (c >> 2)) if JW == 2 else wn
-                        so = ngx * 64 + c * 8 + wsel_s * 2 * JW + kb * N
+                        so = ngx * 64 + c * 8 + 2 * jt0 + kb * N
                         sc = s3h[so[:, None] + np.arange(2 * JW)[None, :]]
                     for t in range(4):
                         wq = np.zeros((64, 4, JW), np.uint32)
-                        wsel = (wn ^ (c >> 2)) if JW == 2 else wn
                         for kq in range(4):
-                            off = h * 2048 + g * 512 + (4 * c + (kq ^ g)) * 16 + wsel * JW * 4 + t * 4096
-                            raw = lds[off[:, None] + np.arange(4 * JW)[None, :]].reshape(64, JW, 4)
-                            wq[:, kq, :] = (raw.astype(np.uint32) << (8 * np.arange(4, dtype=np.uint32))).sum(-1)
+                            off = h * 2048 + g * 512 + (4 * c + (kq ^ g)) * 16 + (0 if JW == 4 else half * 8) + t * 4096
+                            nby = 16 if JW == 4 else 8
+                            raw = lds[off[:, None] + np.arange(nby)[None, :]].reshape(64, nby // 4, 4)
+                            words = (raw.astype(np.uint32) << (8 * np.arange(4, dtype=np.uint32))).sum(-1)
+                            if JW == 1:
+                                wq[:, kq, 0] = words[:, esel]
+                            else:
+                                wq[:, kq, :] = words
                         xops = []
                         for mt in range(MTW):
                             xo = W_BYTES + (wm * MTW * 32 + li) * 128 + (((2 * t + h) ^ ((li >> 1) & 7)) * 16) + mt * 32 * 128
@@ -212,25 +219,28 @@ def tiled_kernel_model(A, B, s3, M, N, K, BM, MTW, JW, ksplit, grouped, return_t
                                 w0, w1 = unpack_pair(wq[:, :, jj], True, sc[:, 2 * jj][:, None], sc[:, 2 * jj + 1][:, None])
                             else:
                                 w0, w1 = unpack_pair(wq[:, :, jj], False)
-                            a0, a1 = _bytes_to_i8(w0), _bytes_to_i8(w1)
-                            for mt in range(MTW):
-                                acc[wave, mt, jj, 0] += mfma_32x32x32(a0, xops[mt])
-                                acc[wave, mt, jj, 1] += mfma_32x32x32(a1, xops[mt])
+                            ws = [w0, w1] if NB == 2 else [w1 if bsel else w0]
+                            for bi, w in enumerate(ws):
+                                a = _bytes_to_i8(w)
+                                for mt in range(MTW):
+                                    acc[wave, mt, jj, bi] += mfma_32x32x32(a, xops[mt])
             # ---- epilogue mapping ----
             lane = np.arange(64)
             li, h = lane & 31, lane >> 5
             for wave in range(WM * WN):
-                wm, wn = wave // WN, wave % WN
+                wm = wave // WN
+                wn, bsel = (wave % WN) // (2 // NB), (wave % WN) % (2 // NB)
                 for jj in range(JW):
-                    jt = ((wn ^ h) if JW == 2 else wn) * JW + jj
-                    for b in range(2):
+                    jt = jj + 0 * h if JW == 4 else (2 * (wn ^ h) + jj if JW == 2 else 2 * ((wn >> 1) ^ h) + (wn & 1))
+                    for bi in range(NB):
+                        b = bi if NB == 2 else bsel
                         for gq in range(4):
                             n = ng0 * 64 + 4 * h + 64 * gq + 16 * jt + 8 * b
                             for mt in range(MTW):
                                 m = m0 + (wm * MTW + mt) * 32 + li
                                 for ln in range(64):
                                     if n[ln] < N and m[ln] < M:
-                                        out[m[ln], n[ln] : n[ln] + 4] += acc[wave, mt, jj, b, ln, 4 * gq : 4 * gq + 4]
+                                        out[m[ln], n[ln] : n[ln] + 4] += acc[wave, mt, jj, bi, ln, 4 * gq : 4 * gq + 4]
     if return_tile_order:
         return out, seen
     return out

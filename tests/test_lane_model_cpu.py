@@ -38,6 +38,9 @@ def test_tiled_kernel_model(grouped):
     assert np.array_equal(out, acc)
     assert len(set(order)) == len(order)
     assert np.array_equal(LM.tiled_kernel_model(A, B, s3, 70, 320, 256, BM=128, MTW=2, JW=2, ksplit=1, grouped=grouped), acc)
+    # wave shapes of the 256-row tile: column-owner (one (jt, b) per wave) and 128 rows x one jt
+    assert np.array_equal(LM.tiled_kernel_model(A, B, s3, 70, 320, 256, BM=256, MTW=8, JW=1, ksplit=1, grouped=grouped, NB=1), acc)
+    assert np.array_equal(LM.tiled_kernel_model(A, B, s3, 70, 320, 256, BM=256, MTW=4, JW=1, ksplit=2, grouped=grouped, NB=2), acc)
 
 
 def test_lds_swizzles_are_bank_conflict_free():
