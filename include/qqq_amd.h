@@ -69,11 +69,13 @@ typedef struct qqq_tune {
 } qqq_tune_t;
 
 /* As qqq_w4a8_gemm; `tune` may be NULL; if `acc_out` != NULL the raw int32 accumulators
- * ([m,n] row-major; x16 convention in per-channel mode) are also written there. */
+ * ([m,n] row-major; x16 convention in per-channel mode) are also written there; if
+ * `bias` != NULL (fp16 [n]) the epilogue adds it in fp16 after the fp16 round, i.e. exactly the
+ * reference's separate `D + self.bias` (qlinear_marlin.py:287) without the extra pass over D. */
 int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, const void* s1, const void* s2,
                      const void* s3, int prob_m, int prob_n, int prob_k, void* workspace,
                      int groupsize, int dev, void* stream, int thread_k, int thread_n, int sms,
-                     int max_par, const qqq_tune_t* tune, int32_t* acc_out);
+                     int max_par, const qqq_tune_t* tune, int32_t* acc_out, const void* bias);
 
 /*
  * Fused per-token dynamic int8 quantisation; replaces the ~8 torch launches of

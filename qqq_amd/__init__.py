@@ -12,8 +12,9 @@ from .ops import (  # noqa: F401
     marlin_qqq_gemm,
     mul,
     qqq_gemm,
+    qqq_gemm_bias,
     qqq_gemm_ex,
 )
 from .qlinear import QuantLinear  # noqa: F401
 
-__all__ = ["qqq_gemm", "qqq_gemm_ex", "mul", "marlin_qqq_gemm", "dynamic_quant", "QuantLinear"]
+__all__ = ["qqq_gemm", "qqq_gemm_bias", "qqq_gemm_ex", "mul", "marlin_qqq_gemm", "dynamic_quant", "QuantLinear"]

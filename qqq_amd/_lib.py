@@ -37,7 +37,7 @@ def lib():
     gemm_args = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp, ci, ci, vp, ci, ci, ci, ci]
     L.qqq_w4a8_gemm.argtypes = gemm_args
     L.qqq_w4a8_gemm.restype = ci
-    L.qqq_w4a8_gemm_ex.argtypes = gemm_args + [ctypes.POINTER(QQQTune), vp]
+    L.qqq_w4a8_gemm_ex.argtypes = gemm_args + [ctypes.POINTER(QQQTune), vp, vp]
     L.qqq_w4a8_gemm_ex.restype = ci
     L.qqq_dynamic_quant.argtypes = [vp, vp, vp, ci, ci, ci, vp]
     L.qqq_dynamic_quant.restype = ci

@@ -62,12 +62,9 @@ __device__ __forceinline__ int s2_stored_index(int n) {
 
 // One lane's 4 consecutive outputs (n % 4 == 0): the fused dequant epilogue
 // (csrc/qqq_gemm.cu:695-700): two separate fp32 RN multiplies, then RN to fp16.
-__device__ __forceinline__ void epilogue_store4(const int v0, const int v1, const int v2,
-                                                const int v3, const int m, const int n,
-                                                const int N, const float a_s,
-                                                const float* __restrict__ s2,
-                                                _Float16* __restrict__ D,
-                                                int32_t* __restrict__ acc_out) {
+__device__ __forceinline__ h4 epilogue_vals4(const int v0, const int v1, const int v2, const int v3,
+                                             const int n, const float a_s,
+                                             const float* __restrict__ s2) {
   const int i0 = s2_stored_index(n);  // n%4==0: (n, n+1) -> (i0, i0+1); (n+2, n+3) -> (i0+8, i0+9)
   const float2 sa = *reinterpret_cast<const float2*>(s2 + i0);
   const float2 sb = *reinterpret_cast<const float2*>(s2 + i0 + 8);
@@ -76,6 +73,20 @@ __device__ __forceinline__ void epilogue_store4(const int v0, const int v1, cons
   o[1] = (_Float16)__fmul_rn(__fmul_rn((float)v1, sa.y), a_s);
   o[2] = (_Float16)__fmul_rn(__fmul_rn((float)v2, sb.x), a_s);
   o[3] = (_Float16)__fmul_rn(__fmul_rn((float)v3, sb.y), a_s);
+  return o;
+}
+
+// ... stored straight from the lane; `bias` (may be null) is added in fp16 AFTER the fp16 round, exactly
+// like the reference's separate `D + self.bias` (qlinear_marlin.py:287).
+__device__ __forceinline__ void epilogue_store4(const int v0, const int v1, const int v2,
+                                                const int v3, const int m, const int n,
+                                                const int N, const float a_s,
+                                                const float* __restrict__ s2,
+                                                _Float16* __restrict__ D,
+                                                int32_t* __restrict__ acc_out,
+                                                const _Float16* __restrict__ bias = nullptr) {
+  h4 o = epilogue_vals4(v0, v1, v2, v3, n, a_s, s2);
+  if (bias) o = o + *reinterpret_cast<const h4*>(bias + n);
   *reinterpret_cast<h4*>(D + (size_t)m * N + n) = o;
   if (acc_out) {
     v4i a = {v0, v1, v2, v3};
@@ -154,7 +165,8 @@ __global__ __launch_bounds__(WAVES * 64) void qqq_stream_kernel(
     const int8_t* __restrict__ A, const unsigned char* __restrict__ B, int32_t* __restrict__ C,
     _Float16* __restrict__ D, const float* __restrict__ s1, const float* __restrict__ s2,
     const _Float16* __restrict__ s3, int32_t* __restrict__ acc_out, int* __restrict__ tickets,
-    const int M, const int N, const int K, const int ksplit, const int fused) {
+    const _Float16* __restrict__ bias, const int M, const int N, const int K, const int ksplit,
+    const int fused) {
   constexpr int NQ = MT * 8;  // MFMA output tiles per wave
   __shared__ int red[NQ * 4 * 64 + 64];
 
@@ -322,7 +334,7 @@ __global__ __launch_bounds__(WAVES * 64) void qqq_stream_kernel(
       if (m < M && n < N) {
         const int q = it >> 6, ln = it & 63;
         const int* rp = &red[(q * 4) * 64 + ln];
-        epilogue_store4(rp[0], rp[64], rp[128], rp[192], m, n, N, s1[m], s2, D, acc_out);
+        epilogue_store4(rp[0], rp[64], rp[128], rp[192], m, n, N, s1[m], s2, D, acc_out, bias);
       }
     }
     return;
@@ -367,7 +379,7 @@ __global__ __launch_bounds__(WAVES * 64) void qqq_stream_kernel(
       v4i sum = {0, 0, 0, 0};
       for (int p = 0; p < ksplit; ++p)
         sum += *reinterpret_cast<const v4i*>(C + ((size_t)p * M + m) * N + n);
-      epilogue_store4(sum[0], sum[1], sum[2], sum[3], m, n, N, s1[m], s2, D, acc_out);
+      epilogue_store4(sum[0], sum[1], sum[2], sum[3], m, n, N, s1[m], s2, D, acc_out, bias);
     }
   }
 }
@@ -378,7 +390,8 @@ __global__ __launch_bounds__(64) void qqq_reduce_kernel(const int32_t* __restric
                                                         _Float16* __restrict__ D,
                                                         const float* __restrict__ s1,
                                                         const float* __restrict__ s2,
-                                                        int32_t* __restrict__ acc_out, const int M,
+                                                        int32_t* __restrict__ acc_out,
+                                                        const _Float16* __restrict__ bias, const int M,
                                                         const int N, const int ksplit) {
   const int nq = N >> 2;
   const long long total = (long long)M * nq;
@@ -399,7 +412,7 @@ __global__ __launch_bounds__(64) void qqq_reduce_kernel(const int32_t* __restric
       sum += (v0 + v1) + (v2 + v3);
     }
     for (; p < ksplit; ++p) sum += *reinterpret_cast<const v4i*>(p0 + (size_t)p * slab);
-    epilogue_store4(sum[0], sum[1], sum[2], sum[3], m, n, N, a_s, s2, D, acc_out);
+    epilogue_store4(sum[0], sum[1], sum[2], sum[3], m, n, N, a_s, s2, D, acc_out, bias);
   }
 }
 
@@ -425,8 +438,9 @@ template <int BM, int MTW, int JW, int NB, bool GROUPED, int NS>
 __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * (2 / NB) * 64) void qqq_tiled_kernel(
     const int8_t* __restrict__ A, const unsigned char* __restrict__ B, int32_t* __restrict__ C,
     _Float16* __restrict__ D, const float* __restrict__ s1, const float* __restrict__ s2,
-    const _Float16* __restrict__ s3, int32_t* __restrict__ acc_out, const int M, const int N,
-    const int K, const int ksplit, const int tiles_m, const int tiles_n) {
+    const _Float16* __restrict__ s3, int32_t* __restrict__ acc_out,
+    const _Float16* __restrict__ bias, const int M, const int N, const int K, const int ksplit,
+    const int tiles_m, const int tiles_n) {
   // wave tile: MTW m-tiles of 32 tokens x JW column tiles (jt) x NB column halves (b).  NB == 1: the two
   // b halves of a packed word go to two different waves (per-group mode: every weight is re-quantised
   // by exactly one wave of the workgroup).
@@ -821,7 +835,7 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * (2 / NB) * 64) void 
     }
   }
 
-  // ---- epilogue straight from the accumulators ----
+  // ---- epilogue ----
   int mrow[MTW];
   float a_s[MTW];
 #pragma unroll
@@ -830,9 +844,52 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * (2 / NB) * 64) void 
     a_s[mt] = (mrow[mt] < M && ksplit == 1) ? s1[mrow[mt]] : 0.f;
   }
   const int n_lane = ng0 * 64 + 4 * h;  // + 64*g' + 16*jt + 8*b  (g' = r >> 2), + (r & 3)
+  if (ksplit == 1) {
+    // fp16 tile -> LDS (row-major, 16-byte chunks XOR-swizzled by the row so that the 8-byte writes of a
+    // lane column and the 16-byte reads of a row are both conflict-light) -> full 128-byte-line stores.
+    // Straight-from-register stores would be 8 bytes per lane scattered over 32 rows (measured: 2.6x write
+    // amplification at the fabric, store-issue bound tail).
+    __syncthreads();  // every wave is done reading the operand ring
+#pragma unroll
+    for (int jj = 0; jj < JW; ++jj) {
+      // D-tile rows of this lane have c = 4*h + (r & 3): c >> 2 == h, so the lane's jt is uniform over r
+      const int jt = (JW == 4) ? jj : (JW == 2) ? 2 * (wn ^ h) + jj : 2 * ((wn >> 1) ^ h) + (wn & 1);
+#pragma unroll
+      for (int bi = 0; bi < NB; ++bi)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int nl = 4 * h + 64 * gq + 16 * jt + 8 * ((NB == 2) ? bi : bsel);  // column inside the tile
+          const int n = ng0 * 64 + nl;
+          const int ncl = (n < N) ? n : 0;  // scales of a dropped column: any legal address
+#pragma unroll
+          for (int mt = 0; mt < MTW; ++mt) {
+            const int ml = (wm * MTW + mt) * 32 + li;
+            const int v0 = acc[mt][jj][bi][4 * gq + 0], v1 = acc[mt][jj][bi][4 * gq + 1];
+            const int v2 = acc[mt][jj][bi][4 * gq + 2], v3 = acc[mt][jj][bi][4 * gq + 3];
+            const h4 o = epilogue_vals4(v0, v1, v2, v3, ncl, a_s[mt], s2);
+            *reinterpret_cast<h4*>(smem + ml * 512 + (((nl >> 3) ^ (ml & 31)) << 4) + ((nl & 7) << 1)) = o;
+            if (acc_out && n < N && mrow[mt] < M) {
+              v4i a = {v0, v1, v2, v3};
+              *reinterpret_cast<v4i*>(acc_out + (size_t)mrow[mt] * N + n) = a;
+            }
+          }
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < BM * 32; idx += NT) {
+      const int ml = idx >> 5, j = idx & 31;
+      const int m = m0 + ml, n = ng0 * 64 + j * 8;
+      if (m < M && n < N) {
+        h8 v = *reinterpret_cast<const h8*>(smem + ml * 512 + ((j ^ (ml & 31)) << 4));
+        if (bias) v = v + *reinterpret_cast<const h8*>(bias + n);  // fp16 add after the fp16 round
+        *reinterpret_cast<h8*>(D + (size_t)m * N + n) = v;
+      }
+    }
+    return;
+  }
+  // split-K: int32 partial sums straight from the accumulators into slab sp of C
 #pragma unroll
   for (int jj = 0; jj < JW; ++jj) {
-    // D-tile rows of this lane have c = 4*h + (r & 3): c >> 2 == h, so the lane's jt is uniform over r
     const int jt = (JW == 4) ? jj : (JW == 2) ? 2 * (wn ^ h) + jj : 2 * ((wn >> 1) ^ h) + (wn & 1);
 #pragma unroll
     for (int bi = 0; bi < NB; ++bi)
@@ -844,14 +901,9 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * (2 / NB) * 64) void 
         for (int mt = 0; mt < MTW; ++mt) {
           const int m = mrow[mt];
           if (m >= M) continue;
-          const int v0 = acc[mt][jj][bi][4 * gq + 0], v1 = acc[mt][jj][bi][4 * gq + 1];
-          const int v2 = acc[mt][jj][bi][4 * gq + 2], v3 = acc[mt][jj][bi][4 * gq + 3];
-          if (ksplit == 1) {
-            epilogue_store4(v0, v1, v2, v3, m, n, N, a_s[mt], s2, D, acc_out);
-          } else {
-            v4i v = {v0, v1, v2, v3};
-            *reinterpret_cast<v4i*>(C + ((size_t)sp * M + m) * N + n) = v;
-          }
+          v4i v = {acc[mt][jj][bi][4 * gq + 0], acc[mt][jj][bi][4 * gq + 1], acc[mt][jj][bi][4 * gq + 2],
+                   acc[mt][jj][bi][4 * gq + 3]};
+          *reinterpret_cast<v4i*>(C + ((size_t)sp * M + m) * N + n) = v;
         }
       }
   }
@@ -1024,6 +1076,7 @@ struct LaunchArgs {
   const _Float16* s3;
   int32_t* acc_out;
   int* tickets;
+  const _Float16* bias;
   int M, N, K;
   hipStream_t stream;
 };
@@ -1032,8 +1085,8 @@ template <int MT, bool GROUPED, int WAVES, int PF>
 static hipError_t launch_stream_t(const LaunchArgs& a, int ksplit, int fused) {
   dim3 grid((a.N + 127) / 128, ksplit, (a.M + 16 * MT - 1) / (16 * MT));
   hipLaunchKernelGGL((qqq_stream_kernel<MT, GROUPED, WAVES, PF>), grid, dim3(WAVES * 64), 0, a.stream,
-                     a.A, a.B, a.C, a.D, a.s1, a.s2, a.s3, a.acc_out, a.tickets, a.M, a.N, a.K, ksplit,
-                     fused);
+                     a.A, a.B, a.C, a.D, a.s1, a.s2, a.s3, a.acc_out, a.tickets, a.bias, a.M, a.N, a.K,
+                     ksplit, fused);
   return hipGetLastError();
 }
 
@@ -1055,7 +1108,6 @@ static hipError_t launch_stream_mt(const LaunchArgs& a, int mt, int pf, int kspl
       case 3:
         return launch_stream_t<3, GROUPED, WAVES, 2>(a, ksplit, fused);
       default:
-        if (pf >= 3) return launch_stream_t<4, GROUPED, WAVES, 3>(a, ksplit, fused);
         return launch_stream_t<4, GROUPED, WAVES, 2>(a, ksplit, fused);
     }
   }
@@ -1078,7 +1130,8 @@ static hipError_t launch_tiled_t(const LaunchArgs& a, int ksplit) {
   constexpr int WAVES = (BM / (32 * MTW)) * (4 / JW) * (2 / NB);
   constexpr int NT = WAVES * 64;
   constexpr int STAGE = 8 * 2048 + BM * 128 + ((NS > 0 && GROUPED) ? WAVES * 512 : 0);
-  constexpr int LDS = (NS == 5 ? 3 : (NS > 0 ? NS : 2)) * STAGE;
+  constexpr int RING = (NS == 5 ? 3 : (NS > 0 ? NS : 2)) * STAGE;
+  constexpr int LDS = RING > BM * 512 ? RING : BM * 512;  // the epilogue stages the fp16 tile (BM x 512 B)
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static bool attr_set[64] = {};  // per instantiation, per device
   auto kern = qqq_tiled_kernel<BM, MTW, JW, NB, GROUPED, NS>;
@@ -1093,7 +1146,7 @@ static hipError_t launch_tiled_t(const LaunchArgs& a, int ksplit) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + 255) / 256;
   dim3 grid(tiles_m * tiles_n, ksplit, 1);
   hipLaunchKernelGGL(kern, grid, dim3(NT), LDS, a.stream, a.A, a.B, a.C, a.D, a.s1, a.s2, a.s3,
-                     a.acc_out, a.M, a.N, a.K, ksplit, tiles_m, tiles_n);
+                     a.acc_out, a.bias, a.M, a.N, a.K, ksplit, tiles_m, tiles_n);
   return hipGetLastError();
 }
 
@@ -1133,10 +1186,6 @@ static hipError_t launch_tiled_bm(const LaunchArgs& a, int bm, int stages, int k
       if (stages == 2) return launch_tiled_t<256, 4, 1, 2, GROUPED, 2>(a, ksplit);
       if (stages == 5) return launch_tiled_t<256, 4, 1, 2, GROUPED, 5>(a, ksplit);
       return launch_tiled_t<256, 4, 1, 2, GROUPED, 3>(a, ksplit);
-    case 257:  // experimental: 256-row tile as 4 waves x (128 x 128), one wave per SIMD
-      if (stages == 0) return launch_tiled_t<256, 4, 2, 2, GROUPED, 0>(a, ksplit);
-      if (stages == 2) return launch_tiled_t<256, 4, 2, 2, GROUPED, 2>(a, ksplit);
-      return launch_tiled_t<256, 4, 2, 2, GROUPED, 3>(a, ksplit);
     default:
       if (stages == 0) return launch_tiled_t<256, 2, 2, 2, GROUPED, 0>(a, ksplit);
       if (stages == 2) return launch_tiled_t<256, 2, 2, 2, GROUPED, 2>(a, ksplit);
@@ -1155,7 +1204,7 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
                                 const void* s2, const void* s3, int prob_m, int prob_n, int prob_k,
                                 void* workspace, int groupsize, int dev, void* stream, int thread_k,
                                 int thread_n, int sms, int max_par, const qqq_tune_t* tune,
-                                int32_t* acc_out) {
+                                int32_t* acc_out, const void* bias) {
   (void)sms;
   g_err[0] = 0;
   const int rc = ref_shape_check(prob_m, prob_n, prob_k, groupsize, thread_k, thread_n);
@@ -1189,6 +1238,7 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
   a.s2 = static_cast<const float*>(s2);
   a.s3 = static_cast<const _Float16*>(s3);
   a.acc_out = acc_out;
+  a.bias = static_cast<const _Float16*>(bias);
   a.tickets = static_cast<int*>(workspace);
   a.M = M;
   a.N = N;
@@ -1232,7 +1282,7 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
       const long long items = (long long)M * (N / 4);
       const int blocks = (int)((items + 63) / 64 > 8192 ? 8192 : (items + 63) / 64);
       hipLaunchKernelGGL(qqq_reduce_kernel, dim3(blocks), dim3(64), 0, a.stream, a.C, a.D, a.s1, a.s2,
-                         a.acc_out, M, N, ksplit);
+                         a.acc_out, a.bias, M, N, ksplit);
       e = hipGetLastError();
       if (e != hipSuccess) return fail_hip(e, "qqq_reduce_kernel launch");
     }
@@ -1241,7 +1291,7 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
 
   // ---- tiled ----
   int bm = t.bm;
-  if (bm != 64 && bm != 128 && bm != 256 && bm != 257 && bm != 258 && bm != 259 && bm != 130 && bm != 131) {
+  if (bm != 64 && bm != 128 && bm != 256 && bm != 258 && bm != 259 && bm != 130 && bm != 131) {
     const long long t256 = (long long)((M + 255) / 256) * ((N + 255) / 256);
     const long long t128 = (long long)((M + 127) / 128) * ((N + 255) / 256);
     // wave shapes per mode (measured, profiles/): per-channel keeps 64x128 wave tiles (least LDS traffic);
@@ -1278,7 +1328,7 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
     const long long items = (long long)M * (N / 4);
     const int blocks = (int)((items + 63) / 64 > 8192 ? 8192 : (items + 63) / 64);
     hipLaunchKernelGGL(qqq_reduce_kernel, dim3(blocks), dim3(64), 0, a.stream, a.C, a.D, a.s1, a.s2,
-                       a.acc_out, M, N, ksplit);
+                       a.acc_out, a.bias, M, N, ksplit);
     e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "qqq_reduce_kernel launch");
   }
@@ -1290,7 +1340,7 @@ extern "C" int qqq_w4a8_gemm(const void* A, const void* B, void* C, void* D, con
                              void* workspace, int groupsize, int dev, void* stream, int thread_k,
                              int thread_n, int sms, int max_par) {
   return qqq_w4a8_gemm_ex(A, B, C, D, s1, s2, s3, prob_m, prob_n, prob_k, workspace, groupsize, dev,
-                          stream, thread_k, thread_n, sms, max_par, nullptr, nullptr);
+                          stream, thread_k, thread_n, sms, max_par, nullptr, nullptr, nullptr);
 }
 
 extern "C" int qqq_dynamic_quant(const void* x, void* xq, void* s1, int m, int k, int dev,
@@ -1389,7 +1439,7 @@ extern "C" int qqq_bench_gemm(const void* A, const void* const* Bs, int nB, void
     for (int i = 0; i < iters && rc == QQQ_OK; ++i) {
       (void)hipEventRecord(ev[2 * i], st);
       rc = qqq_w4a8_gemm_ex(A, Bs[i % nB], C, D, s1, s2, s3, prob_m, prob_n, prob_k, workspace, groupsize,
-                            dev, stream, -1, -1, -1, max_par, tune, nullptr);
+                            dev, stream, -1, -1, -1, max_par, tune, nullptr, nullptr);
       (void)hipEventRecord(ev[2 * i + 1], st);
     }
     hipError_t e = hipStreamSynchronize(st);

@@ -78,8 +78,10 @@ def _raise_for(err, prob_m, prob_n, prob_k, thread_k, thread_n, groupsize):
 
 
 def qqq_gemm_ex(A, B, C, D, s1, s2, s3, workspace, thread_k=-1, thread_n=-1, sms=-1, max_par=8,
-                tune: Optional[dict] = None, acc_out: Optional[torch.Tensor] = None) -> None:
-    """qqq_gemm with tuning / debug hooks (tests, bench).  `tune` keys: kernel, ksplit, waves, fused, bm, glds."""
+                tune: Optional[dict] = None, acc_out: Optional[torch.Tensor] = None,
+                bias: Optional[torch.Tensor] = None) -> None:
+    """qqq_gemm with tuning / debug hooks (tests, bench) and the fused fp16 bias epilogue.
+    `tune` keys: kernel, ksplit, waves, fused, bm, glds, pf, stages."""
     L = _lib.lib()
     prob_m, prob_n, prob_k, groupsize = _check_common(A, B, C, D, s1, s2, s3, workspace, max_par)
     tn = None
@@ -90,10 +92,14 @@ def qqq_gemm_ex(A, B, C, D, s1, s2, s3, workspace, thread_k=-1, thread_n=-1, sms
     if acc_out is not None:
         if acc_out.dtype != torch.int32 or acc_out.numel() != prob_m * prob_n or not acc_out.is_contiguous():
             raise RuntimeError("acc_out must be a contiguous int32 [m, n] tensor")
+    if bias is not None:
+        if bias.dtype != torch.float16 or bias.numel() != prob_n or not bias.is_contiguous() or bias.device != A.device:
+            raise RuntimeError("bias must be a contiguous fp16 [n] tensor on A's device")
     err = L.qqq_w4a8_gemm_ex(
         _ptr(A), _ptr(B), _ptr(C), _ptr(D), _ptr(s1), _ptr(s2), _ptr(s3), prob_m, prob_n, prob_k,
         _ptr(workspace), groupsize, A.device.index if A.device.index is not None else 0, _stream_for(A),
         thread_k, thread_n, sms, max_par, ctypes.byref(tn) if tn is not None else None, _ptr(acc_out),
+        _ptr(bias),
     )
     _raise_for(err, prob_m, prob_n, prob_k, thread_k, thread_n, groupsize)
 
@@ -114,6 +120,18 @@ def _qqq_gemm_op(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, D: torch.Ten
                  s2: torch.Tensor, s3: torch.Tensor, workspace: torch.Tensor, thread_k: int, thread_n: int,
                  sms: int, max_par: int) -> None:
     _qqq_gemm_impl(A, B, C, D, s1, s2, s3, workspace, thread_k, thread_n, sms, max_par)
+
+
+@torch.library.custom_op("qqq_amd::qqq_gemm_bias", mutates_args=("C", "D", "workspace"))
+def _qqq_gemm_bias_op(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, D: torch.Tensor, s1: torch.Tensor,
+                      s2: torch.Tensor, s3: torch.Tensor, workspace: torch.Tensor, bias: torch.Tensor,
+                      max_par: int) -> None:
+    qqq_gemm_ex(A, B, C, D, s1, s2, s3, workspace, -1, -1, -1, max_par, bias=bias)
+
+
+def qqq_gemm_bias(A, B, C, D, s1, s2, s3, workspace, bias, max_par=16) -> None:
+    """qqq_gemm + the reference's `D + self.bias` (qlinear_marlin.py:287) fused into the epilogue."""
+    _qqq_gemm_bias_op(A, B, C, D, s1, s2, s3, workspace, bias, max_par)
 
 
 def qqq_gemm(A, B, C, D, s1, s2, s3, workspace, thread_k=-1, thread_n=-1, sms=-1, max_par=8) -> None:

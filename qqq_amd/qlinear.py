@@ -112,10 +112,13 @@ class QuantLinear(nn.Module):
         A = A.reshape(-1, A.shape[-1]).half()
         quant_A, s1 = self.dynamic_quant(A)
         D = torch.empty(A.shape[0], self.outfeatures, dtype=A.dtype, device=A.device)
-        ops.mul(quant_A, self.B, self.reduce_buffer, D, s1, self.s_channel, self.s_group, self.workspace,
-                max_par=self.max_par)
         if self.bias is not None:
-            ops.add_bias_(D, self.bias)  # fp16 add after the fp16 round, as `D + self.bias` (:287)
+            # fp16 add after the fp16 round, as the reference's `D + self.bias` (:287), fused in the epilogue
+            ops.qqq_gemm_bias(quant_A, self.B, self.reduce_buffer, D, s1, self.s_channel, self.s_group,
+                              self.workspace, self.bias, max_par=self.max_par)
+        else:
+            ops.mul(quant_A, self.B, self.reduce_buffer, D, s1, self.s_channel, self.s_group, self.workspace,
+                    max_par=self.max_par)
         return D.reshape(out_shape)
 
 

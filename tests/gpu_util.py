@@ -38,14 +38,16 @@ class GemmHarness:
         self.C = torch.full((max_par * 64, self.N), 0x7B7B7B7B, dtype=torch.int32, device=dev)
         self.ws = torch.zeros(max(self.N // 128, 1) * max_par, dtype=torch.int32, device=dev)
 
-    def run(self, A, s1, tune=None, want_acc=True):
+    def run(self, A, s1, tune=None, want_acc=True, bias=None):
         A = (torch.from_numpy(np.ascontiguousarray(A)) if isinstance(A, np.ndarray) else A).to(self.dev).contiguous()
         s1 = (torch.from_numpy(np.ascontiguousarray(s1, dtype=np.float32)) if isinstance(s1, np.ndarray) else s1).to(self.dev).contiguous()
         M = A.shape[0]
         D = torch.full((M, self.N), float("nan"), dtype=torch.float16, device=self.dev)
         acc = torch.full((M, self.N), -1, dtype=torch.int32, device=self.dev) if want_acc else None
+        if bias is not None:
+            bias = (torch.from_numpy(np.ascontiguousarray(bias)) if isinstance(bias, np.ndarray) else bias).to(self.dev)
         ops.qqq_gemm_ex(A, self.B, self.C, D, s1, self.s2, self.s3, self.ws, -1, -1, -1, self.max_par,
-                        tune=tune, acc_out=acc)
+                        tune=tune, acc_out=acc, bias=bias)
         torch.cuda.synchronize()
         assert int(self.ws.abs().sum().item()) == 0, "workspace must be all-zero on return"
         return D.cpu().numpy(), (acc.cpu().numpy() if want_acc else None)

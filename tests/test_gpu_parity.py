@@ -56,6 +56,19 @@ def test_scratch_reuse_and_repeated_calls(golden, dev):
                 assert ulp_distance(D, golden[f"{tag}/m{M}/oracle_D"]) == 0
 
 
+def test_fused_bias_every_path(golden, dev):
+    """bias is added in fp16 AFTER the fp16 round (the reference's `D + self.bias`, qlinear_marlin.py:287), in
+    the direct, LDS-transposed, in-launch-reduce and reduce-kernel epilogues alike."""
+    for tag in ("g-1_n128_k256", "g128_n256_k512"):
+        h = GemmHarness(golden[f"{tag}/ref_B"], golden[f"{tag}/ref_s_channel"], golden[f"{tag}/ref_s_group"], dev)
+        bias = golden[f"{tag}/bias"]
+        for M in golden[f"{tag}/Ms"]:
+            exp = (torch.from_numpy(golden[f"{tag}/m{M}/oracle_D"].copy()) + torch.from_numpy(bias.copy())).numpy()
+            for tune in variants(int(M), h.K, h.N):
+                D, _ = h.run(golden[f"{tag}/m{M}/ref_xq"], golden[f"{tag}/m{M}/ref_s1"], tune, want_acc=False, bias=bias)
+                assert ulp_distance(D, exp) == 0, (tag, int(M), tune)
+
+
 def test_empty_and_error_behaviour(golden, dev):
     from qqq_amd import qqq_gemm
 

@@ -25,11 +25,12 @@ Ms = [int(x) for x in os.environ.get("MS", "4096").split(",")]
 grouped = os.environ.get("MODE", "pc") == "g128"
 rounds = int(os.environ.get("ROUNDS", "5"))
 iters = int(os.environ.get("ITERS", "4"))
-layer = Bn.Layer(dev, grouped=grouped, nbuf=int(os.environ.get("NBUF", "4")))
+NN, KK = [int(x) for x in os.environ.get("NK", f"{Bn.N_FULL},{Bn.K_FULL}").split(",")]
+layer = Bn.Layer(dev, grouped=grouped, nbuf=int(os.environ.get("NBUF", "4")), N=NN, K=KK)
 arr = (ctypes.c_void_p * len(layer.Bs))(*[b.data_ptr() for b in layer.Bs])
 for M in Ms:
-    A, s1 = Bn.make_tokens(dev, M, M)
-    D = torch.empty((M, Bn.N_FULL), dtype=torch.float16, device=dev)
+    A, s1 = Bn.make_tokens(dev, M, M, K=KK)
+    D = torch.empty((M, NN), dtype=torch.float16, device=dev)
     res = {}
     def run(L, tune, n):
         out = (ctypes.c_float * n)()
@@ -49,7 +50,7 @@ for M in Ms:
         for li, L in enumerate(Ls):
             for ti, tune in enumerate(tunes):
                 res.setdefault((li, ti), []).extend(run(L, tune, iters))
-    ops = Bn.algorithmic_ops(M, Bn.N_FULL, Bn.K_FULL); byts = Bn.algorithmic_bytes(M, Bn.N_FULL, Bn.K_FULL, grouped)
+    ops = Bn.algorithmic_ops(M, NN, KK); byts = Bn.algorithmic_bytes(M, NN, KK, grouped)
     for (li, ti), v in sorted(res.items()):
         v = np.array(v)
         print(f"M={M} {os.path.basename(libs[li]):24s} {str(tunes[ti]):60s} med {np.median(v):8.1f} us  min {v.min():8.1f}  {ops/np.median(v)/1e6:7.0f} TOPS {byts/np.median(v)/1e3:6.0f} GB/s")

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""BASELINE configs[3]: Llama-2-7B linear shapes, batch in {1,8,32} x seq 1024 (M = 1024, 8192, 32768 tokens),
+QuantLinear (fused dynamic_quant + W4A8 GEMM) vs fp16 nn.Linear on the same GPU.  Synthetic weights/tokens.
+Prints one JSON object (kept under profiles/)."""
+import json, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from qqq_amd import QuantLinear, pack as P
+
+LAYERS = [("q_proj", 4096, 4096), ("k_proj", 4096, 4096), ("v_proj", 4096, 4096), ("o_proj", 4096, 4096),
+          ("gate_proj", 11008, 4096), ("up_proj", 11008, 4096), ("down_proj", 4096, 11008)]  # (name, N, K)
+
+
+def make_ql(dev, N, K, group_size, seed):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    ql = QuantLinear(4, group_size, K, N, bias=False).to(dev)
+    grouped = group_size != -1
+    if grouped:
+        codes = torch.randint(0, 16, (K, N), generator=g, dtype=torch.int8, device=dev)
+        ql.s_group.copy_((torch.rand((K // 128, N), generator=g, device=dev) * 15 + 0.5).half())
+    else:
+        codes = torch.randint(-7, 8, (K, N), generator=g, dtype=torch.int8, device=dev)
+    ql.B.copy_(P.pack_codes(codes, grouped))
+    ql.s_channel.copy_(torch.rand((1, N), generator=g, device=dev) * 2e-4 + 1e-5)
+    return ql
+
+
+def time_fn(fn, iters=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in ev:
+        a.record(); fn(); b.record()
+    torch.cuda.synchronize()
+    return float(np.median([a.elapsed_time(b) for a, b in ev]) * 1e3)
+
+
+def main():
+    dev = torch.device("cuda:0")
+    out = {"device": torch.cuda.get_device_name(dev), "layers": {}}
+    for gs in (-1, 128):
+        mode = "per_channel" if gs == -1 else "g128"
+        tot = {}
+        for (name, N, K) in LAYERS:
+            ql = make_ql(dev, N, K, gs, hash((name, gs)) & 0xFFFF)
+            lin = torch.nn.Linear(K, N, bias=False).half().to(dev)
+            for M in (1024, 8192, 32768):
+                x = torch.randn((M, K), device=dev, dtype=torch.float16)
+                t_q = time_fn(lambda: ql(x))
+                xq, s1 = ql.dynamic_quant(x)
+                D = torch.empty((M, N), dtype=torch.float16, device=dev)
+                from qqq_amd import ops
+                t_g = time_fn(lambda: ops.mul(xq, ql.B, ql.reduce_buffer, D, s1, ql.s_channel, ql.s_group, ql.workspace, max_par=16))
+                t_f = time_fn(lambda: lin(x))
+                out["layers"].setdefault(mode, {}).setdefault(name, {})[str(M)] = {
+                    "quantlinear_us": t_q, "gemm_only_us": t_g, "fp16_linear_us": t_f,
+                    "gemm_tops": 2.0 * M * N * K / t_g / 1e6, "speedup_vs_fp16": t_f / t_q}
+                tot.setdefault(M, [0.0, 0.0])
+                tot[M][0] += t_q; tot[M][1] += t_f
+                del x, D
+            del ql, lin
+            torch.cuda.empty_cache()
+        out.setdefault("sum_of_7_linears", {})[mode] = {str(M): {"quantlinear_us": a, "fp16_us": b, "speedup": b / a} for M, (a, b) in tot.items()}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
