@@ -1292,17 +1292,42 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
   // ---- tiled ----
   int bm = t.bm;
   if (bm != 64 && bm != 128 && bm != 256 && bm != 258 && bm != 259 && bm != 130 && bm != 131) {
-    const long long t256 = (long long)((M + 255) / 256) * ((N + 255) / 256);
-    const long long t128 = (long long)((M + 127) / 128) * ((N + 255) / 256);
-    // wave shapes per mode (measured, profiles/): per-channel keeps 64x128 wave tiles (least LDS traffic);
-    // per-group uses the column-owner shape (258 / 130) so that every weight is re-quantised once per
-    // workgroup instead of once per wave row.
-    if (t256 >= 384)
-      bm = grouped ? 258 : 256;
-    else if (t128 >= 192 || M > 64)
-      bm = grouped ? 130 : 131;
-    else
-      bm = 64;
+    // Pick the tile height (and its K split) by a small cost model in microseconds:
+    //   rounds(tiles x ksplit over 256 CUs) x tile_time(rows, K / ksplit, rate(shape)) + split-K reduce cost,
+    // per-shape rates (TOPS at large m) measured on MI355X (profiles/).  Bigger tiles are more efficient per
+    // MFMA but quantise worse over the CUs; split-K fills idle CUs at the price of int32 slab traffic.
+    // Wave shapes per mode: per-channel keeps 64x128 wave tiles (least LDS traffic); per-group uses the
+    // column-owner shapes (258 / 130): every weight re-quantised once per workgroup.
+    const long long strips = (N + 255) / 256;
+    // {several workgroups co-resident per CU, a single one} -- small tiles lose efficiency when alone on a CU
+    const double rate256 = grouped ? 1800.0 : 2300.0;
+    const double rate128[2] = {grouped ? 1360.0 : 2050.0, grouped ? 1320.0 : 1650.0};
+    const double rate64[2] = {grouped ? 800.0 : 1560.0, grouped ? 650.0 : 1170.0};
+    int best_ks = 1;
+    double best = 1e30;
+    auto consider = [&](int rows, const double* rates, int code) {
+      const long long tl = (long long)((M + rows - 1) / rows) * strips;
+      int ks = 1;
+      if (tl < 192 && have_scratch) {
+        ks = (int)((256 + tl - 1) / tl);
+        ks = clampi(ks, 1, (K / 128) / 4 > 0 ? (K / 128) / 4 : 1);
+        if ((long long)ks * M > cap_rows) ks = (int)(cap_rows / M);
+        if (ks < 1) ks = 1;
+      }
+      const double rate = (rows == 256) ? rates[0] : rates[(tl * ks <= 256) ? 1 : 0];
+      const double tile_us = (double)rows * ((double)K / ks) * 131072.0 / (rate * 1e6) + 6.0;  // + prologue/epilogue
+      double us = (double)((tl * ks + 255) / 256) * tile_us;
+      if (ks > 1) us += 5.0 + (double)ks * M * N * 8.0 / 3.0e6;  // slabs written + read at ~3 TB/s, + launch
+      if (us < best) {
+        best = us;
+        bm = code;
+        best_ks = ks;
+      }
+    };
+    consider(256, &rate256, grouped ? 258 : 256);
+    consider(128, rate128, grouped ? 130 : 131);
+    consider(64, rate64, 64);
+    if (t.ksplit <= 0) t.ksplit = best_ks;
   }
   // glds: 2 = register-staged, 1 = LDS-DMA ring with `stages` buffers; auto: the DMA ring pays at the
   // 8-wave 256-row tile, register staging is faster for the 4-wave tiles (measured)
