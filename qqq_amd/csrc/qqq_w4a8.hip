@@ -697,8 +697,9 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * (2 / NB) * 64) void 
 #pragma unroll
       for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-        for (int bi = 0; bi < NB; ++bi)
+        for (int bi = 0; bi < NB; ++bi) {
           acc[mt][jj][bi] = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.a[jj][bi], f.xop[mt], acc[mt][jj][bi], 0, 0, 0);
+        }
   };
   auto mma_frag = [&](const Frag& f) {
     Ops o;
@@ -800,6 +801,21 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * (2 / NB) * 64) void 
       };
       Frag fr[2] = {};
       Ops ops;
+#ifdef QQQ_TRACE
+      int tr_n = 0;
+      auto stamp = [&](int tag) {
+        if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && C && tr_n < 400) {  // C is idle when ksplit == 1
+          const unsigned long long tm = __builtin_readcyclecounter();
+          C[(wave * 400 + tr_n) * 4 + 0] = tag;
+          C[(wave * 400 + tr_n) * 4 + 1] = (int)(tm & 0xffffffffu);
+          C[(wave * 400 + tr_n) * 4 + 2] = (int)(tm >> 32);
+          ++tr_n;
+        }
+      };
+#define QQQ_STAMP(x) stamp(x)
+#else
+#define QQQ_STAMP(x)
+#endif
       if (nkb > 0) {
         issue_loads(kb_begin, 0);
         if (nkb > 1) issue_loads(kb_begin + 1, 1);
@@ -814,6 +830,7 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * (2 / NB) * 64) void 
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           // ---------------- LOAD phase ----------------
+          QQQ_STAMP(0 + t);
           if (t == 0) {
             if (i + 2 < nkb) issue_loads(kb_begin + i + 2, (i + 2) % 3);
             if constexpr (GROUPED) sc_cur = *reinterpret_cast<const hsc*>(st + scrd);
@@ -824,11 +841,16 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * (2 / NB) * 64) void 
           } else if (i + 1 < nkb) {
             read_frag(stn, 0, fr[0]);
           }
+          QQQ_STAMP(10 + t);
           unpack_frag(fr[t & 1], ops);
+          QQQ_STAMP(20 + t);
           phase_barrier();
+          QQQ_STAMP(30 + t);
           // ---------------- MFMA phase ----------------
           mfma_ops(ops, fr[t & 1]);
+          QQQ_STAMP(40 + t);
           phase_barrier();
+          QQQ_STAMP(50 + t);
         }
       }
       if (nkb > 0 && !late) phase_barrier();  // both groups execute the same number of barriers
