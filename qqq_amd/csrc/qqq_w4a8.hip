@@ -847,7 +847,13 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * (2 / NB) * 64) void 
           phase_barrier();
           QQQ_STAMP(30 + t);
           // ---------------- MFMA phase ----------------
+#ifndef QQQ_NO_SETPRIO
+          __builtin_amdgcn_s_setprio(1);  // the partner wave on this SIMD is in its LOAD phase: MFMA issue first
+#endif
           mfma_ops(ops, fr[t & 1]);
+#ifndef QQQ_NO_SETPRIO
+          __builtin_amdgcn_s_setprio(0);
+#endif
           QQQ_STAMP(40 + t);
           phase_barrier();
           QQQ_STAMP(50 + t);

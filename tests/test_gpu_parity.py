@@ -89,6 +89,44 @@ def test_empty_and_error_behaviour(golden, dev):
     torch.cuda.synchronize()
 
 
+def test_random_shapes_against_oracle(dev):
+    """Ragged shapes the reference admits (qlinear_marlin.py:65-77: K%64==0 & N%256==0, or (128,128),
+    (128,64), (64,128) multiples): N%128==64 / N%256 in {64,128,192} column edges, K%128==64 (stream kernel
+    only), m not a multiple of any tile, both modes, automatic dispatch and forced kernels."""
+    from oracle import c_oracle as C
+    from oracle import qqq_ref as R
+
+    rng = np.random.default_rng(2024)
+    shapes = [(1, 64, 128), (3, 192, 256), (17, 320, 192), (33, 448, 384), (65, 576, 640), (129, 704, 256),
+              (130, 832, 1152), (257, 1088, 512), (300, 1344, 320), (513, 2112, 768), (40, 11008 // 43 * 2, 4096 // 8)]
+    for (M, N, K) in shapes:
+        for grouped in (False, True):
+            if grouped and K % 128:
+                continue
+            if not any(K % tk == 0 and N % tn == 0 for tk, tn in [(64, 256), (128, 128), (128, 64), (64, 128)]):
+                continue
+            if grouped:
+                codes = rng.integers(0, 16, size=(K, N), dtype=np.int8)
+                s3 = (rng.random((K // 128, N), dtype=np.float32) * 15 + 0.5).astype(np.float16)
+            else:
+                codes = rng.integers(-8, 8, size=(K, N), dtype=np.int8)  # -8 included: the kernel path is generic
+                s3 = np.zeros((0,), np.float16)
+            B = R.pack_codes(codes, grouped)
+            A = rng.integers(-128, 128, size=(M, K), dtype=np.int8)
+            s1 = (rng.random((M, 1), dtype=np.float32) * 0.05 + 0.001)
+            s2 = (rng.random((1, N), dtype=np.float32) * 2e-4 + 1e-5)
+            eD, eacc = C.qqq_gemm(A, B, s1, s2, s3 if grouped else None, return_acc=True)
+            h = GemmHarness(B, s2, s3, dev)
+            tunes = [None, dict(kernel=1), dict(kernel=1, ksplit=2, fused=1)]
+            if K % 128 == 0:
+                tunes += [dict(kernel=2), dict(kernel=2, bm=64, glds=1, stages=3), dict(kernel=2, bm=130, glds=1, stages=5),
+                          dict(kernel=2, bm=258, glds=1, stages=3, ksplit=2)]
+            for tune in tunes:
+                D, acc = h.run(A, s1, tune)
+                assert np.array_equal(acc, eacc), (M, N, K, grouped, tune)
+                assert ulp_distance(D, eD) == 0, (M, N, K, grouped, tune)
+
+
 # ------------------------------------------------------------------------------------------------
 # BASELINE sizes: N=8192, K=21760
 # ------------------------------------------------------------------------------------------------
