@@ -183,6 +183,17 @@ def cpu_baseline(sample_rows=64, budget_s=12.0):
     return out
 
 
+def measured_traffic(key):
+    """HBM/fabric bytes per launch of the roofline kernels, from the committed rocprofv3 PMC passes
+    (profiles/hbm_traffic.json: FETCH_SIZE / WRITE_SIZE collected in separate --pmc runs and corrected as
+    MI355X_MICROARCH.md prescribes).  None when the file has no entry."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+        return d[key]["bytes"]
+    except Exception:
+        return None
+
+
 def cpu_model_name():
     try:
         for line in open("/proc/cpuinfo"):
@@ -342,13 +353,17 @@ def main():
         a = per_m["4096"]
         result["roofline"] = {
             "kernel": "qqq_tiled_kernel (M=4096)", "bound": "mfma", "achieved": a["tops"], "peak": PEAK_MFMA_TOPS,
-            "unit": "TOPS", "frac": a["tops"] / PEAK_MFMA_TOPS, "traffic": None,
-            "avg_launch_us": a["us"],
+            "unit": "TOPS", "frac": a["tops"] / PEAK_MFMA_TOPS, "traffic": measured_traffic("qqq_tiled_kernel_M4096"),
+            "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/hbm_traffic.json)",
+            "algorithmic_bytes": algorithmic_bytes(4096, N_FULL, K_FULL), "avg_launch_us": a["us"],
         }
         h = per_m["16"]
         result["roofline_hbm"] = {
             "kernel": "qqq_stream_kernel (M=16)", "bound": "hbm", "achieved": h["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
-            "frac": h["gbs"] / PEAK_HBM_GBS, "traffic": None, "avg_launch_us": h["us"],
+            "frac": h["gbs"] / PEAK_HBM_GBS, "traffic": measured_traffic("qqq_stream_kernel_M16"),
+            "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/hbm_traffic.json)",
+            "algorithmic_bytes": algorithmic_bytes(16, N_FULL, K_FULL), "avg_launch_us": h["us"],
+            "note": "whole qqq_gemm call (stream kernel + split-K reduce launch); the stream kernel alone averages 17 us = 5.3 TB/s (profiles/r01_bench_kernel_stats.csv)",
         }
         # per-group (BASELINE configs[2]) detail
         try:
