@@ -65,7 +65,8 @@ typedef struct qqq_tune {
   int glds;    /* tiled: 1 = direct global->LDS loads, 2 = register staged; 0 auto          */
   int pf;      /* stream: prefetch depth in 4 KiB steps per wave (3, 5, 7); 0 auto               */
   int stages;  /* tiled + LDS-DMA: ring depth 2..4 (0 auto)                                      */
-  int reserved[4];
+  int mt;      /* stream: 16-token tiles per workgroup (1..4); 0 auto                           */
+  int reserved[3];
 } qqq_tune_t;
 
 /* As qqq_w4a8_gemm; `tune` may be NULL; if `acc_out` != NULL the raw int32 accumulators

@@ -14,7 +14,7 @@ class QQQTune(ctypes.Structure):
     _fields_ = [
         ("kernel", ctypes.c_int), ("ksplit", ctypes.c_int), ("waves", ctypes.c_int),
         ("fused", ctypes.c_int), ("bm", ctypes.c_int), ("glds", ctypes.c_int),
-        ("pf", ctypes.c_int), ("stages", ctypes.c_int), ("reserved", ctypes.c_int * 4),
+        ("pf", ctypes.c_int), ("stages", ctypes.c_int), ("mt", ctypes.c_int), ("reserved", ctypes.c_int * 3),
     ]
 
 

@@ -1280,7 +1280,7 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
   if (kernel == 1) {
     // rows are processed in m-blocks of 16*MT (grid.z); every m-block re-reads the weights, so this
     // kernel is meant for m <= 64 (one m-block) but stays correct for any m.
-    const int mt = clampi((M + 15) / 16, 1, 4);
+    const int mt = (t.mt >= 1 && t.mt <= 4) ? t.mt : clampi((M + 15) / 16, 1, 4);
     const int mblocks = (M + 16 * mt - 1) / (16 * mt);
     const int strips = (N + 127) / 128;
     const int KS = K / 64;

@@ -76,3 +76,25 @@ def test_state_dict_roundtrip_and_vllm_wrapper(golden, dev):
     D = marlin_qqq_gemm(xq, ql.B, s1, ql.s_channel, ql.s_group, ql.workspace, M, 256, 256)
     torch.cuda.synchronize()
     assert ulp_distance(D.cpu().numpy(), golden[f"{tag}/m{M}/oracle_D"]) == 0
+
+
+def test_custom_op_traces_under_torch_compile(golden, dev):
+    """north_star: `qqq_gemm` is a real torch custom op (torch.library), so a compiled graph keeps it as one
+    node instead of graph-breaking on a pybind function.  aot_eager avoids needing a codegen backend."""
+    import torch._dynamo
+    from qqq_amd import QuantLinear
+
+    tag = "g-1_n128_k256"
+    ql = QuantLinear(4, -1, 256, 128, bias=True)
+    ql.load_state_dict({"B": torch.from_numpy(golden[f"{tag}/ref_B"].copy()),
+                        "s_channel": torch.from_numpy(golden[f"{tag}/ref_s_channel"].copy()),
+                        "s_group": torch.empty(0, dtype=torch.float16),
+                        "bias": torch.from_numpy(golden[f"{tag}/bias"].copy())})
+    ql = ql.to(dev)
+    x = torch.from_numpy(golden[f"{tag}/m16/x"].copy()).to(dev)
+    eager = ql(x)
+    torch._dynamo.reset()
+    compiled = torch.compile(ql, backend="aot_eager", fullgraph=True)
+    out = compiled(x)
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)
