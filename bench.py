@@ -212,6 +212,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-fp16", action="store_true", help="skip the torch fp16 GPU GEMM comparison")
     ap.add_argument("--detail-iters", type=int, default=30)
+    ap.add_argument("--check", action="store_true",
+                    help="after the timed region verify the gathered outputs of the sharded points against a local full GEMM")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -221,14 +223,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU; the modulo only matters for the single-GPU functional test of the N>1 path
+    # (QQQ_BENCH_BACKEND=gloo, two ranks sharing cuda:0) -- RCCL itself refuses two ranks on one device
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        backend = os.environ.get("QQQ_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from qqq_amd import ops
     from qqq_amd.parallel import ShardedGemm, shard_rows
@@ -311,6 +319,18 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+
+    if args.check and world > 1:
+        for j, M in enumerate(SWEEP_M):
+            if M in sharded:
+                A, s1 = toks[M]
+                ref = torch.empty((M, N_FULL), dtype=torch.float16, device=dev)
+                ops.qqq_gemm(A, layer.Bs[j % NBUF], layer.C, ref, s1, layer.s2, layer.s3, layer.ws, -1, -1, -1, MAX_PAR)
+                torch.cuda.synchronize()
+                if not torch.equal(ref, Dfull[M]):
+                    raise SystemExit(f"[bench --check] rank {rank}: gathered output differs from the local GEMM at M={M}")
+        if rank == 0:
+            print(f"[bench --check] sharded + all-gathered outputs identical to local full GEMMs for M in {sorted(sharded)}", file=sys.stderr)
 
     total_ops = sum(algorithmic_ops(M, N_FULL, K_FULL) for M in SWEEP_M)
     ms_per_step = dt / args.steps * 1e3

@@ -59,8 +59,9 @@ typedef struct qqq_tune {
                   2 = "tiled" (LDS-staged 32x32x32 MFMA tiles, large m)                       */
   int ksplit;  /* 0 auto, else number of K slices (partials go through C)                   */
   int waves;   /* stream: waves per workgroup (4, 8 or 16); 0 auto                           */
-  int fused;   /* stream split-K: 1 = last-arriving workgroup reduces in-launch (tickets in
-                  workspace), 2 = separate reduce launch; 0 auto                             */
+  int fused;   /* stream split-K: 1 = last-arriving workgroup reduces in-launch (tickets in workspace,
+                  release fence), 3 = same with write-through slab stores (no release fence),
+                  2 = separate reduce launch; 0 auto                                          */
   int bm;      /* tiled: rows per workgroup tile (64, 128, 256); 0 auto                      */
   int glds;    /* tiled: 1 = direct global->LDS loads, 2 = register staged; 0 auto          */
   int pf;      /* stream: prefetch depth in 4 KiB steps per wave (3, 5, 7); 0 auto               */

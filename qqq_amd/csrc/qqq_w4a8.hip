@@ -348,18 +348,26 @@ __global__ __launch_bounds__(WAVES * 64) void qqq_stream_kernel(
       const int q = it >> 6, ln = it & 63;
       const int* rp = &red[(q * 4) * 64 + ln];
       v4i v = {rp[0], rp[64], rp[128], rp[192]};
-      *reinterpret_cast<v4i*>(C + ((size_t)sp * M + m) * N + n) = v;
+      int32_t* dst = C + ((size_t)sp * M + m) * N + n;
+      if (fused == 2) {
+        // write-through (sc0 sc1) slab store: reaches memory without a later L2 write-back, so the
+        // publish below needs no agent-scope release fence (MI355X hand-off recipe R1)
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+      } else {
+        *reinterpret_cast<v4i*>(dst) = v;
+      }
     }
   }
   if (!fused) return;  // a separate reduce launch finishes the job
 
   // in-launch reduction by the last-arriving workgroup of this (strip, m-block) tile:
-  // agent-scope release -> ticket -> agent-scope acquire (placement independent).
+  // (fused == 1) plain stores -> agent-scope release -> ticket, or (fused == 2) write-through stores ->
+  // drained -> ticket; then one agent-scope acquire in the last arriver (placement independent).
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   int* flag = &red[NQ * 4 * 64];
   if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (fused == 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int* tk = tickets + (blockIdx.z * gridDim.x + strip);
     const int t = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1301,12 +1309,13 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
     int fused = t.fused;
     if (fused == 0) fused = 2;  // separate reduce launch measured ~2 us faster than the in-launch ticket path
     // tickets: one int per (m-block, strip); the reference guarantees n/128*max_par ints
-    if (fused == 1 && (workspace == nullptr || (long long)mblocks * strips > (long long)(N / 128) * max_par))
+    if ((fused == 1 || fused == 3) && (workspace == nullptr || (long long)mblocks * strips > (long long)(N / 128) * max_par))
       fused = 2;
     const int pf = t.pf > 0 ? t.pf : (mt <= 2 ? 3 : 2);
-    e = launch_stream(a, grouped, mt, waves, pf, ksplit, fused == 1 ? 1 : 0);
+    // kernel arg: 0 = slabs only (separate reduce launch), 1 = in-launch + release fence, 2 = in-launch + write-through
+    e = launch_stream(a, grouped, mt, waves, pf, ksplit, fused == 1 ? 1 : (fused == 3 ? 2 : 0));
     if (e != hipSuccess) return fail_hip(e, "qqq_stream_kernel launch");
-    if (ksplit > 1 && fused != 1) {
+    if (ksplit > 1 && fused != 1 && fused != 3) {
       const long long items = (long long)M * (N / 4);
       const int blocks = (int)((items + 63) / 64 > 8192 ? 8192 : (items + 63) / 64);
       hipLaunchKernelGGL(qqq_reduce_kernel, dim3(blocks), dim3(64), 0, a.stream, a.C, a.D, a.s1, a.s2,

@@ -57,9 +57,9 @@ def variants(M, K, N):
     """tuning variants that are valid for this problem"""
     v = [dict(kernel=1, ksplit=1, waves=4), dict(kernel=1, ksplit=1, waves=8)]
     if K // 64 >= 4:
-        v += [dict(kernel=1, ksplit=2, waves=4, fused=1), dict(kernel=1, ksplit=2, waves=4, fused=2)]
+        v += [dict(kernel=1, ksplit=2, waves=4, fused=1), dict(kernel=1, ksplit=2, waves=4, fused=2), dict(kernel=1, ksplit=2, waves=8, fused=3)]
     if K // 64 >= 8:
-        v += [dict(kernel=1, ksplit=3, waves=8, fused=1)]
+        v += [dict(kernel=1, ksplit=3, waves=8, fused=1), dict(kernel=1, ksplit=4, waves=4, fused=3)]
     if M <= 16:
         v += [dict(kernel=1, ksplit=1, waves=16)]
     v += [dict(kernel=1)]  # auto split

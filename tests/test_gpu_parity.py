@@ -49,7 +49,7 @@ def test_scratch_reuse_and_repeated_calls(golden, dev):
     Ms = [int(m) for m in golden[f"{tag}/Ms"]]
     for rep in range(3):
         for M in Ms + Ms[::-1]:
-            for tune in (dict(kernel=1, ksplit=2, waves=4, fused=1), dict(kernel=1, ksplit=2, waves=4, fused=2),
+            for tune in (dict(kernel=1, ksplit=2, waves=4, fused=1), dict(kernel=1, ksplit=2, waves=4, fused=2), dict(kernel=1, ksplit=2, waves=4, fused=3),
                          dict(kernel=2, bm=64, glds=1, ksplit=2)):
                 D, acc = h.run(golden[f"{tag}/m{M}/ref_xq"], golden[f"{tag}/m{M}/ref_s1"], tune)
                 assert np.array_equal(acc, golden[f"{tag}/m{M}/oracle_acc"]), (rep, M, tune)
