@@ -463,8 +463,11 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * (2 / NB) * 64) void 
   // NS >= 2: LDS-DMA (global_load_lds) ring of NS stages, NS-1 stages of loads in flight
   // NS == 5: LDS-DMA ring of 3 stages driven by the staggered two-group ("ping-pong") schedule
   constexpr bool GLDS = NS > 0;
+  // NS == 6: LDS-DMA ring of 3 stages, ONE barrier per 128-k block placed two k-steps before the stage
+  //          switch, fragment pipeline (W reads 2 steps ahead, unpack 1 step ahead) running across it
   constexpr bool PINGPONG = (NS == 5);
-  constexpr int NSTAGE = PINGPONG ? 3 : NS;
+  constexpr bool CONTPIPE = (NS == 6);
+  constexpr int NSTAGE = (PINGPONG || CONTPIPE) ? 3 : NS;
   constexpr int SC_BYTES = (GLDS && GROUPED) ? WM * WN * 512 : 0;  // per-wave slot of group scales
   constexpr int STAGE = W_BYTES + X_BYTES + SC_BYTES;
   constexpr int W_CHUNKS = W_BYTES / 16;  // 1024
@@ -772,7 +775,126 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * (2 / NB) * 64) void 
       }
     };
     const int nkb = kb_end - kb_begin;
-    if constexpr (!PINGPONG) {
+    if constexpr (CONTPIPE) {
+      // ---- continuous fragment pipeline over a 3-stage DMA ring.
+      // step u = 4*i + t:   ds_read W(u+2), X(u+1)  |  unpack W(u+1) -> ops  |  8 MFMA(u)
+      // The only barrier of block i sits at the start of its step t=2: by then every wave has waited for
+      // its DMA of stage i+1 (issued one block earlier), so from t=2 on stage i+1 may be read; stage i+2
+      // is issued right behind that barrier into the buffer of stage i-1 (last read at (i-1, t=1)).
+      // Reads past the last step are redirected to the last stage (harmless), never branched around, so
+      // each step is one straight-line scheduling region with an enforced MFMA/VALU/DS interleave.
+      unsigned wraw[2][4][JW];
+      v4i xfr[2][MTW];
+      Ops ops2[2];
+      auto read_w = [&](const unsigned char* st, const int t, unsigned (&w)[4][JW]) {
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) {
+          const unsigned char* p = st + wrd[kq] + t * 4096;
+          if constexpr (JW == 4) {
+            const v4u v = *reinterpret_cast<const v4u*>(p);
+            w[kq][0] = v[0]; w[kq][1] = v[1]; w[kq][2] = v[2]; w[kq][3] = v[3];
+          } else if constexpr (JW == 2) {
+            const uint2 v = *reinterpret_cast<const uint2*>(p);
+            w[kq][0] = v.x; w[kq][1] = v.y;
+          } else {
+            const uint2 v = *reinterpret_cast<const uint2*>(p);
+            w[kq][0] = esel ? v.y : v.x;
+          }
+        }
+      };
+      auto read_x = [&](const unsigned char* st, const int t, v4i (&x)[MTW]) {
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) x[mt] = *reinterpret_cast<const v4i*>(st + xrd[t] + mt * (32 * 128));
+      };
+      auto unpack_w = [&](const unsigned (&w)[4][JW], Ops& o) {
+        Frag f;
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq)
+#pragma unroll
+          for (int jj = 0; jj < JW; ++jj) f.wq[kq][jj] = w[kq][jj];
+        unpack_frag(f, o);
+      };
+      auto mfma_x = [&](const Ops& o, const v4i (&x)[MTW]) {
+#pragma unroll
+        for (int jj = 0; jj < JW; ++jj)
+#pragma unroll
+          for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+            for (int bi = 0; bi < NB; ++bi)
+              acc[mt][jj][bi] = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.a[jj][bi], x[mt], acc[mt][jj][bi], 0, 0, 0);
+      };
+      if (nkb > 0) {
+        issue_loads(kb_begin, 0);
+        if (nkb > 1) issue_loads(kb_begin + 1, 1);
+        wait_younger(nkb > 1 ? 1 : 0);
+        __syncthreads();
+        if constexpr (GROUPED) sc_cur = *reinterpret_cast<const hsc*>(smem + scrd);
+        read_w(smem, 0, wraw[0]);
+        read_x(smem, 0, xfr[0]);
+        read_w(smem, 1, wraw[1]);
+        unpack_w(wraw[0], ops2[0]);
+      }
+      for (int i = 0; i < nkb; ++i) {
+        const unsigned char* st = smem + (i % 3) * STAGE;
+        const bool has_next = (i + 1 < nkb);
+        const unsigned char* stn = has_next ? smem + ((i + 1) % 3) * STAGE : st;  // redirect past-the-end reads
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          if (t == 2) {
+            if (has_next) {
+              wait_younger(0);  // this wave's DMA of stage i+1 (the only one in flight) has landed
+              __syncthreads();  // ... and everybody else's
+            }
+            if (i + 2 < nkb) issue_loads(kb_begin + i + 2, (i + 2) % 3);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          // fragment reads: W two steps ahead, X one step ahead
+          read_w((t + 2 < 4) ? st : stn, (t + 2) & 3, wraw[t & 1]);
+          read_x((t + 1 < 4) ? st : stn, (t + 1) & 3, xfr[(t + 1) & 1]);
+          if constexpr (GROUPED)
+            if (t == 3) sc_cur = *reinterpret_cast<const hsc*>(stn + scrd);  // scales of the block being unpacked
+          __builtin_amdgcn_sched_barrier(0);
+          // hand-interleaved issue order: one MFMA of step u, then the unpack of one packed word of step
+          // u+1 (hipcc otherwise issues the 8 MFMAs back to back and leaves the VALU work uncovered)
+          constexpr int NM = MTW * JW * NB;  // MFMAs per step
+          constexpr int NWD = 4 * JW;        // packed words per step
+#pragma unroll
+          for (int q = 0; q < (NM > NWD ? NM : NWD); ++q) {
+            if (q < NM) {
+              const int jj = q / (MTW * NB), mt = (q / NB) % MTW, bi = q % NB;
+              acc[mt][jj][bi] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ops2[t & 1].a[jj][bi], xfr[t & 1][mt],
+                                                                      acc[mt][jj][bi], 0, 0, 0);
+            }
+            if (q < NWD) {
+              const int kq = q & 3, jj = q >> 2;
+              const unsigned wq_ = wraw[(t + 1) & 1][kq][jj];
+              h2 sb0 = {(_Float16)0, (_Float16)0}, sb1 = sb0;
+              if constexpr (GROUPED) {
+                sb0 = (h2){sc_cur[2 * jj], sc_cur[2 * jj]};
+                sb1 = (h2){sc_cur[2 * jj + 1], sc_cur[2 * jj + 1]};
+              }
+              // the empty asm pins the unpack HERE (LLVM would otherwise sink it to its use, one step later)
+              if constexpr (NB == 2) {
+                int w0, w1;
+                unpack_pair<GROUPED>(wq_, sb0, sb1, w0, w1);
+                asm volatile("" : "+v"(w0), "+v"(w1));
+                ops2[(t + 1) & 1].a[jj][0][kq] = w0;
+                ops2[(t + 1) & 1].a[jj][1][kq] = w1;
+              } else if constexpr (GROUPED) {
+                int w0 = (int)dequant_group4(wq_ >> (8 * bsel), bsel ? sb1 : sb0);
+                asm volatile("" : "+v"(w0));
+                ops2[(t + 1) & 1].a[jj][0][kq] = w0;
+              } else {
+                int w0 = (int)((wq_ << (4 * bsel)) & QQQ_NIB_MASK);
+                asm volatile("" : "+v"(w0));
+                ops2[(t + 1) & 1].a[jj][0][kq] = w0;
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+    } else if constexpr (!PINGPONG) {
       int issued = 0;  // stages issued so far (relative index)
       for (; issued < NSTAGE - 1 && issued < nkb; ++issued) issue_loads(kb_begin + issued, issued % NSTAGE);
       if (nkb > 0) {
@@ -1166,7 +1288,7 @@ static hipError_t launch_tiled_t(const LaunchArgs& a, int ksplit) {
   constexpr int WAVES = (BM / (32 * MTW)) * (4 / JW) * (2 / NB);
   constexpr int NT = WAVES * 64;
   constexpr int STAGE = 8 * 2048 + BM * 128 + ((NS > 0 && GROUPED) ? WAVES * 512 : 0);
-  constexpr int RING = (NS == 5 ? 3 : (NS > 0 ? NS : 2)) * STAGE;
+  constexpr int RING = ((NS == 5 || NS == 6) ? 3 : (NS > 0 ? NS : 2)) * STAGE;
   constexpr int LDS = RING > BM * 512 ? RING : BM * 512;  // the epilogue stages the fp16 tile (BM x 512 B)
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static bool attr_set[64] = {};  // per instantiation, per device
@@ -1226,6 +1348,7 @@ static hipError_t launch_tiled_bm(const LaunchArgs& a, int bm, int stages, int k
       if (stages == 0) return launch_tiled_t<256, 2, 2, 2, GROUPED, 0>(a, ksplit);
       if (stages == 2) return launch_tiled_t<256, 2, 2, 2, GROUPED, 2>(a, ksplit);
       if (stages == 5) return launch_tiled_t<256, 2, 2, 2, GROUPED, 5>(a, ksplit);
+      if (stages == 6) return launch_tiled_t<256, 2, 2, 2, GROUPED, 6>(a, ksplit);
       return launch_tiled_t<256, 2, 2, 2, GROUPED, 3>(a, ksplit);
   }
 }
@@ -1370,7 +1493,7 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
   // 8-wave 256-row tile, register staging is faster for the 4-wave tiles (measured)
   int stages;
   if (t.glds == 2) stages = 0;
-  else if (t.glds == 1) stages = ((t.stages >= 2 && t.stages <= 4) || (t.stages == 5 && bm != 64 && bm != 128)) ? t.stages : (bm >= 256 ? 3 : 4);
+  else if (t.glds == 1) stages = ((t.stages >= 2 && t.stages <= 4) || (t.stages == 5 && bm != 64 && bm != 128) || (t.stages == 6 && bm == 256)) ? t.stages : (bm >= 256 ? 3 : 4);
   else stages = (bm == 256) ? 5 : (bm == 258) ? 3 : (bm == 130) ? 4 : 0;  // measured best per shape
   if (bm >= 256 && stages == 4) stages = 3;
   const int bm_rows = (bm >= 256) ? 256 : (bm >= 128 ? 128 : bm);
