@@ -31,6 +31,9 @@ arr = (ctypes.c_void_p * len(layer.Bs))(*[b.data_ptr() for b in layer.Bs])
 for M in Ms:
     A, s1 = Bn.make_tokens(dev, M, M, K=KK)
     D = torch.empty((M, NN), dtype=torch.float16, device=dev)
+    if os.environ.get('ZERO') == '1':
+        A.zero_()
+        for b in layer.Bs: b.zero_()
     res = {}
     def run(L, tune, n):
         out = (ctypes.c_float * n)()
