@@ -15,6 +15,7 @@ from .ops import (  # noqa: F401
     qqq_gemm_bias,
     qqq_gemm_ex,
 )
-from .qlinear import QuantLinear  # noqa: F401
+from .qlinear import QuantLinear, fuse_quant_linears  # noqa: F401
 
-__all__ = ["qqq_gemm", "qqq_gemm_bias", "qqq_gemm_ex", "mul", "marlin_qqq_gemm", "dynamic_quant", "QuantLinear"]
+__all__ = ["qqq_gemm", "qqq_gemm_bias", "qqq_gemm_ex", "mul", "marlin_qqq_gemm", "dynamic_quant", "QuantLinear",
+           "fuse_quant_linears"]

@@ -122,4 +122,35 @@ class QuantLinear(nn.Module):
         return D.reshape(out_shape)
 
 
-__all__ = ["QuantLinear"]
+def fuse_quant_linears(layers) -> QuantLinear:
+    """Concatenate QuantLinear layers that share their input along the output dimension (q/k/v, gate/up:
+    the reference wraps them as separate modules, gptq/models/llama.py:202-229, :275-283) into ONE layer,
+    so one W4A8 GEMM with N = sum(N_i) replaces several (what vLLM does with merged projections).
+
+    The packed layout is made of independent 64-column groups (word index 128*ng + ...), s_channel of
+    independent 32-column blocks and s_group of independent 64-column blocks, so concatenating the stored
+    tensors along the column axis IS the packing of the concatenated weight: no repacking.
+    """
+    layers = list(layers)
+    first = layers[0]
+    for l in layers[1:]:
+        if l.infeatures != first.infeatures or l.group_size != first.group_size or l.bits != first.bits:
+            raise ValueError("fuse_quant_linears: layers must share infeatures / group_size / bits")
+        if (l.bias is None) != (first.bias is None):
+            raise ValueError("fuse_quant_linears: either all or none of the layers carry a bias")
+    n_total = sum(l.outfeatures for l in layers)
+    gs = -1 if first.group_size == first.infeatures else first.group_size
+    fused = QuantLinear(first.bits, gs, first.infeatures, n_total, bias=first.bias is not None)
+    fused = fused.to(first.B.device)
+    fused.B.copy_(torch.cat([l.B for l in layers], dim=1))
+    fused.s_channel.copy_(torch.cat([l.s_channel for l in layers], dim=1))
+    if first.s_group.numel():
+        fused.s_group.copy_(torch.cat([l.s_group for l in layers], dim=1))
+    else:
+        fused.s_group = torch.tensor([], dtype=torch.half, device=first.B.device)
+    if first.bias is not None:
+        fused.bias.copy_(torch.cat([l.bias for l in layers], dim=0))
+    return fused
+
+
+__all__ = ["QuantLinear", "fuse_quant_linears"]

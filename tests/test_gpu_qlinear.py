@@ -98,3 +98,23 @@ def test_custom_op_traces_under_torch_compile(golden, dev):
     out = compiled(x)
     torch.cuda.synchronize()
     assert torch.equal(out, eager)
+
+
+def test_fused_projections_match_separate_layers(golden, dev):
+    from qqq_amd import QuantLinear, fuse_quant_linears
+
+    for gs, tags in ((-1, ("g-1_n128_k256", "g-1_n256_k256")), (128, ("g128_n128_k256", "g128_n256_k256"))):
+        parts = []
+        for tag in tags:
+            N, K = golden[f"{tag}/W_fq"].shape
+            ql = QuantLinear(4, gs, K, N, bias=True)
+            sd = {"B": torch.from_numpy(golden[f"{tag}/ref_B"].copy()), "s_channel": torch.from_numpy(golden[f"{tag}/ref_s_channel"].copy()),
+                  "s_group": torch.from_numpy(golden[f"{tag}/ref_s_group"].copy()), "bias": torch.from_numpy(golden[f"{tag}/bias"].copy())}
+            ql.load_state_dict(sd)
+            parts.append(ql.to(dev))
+        fused = fuse_quant_linears(parts)
+        x = torch.from_numpy(golden[f"{tags[0]}/m16/x"].copy()).to(dev)
+        sep = torch.cat([p(x) for p in parts], dim=-1)
+        out = fused(x)
+        torch.cuda.synchronize()
+        assert torch.equal(out, sep)

@@ -85,3 +85,33 @@ def test_ops_refuse_cpu_tensors():
         qqq_gemm(A, B, C, D, s1, s2, s3, ws[:1], -1, -1, -1, 16)
     with pytest.raises(RuntimeError, match="not compatible with 3 groups"):
         qqq_gemm(A, B, C, D, s1, s2, torch.zeros((3, 256), dtype=torch.float16), ws, -1, -1, -1, 16)
+
+
+def test_fuse_quant_linears_equals_packing_the_concatenated_weight(golden):
+    """q/k/v-style fusion: concatenating stored tensors == pack() of the concatenated layer."""
+    from qqq_amd import fuse_quant_linears
+
+    for gs, tags in ((-1, ("g-1_n128_k256", "g-1_n256_k256")), (128, ("g128_n128_k256", "g128_n256_k256"))):
+        parts, Ws, scs, ses, biases = [], [], [], [], []
+        for tag in tags:
+            W = golden[f"{tag}/W_fq"]
+            N, K = W.shape
+            lin = torch.nn.Linear(K, N, bias=True).half()
+            lin.weight.data = torch.from_numpy(W.copy())
+            lin.bias.data = torch.from_numpy(golden[f"{tag}/bias"].copy())
+            ql = QuantLinear(4, gs, K, N, bias=True)
+            se = torch.from_numpy(golden[f"{tag}/s_extra"].copy()) if gs != -1 else None
+            ql.pack(lin, torch.from_numpy(golden[f"{tag}/scale"].copy()), se)
+            parts.append(ql)
+            Ws.append(W); scs.append(golden[f"{tag}/scale"]); biases.append(golden[f"{tag}/bias"])
+            if gs != -1:
+                ses.append(golden[f"{tag}/s_extra"])
+        fused = fuse_quant_linears(parts)
+        Wc = np.concatenate(Ws, 0)
+        lin = torch.nn.Linear(Wc.shape[1], Wc.shape[0], bias=True).half()
+        lin.weight.data = torch.from_numpy(Wc.copy())
+        lin.bias.data = torch.from_numpy(np.concatenate(biases))
+        ref = QuantLinear(4, gs, Wc.shape[1], Wc.shape[0], bias=True)
+        ref.pack(lin, torch.from_numpy(np.concatenate(scs, 0)), torch.from_numpy(np.concatenate(ses, 0)) if gs != -1 else None)
+        assert torch.equal(fused.B, ref.B) and torch.equal(fused.s_channel, ref.s_channel)
+        assert torch.equal(fused.s_group, ref.s_group) and torch.equal(fused.bias, ref.bias)
