@@ -28,17 +28,22 @@ def variants(M, grouped):
                     for fused in ((1, 2) if ks > 1 else (1,)):
                         v.append(dict(kernel=1, waves=waves, ksplit=ks, fused=fused, pf=pf))
     if M >= 16:
-        for bm in (64, 128, 256):
-            if bm > 64 and M < bm // 2:
+        for bm in (64, 128, 131, 130, 256, 258, 259):
+            rows = 256 if bm >= 256 else (128 if bm >= 128 else 64)
+            if rows > 64 and M < rows // 2:
                 continue
-            for stages in (0, 2, 3, 4):
-                if bm == 256 and stages == 4:
+            for stages in (0, 2, 3, 4, 5, 6):
+                if stages == 4 and rows == 256:
                     continue
-                for ks in (1, 2, 4, 8, 16):
+                if stages == 5 and bm in (64, 128):
+                    continue
+                if stages == 6 and bm != 256:
+                    continue
+                for ks in (1, 2, 4, 8):
                     if ks > 1 and ks * M > 1024:
                         continue
-                    tiles = -(-M // bm) * 32
-                    if tiles * ks > 4096 or (ks > 1 and tiles >= 512):
+                    tiles = -(-M // rows) * 32
+                    if tiles * ks > 4096 or (ks > 1 and tiles >= 256):
                         continue
                     v.append(dict(kernel=2, bm=bm, glds=(2 if stages == 0 else 1), stages=stages, ksplit=ks))
     return v
