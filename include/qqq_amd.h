@@ -59,9 +59,10 @@ typedef struct qqq_tune {
                   2 = "tiled" (LDS-staged 32x32x32 MFMA tiles, large m)                       */
   int ksplit;  /* 0 auto, else number of K slices (partials go through C)                   */
   int waves;   /* stream: waves per workgroup (4, 8 or 16); 0 auto                           */
-  int fused;   /* stream split-K: 1 = last-arriving workgroup reduces in-launch (tickets in workspace,
-                  release fence), 3 = same with write-through slab stores (no release fence),
-                  2 = separate reduce launch; 0 auto                                          */
+  int fused;   /* split-K finish; 0 auto.  stream: 1 = last-arriving workgroup reduces in-launch (tickets in
+                  workspace, release fence), 3 = same with write-through slab stores (no release fence),
+                  2 = separate reduce launch.  tiled: 1 = in-launch (K slices of a tile meet in tile-sized int32
+                  slots of C, tickets in workspace), 2 = ksplit [m,n] slabs in C + separate reduce launch      */
   int bm;      /* tiled: rows per workgroup tile (64, 128, 256); 0 auto                      */
   int glds;    /* tiled: 1 = direct global->LDS loads, 2 = register staged; 0 auto          */
   int pf;      /* stream: prefetch depth in 4 KiB steps per wave (3, 5, 7); 0 auto               */
@@ -78,6 +79,13 @@ int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, const void*
                      const void* s3, int prob_m, int prob_n, int prob_k, void* workspace,
                      int groupsize, int dev, void* stream, int thread_k, int thread_n, int sms,
                      int max_par, const qqq_tune_t* tune, int32_t* acc_out, const void* bias);
+
+/* The dispatch decision qqq_w4a8_gemm_ex would take for this problem, without touching the GPU (pure host
+ * logic; used by tests and tools).  have_scratch / have_workspace: whether C / workspace would be non-NULL.
+ * plan_out: kernel, ksplit, fused, waves, pf, mt (stream) or bm, glds, stages (tiled) as chosen;
+ * reserved[0] = number of tile-sized slots of C used by the tiled in-launch split-K (0 = slabs or no split). */
+int qqq_w4a8_plan(int prob_m, int prob_n, int prob_k, int groupsize, int max_par, int have_scratch,
+                  int have_workspace, const qqq_tune_t* tune, qqq_tune_t* plan_out);
 
 /*
  * Fused per-token dynamic int8 quantisation; replaces the ~8 torch launches of

@@ -39,6 +39,8 @@ def lib():
     L.qqq_w4a8_gemm.restype = ci
     L.qqq_w4a8_gemm_ex.argtypes = gemm_args + [ctypes.POINTER(QQQTune), vp, vp]
     L.qqq_w4a8_gemm_ex.restype = ci
+    L.qqq_w4a8_plan.argtypes = [ci, ci, ci, ci, ci, ci, ci, ctypes.POINTER(QQQTune), ctypes.POINTER(QQQTune)]
+    L.qqq_w4a8_plan.restype = ci
     L.qqq_dynamic_quant.argtypes = [vp, vp, vp, ci, ci, ci, vp]
     L.qqq_dynamic_quant.restype = ci
     L.qqq_add_bias.argtypes = [vp, vp, ci, ci, ci, vp]
@@ -60,3 +62,20 @@ def lib():
 
 def last_error() -> str:
     return lib().qqq_amd_last_error().decode()
+
+
+def plan(m, n, k, groupsize=-1, max_par=16, have_scratch=True, have_workspace=True, tune=None) -> dict:
+    """the dispatch decision for one problem (host logic only, no GPU work): see qqq_w4a8_plan"""
+    tn = None
+    if tune:
+        tn = QQQTune()
+        for key, v in tune.items():
+            setattr(tn, key, int(v))
+    out = QQQTune()
+    rc = lib().qqq_w4a8_plan(m, n, k, groupsize, max_par, int(have_scratch), int(have_workspace),
+                             ctypes.byref(tn) if tn is not None else None, ctypes.byref(out))
+    if rc:
+        raise RuntimeError(f"qqq_w4a8_plan failed ({rc}): {last_error()}")
+    d = {f: getattr(out, f) for f, _ in QQQTune._fields_ if f != "reserved"}
+    d["nslots"] = out.reserved[0]
+    return d

@@ -448,7 +448,7 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * (2 / NB) * 64) void 
     _Float16* __restrict__ D, const float* __restrict__ s1, const float* __restrict__ s2,
     const _Float16* __restrict__ s3, int32_t* __restrict__ acc_out,
     const _Float16* __restrict__ bias, const int M, const int N, const int K, const int ksplit,
-    const int tiles_m, const int tiles_n) {
+    const int tiles_m, const int tiles_n, int* __restrict__ tickets, const int nslots) {
   // wave tile: MTW m-tiles of 32 tokens x JW column tiles (jt) x NB column halves (b).  NB == 1: the two
   // b halves of a packed word go to two different waves (per-group mode: every weight is re-quantised
   // by exactly one wave of the workgroup).
@@ -993,16 +993,97 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * (2 / NB) * 64) void 
     }
   }
 
+  // ---- in-launch split-K (nslots > 0): the K slices of one tile meet in `nslots` tile-sized int32 slots of C.
+  // Workgroups take a ticket in ARRIVAL order.  Arrival t < ksplit-1 deposits its partial tile in slot
+  // t % nslots -- adding what the slot already holds when it is the slot's (t / nslots + 1)-th deposit --
+  // and leaves; the last arrival adds every slot to its accumulators and runs the normal epilogue.
+  // Whoever is waited for has already arrived (is past its main loop), so the spins are short and cannot
+  // deadlock whatever the dispatch order.  Slot images are lane-linear (16 B per lane, full lines); they
+  // are written through (sc0 sc1) and read behind an agent-scope acquire, because the K slices of a tile
+  // run on different XCDs (= different, mutually non-coherent L2s).  int32 adds commute: bit-exact.
+  // tickets[(1 + nslots) * tile + {0: arrivals, 1 + s: deposits completed in slot s}], all zero again on exit.
+  bool finish = (ksplit == 1);
+  if (ksplit > 1 && nslots > 0) {
+    constexpr int NQ4 = MTW * JW * NB * 4;
+    __shared__ int xch;
+    int* tk = tickets + (size_t)lin * (1 + nslots);
+    if (tid == 0) xch = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int t = xch;
+    const unsigned voff = lane * 16;  // lane offset inside a 1 KiB wave-row of a slot image
+    auto slot_base = [&](const int s_) {  // wave-uniform: lets the accesses use the SGPR-base + VGPR-offset form
+      return reinterpret_cast<const unsigned char*>(C + ((size_t)s_ * ntiles + lin) * ((size_t)BM * 256) +
+                                                    (size_t)wave * NQ4 * 256);
+    };
+    auto wait_done = [&](const int s_, const int want) {
+      if (tid == 0)
+        while (__hip_atomic_load(tk + 1 + s_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want)
+          __builtin_amdgcn_s_sleep(4);
+      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    };
+    auto add_slot = [&](const int s_) {
+      const unsigned char* p = slot_base(s_);
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int jj = 0; jj < JW; ++jj) {
+#pragma unroll
+          for (int bi = 0; bi < NB; ++bi)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+              const v4i v = *reinterpret_cast<const v4i*>(p + (((mt * JW + jj) * NB + bi) * 4 + gq) * 1024 + (size_t)voff);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc[mt][jj][bi][4 * gq + r] += v[r];
+            }
+          __builtin_amdgcn_sched_barrier(0);  // at most 4*NB loads in flight: no spill next to 128 accumulators
+        }
+    };
+    // one loop for both roles (a depositor folds at most its own slot, the last arrival every used slot)
+    const bool last = (t == ksplit - 1);
+    const int slot = last ? 0 : t % nslots, gen = last ? 0 : t / nslots;
+    const int used = (ksplit - 1 < nslots) ? ksplit - 1 : nslots;
+    const int nfold = last ? used : (gen > 0 ? 1 : 0);
+    for (int i = 0; i < nfold; ++i) {
+      const int s_ = slot + i;
+      wait_done(s_, last ? (ksplit - 1 - s_ + nslots - 1) / nslots : gen);
+      add_slot(s_);
+    }
+    if (!last) {
+      // scalar base + one 32-bit lane offset: the 4*MTW*JW*NB stores share a single address VGPR
+      const unsigned char* sbase = slot_base(slot);
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int jj = 0; jj < JW; ++jj)
+#pragma unroll
+          for (int bi = 0; bi < NB; ++bi)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+              const v4i v = {acc[mt][jj][bi][4 * gq + 0], acc[mt][jj][bi][4 * gq + 1], acc[mt][jj][bi][4 * gq + 2],
+                             acc[mt][jj][bi][4 * gq + 3]};
+              const unsigned char* sb = sbase + (((mt * JW + jj) * NB + bi) * 4 + gq) * 1024;
+              asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1" ::"v"(voff), "v"(v), "s"(sb) : "memory");
+            }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // every wave's part of the deposit has reached memory
+      if (tid == 0) __hip_atomic_store(tk + 1 + slot, gen + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    if (tid <= used) __hip_atomic_store(tk + tid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // workspace zero on return
+    finish = true;
+  }
+
   // ---- epilogue ----
   int mrow[MTW];
   float a_s[MTW];
 #pragma unroll
   for (int mt = 0; mt < MTW; ++mt) {
     mrow[mt] = m0 + (wm * MTW + mt) * 32 + li;
-    a_s[mt] = (mrow[mt] < M && ksplit == 1) ? s1[mrow[mt]] : 0.f;
+    a_s[mt] = (mrow[mt] < M && finish) ? s1[mrow[mt]] : 0.f;
   }
   const int n_lane = ng0 * 64 + 4 * h;  // + 64*g' + 16*jt + 8*b  (g' = r >> 2), + (r & 3)
-  if (ksplit == 1) {
+  if (finish) {
     // fp16 tile -> LDS (row-major, 16-byte chunks XOR-swizzled by the row so that the 8-byte writes of a
     // lane column and the 16-byte reads of a row are both conflict-light) -> full 128-byte-line stores.
     // Straight-from-register stores would be 8 bytes per lane scattered over 32 rows (measured: 2.6x write
@@ -1284,7 +1365,7 @@ static hipError_t launch_stream(const LaunchArgs& a, bool grouped, int mt, int w
 }
 
 template <int BM, int MTW, int JW, int NB, bool GROUPED, int NS>
-static hipError_t launch_tiled_t(const LaunchArgs& a, int ksplit) {
+static hipError_t launch_tiled_t(const LaunchArgs& a, int ksplit, int nslots) {
   constexpr int WAVES = (BM / (32 * MTW)) * (4 / JW) * (2 / NB);
   constexpr int NT = WAVES * 64;
   constexpr int STAGE = 8 * 2048 + BM * 128 + ((NS > 0 && GROUPED) ? WAVES * 512 : 0);
@@ -1304,108 +1385,86 @@ static hipError_t launch_tiled_t(const LaunchArgs& a, int ksplit) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + 255) / 256;
   dim3 grid(tiles_m * tiles_n, ksplit, 1);
   hipLaunchKernelGGL(kern, grid, dim3(NT), LDS, a.stream, a.A, a.B, a.C, a.D, a.s1, a.s2, a.s3,
-                     a.acc_out, a.bias, a.M, a.N, a.K, ksplit, tiles_m, tiles_n);
+                     a.acc_out, a.bias, a.M, a.N, a.K, ksplit, tiles_m, tiles_n, a.tickets, nslots);
   return hipGetLastError();
 }
 
 // stages: 0 = register-staged; 2..4 = LDS-DMA ring depth (clamped to what fits in 160 KiB of LDS)
 template <bool GROUPED>
-static hipError_t launch_tiled_bm(const LaunchArgs& a, int bm, int stages, int ksplit) {
+static hipError_t launch_tiled_bm(const LaunchArgs& a, int bm, int stages, int ksplit, int nslots) {
   switch (bm) {
     case 64:
-      if (stages == 0) return launch_tiled_t<64, 1, 2, 2, GROUPED, 0>(a, ksplit);
-      if (stages == 2) return launch_tiled_t<64, 1, 2, 2, GROUPED, 2>(a, ksplit);
-      if (stages == 3) return launch_tiled_t<64, 1, 2, 2, GROUPED, 3>(a, ksplit);
-      return launch_tiled_t<64, 1, 2, 2, GROUPED, 4>(a, ksplit);
+      if (stages == 0) return launch_tiled_t<64, 1, 2, 2, GROUPED, 0>(a, ksplit, nslots);
+      if (stages == 2) return launch_tiled_t<64, 1, 2, 2, GROUPED, 2>(a, ksplit, nslots);
+      if (stages == 3) return launch_tiled_t<64, 1, 2, 2, GROUPED, 3>(a, ksplit, nslots);
+      return launch_tiled_t<64, 1, 2, 2, GROUPED, 4>(a, ksplit, nslots);
     case 128:
-      if (stages == 0) return launch_tiled_t<128, 2, 2, 2, GROUPED, 0>(a, ksplit);
-      if (stages == 2) return launch_tiled_t<128, 2, 2, 2, GROUPED, 2>(a, ksplit);
-      if (stages == 3) return launch_tiled_t<128, 2, 2, 2, GROUPED, 3>(a, ksplit);
-      return launch_tiled_t<128, 2, 2, 2, GROUPED, 4>(a, ksplit);
+      if (stages == 0) return launch_tiled_t<128, 2, 2, 2, GROUPED, 0>(a, ksplit, nslots);
+      if (stages == 2) return launch_tiled_t<128, 2, 2, 2, GROUPED, 2>(a, ksplit, nslots);
+      if (stages == 3) return launch_tiled_t<128, 2, 2, 2, GROUPED, 3>(a, ksplit, nslots);
+      return launch_tiled_t<128, 2, 2, 2, GROUPED, 4>(a, ksplit, nslots);
     case 130:  // 128-row tile, 8 waves, each wave owns ONE (jt, b) column set over all 128 rows
-      if (stages == 0) return launch_tiled_t<128, 4, 1, 1, GROUPED, 0>(a, ksplit);
-      if (stages == 2) return launch_tiled_t<128, 4, 1, 1, GROUPED, 2>(a, ksplit);
-      if (stages == 3) return launch_tiled_t<128, 4, 1, 1, GROUPED, 3>(a, ksplit);
-      if (stages == 5) return launch_tiled_t<128, 4, 1, 1, GROUPED, 5>(a, ksplit);
-      return launch_tiled_t<128, 4, 1, 1, GROUPED, 4>(a, ksplit);
+      if (stages == 0) return launch_tiled_t<128, 4, 1, 1, GROUPED, 0>(a, ksplit, nslots);
+      if (stages == 2) return launch_tiled_t<128, 4, 1, 1, GROUPED, 2>(a, ksplit, nslots);
+      if (stages == 3) return launch_tiled_t<128, 4, 1, 1, GROUPED, 3>(a, ksplit, nslots);
+      if (stages == 5) return launch_tiled_t<128, 4, 1, 1, GROUPED, 5>(a, ksplit, nslots);
+      return launch_tiled_t<128, 4, 1, 1, GROUPED, 4>(a, ksplit, nslots);
     case 131:  // 128-row tile, 8 waves as 2 (m) x 4 (jt): wave = 64 rows x one jt, both b
-      if (stages == 0) return launch_tiled_t<128, 2, 1, 2, GROUPED, 0>(a, ksplit);
-      if (stages == 2) return launch_tiled_t<128, 2, 1, 2, GROUPED, 2>(a, ksplit);
-      if (stages == 3) return launch_tiled_t<128, 2, 1, 2, GROUPED, 3>(a, ksplit);
-      if (stages == 5) return launch_tiled_t<128, 2, 1, 2, GROUPED, 5>(a, ksplit);
-      return launch_tiled_t<128, 2, 1, 2, GROUPED, 4>(a, ksplit);
+      if (stages == 0) return launch_tiled_t<128, 2, 1, 2, GROUPED, 0>(a, ksplit, nslots);
+      if (stages == 2) return launch_tiled_t<128, 2, 1, 2, GROUPED, 2>(a, ksplit, nslots);
+      if (stages == 3) return launch_tiled_t<128, 2, 1, 2, GROUPED, 3>(a, ksplit, nslots);
+      if (stages == 5) return launch_tiled_t<128, 2, 1, 2, GROUPED, 5>(a, ksplit, nslots);
+      return launch_tiled_t<128, 2, 1, 2, GROUPED, 4>(a, ksplit, nslots);
     case 258:  // 256-row tile, 8 waves, each wave owns ONE (jt, b) column set over all 256 rows
-      if (stages == 0) return launch_tiled_t<256, 8, 1, 1, GROUPED, 0>(a, ksplit);
-      if (stages == 2) return launch_tiled_t<256, 8, 1, 1, GROUPED, 2>(a, ksplit);
-      if (stages == 5) return launch_tiled_t<256, 8, 1, 1, GROUPED, 5>(a, ksplit);
-      return launch_tiled_t<256, 8, 1, 1, GROUPED, 3>(a, ksplit);
+      if (stages == 0) return launch_tiled_t<256, 8, 1, 1, GROUPED, 0>(a, ksplit, nslots);
+      if (stages == 2) return launch_tiled_t<256, 8, 1, 1, GROUPED, 2>(a, ksplit, nslots);
+      if (stages == 5) return launch_tiled_t<256, 8, 1, 1, GROUPED, 5>(a, ksplit, nslots);
+      return launch_tiled_t<256, 8, 1, 1, GROUPED, 3>(a, ksplit, nslots);
     case 259:  // 256-row tile, 8 waves as 2 (m) x 4 (jt): wave = 128 rows x one jt, both b
-      if (stages == 0) return launch_tiled_t<256, 4, 1, 2, GROUPED, 0>(a, ksplit);
-      if (stages == 2) return launch_tiled_t<256, 4, 1, 2, GROUPED, 2>(a, ksplit);
-      if (stages == 5) return launch_tiled_t<256, 4, 1, 2, GROUPED, 5>(a, ksplit);
-      return launch_tiled_t<256, 4, 1, 2, GROUPED, 3>(a, ksplit);
+      if (stages == 0) return launch_tiled_t<256, 4, 1, 2, GROUPED, 0>(a, ksplit, nslots);
+      if (stages == 2) return launch_tiled_t<256, 4, 1, 2, GROUPED, 2>(a, ksplit, nslots);
+      if (stages == 5) return launch_tiled_t<256, 4, 1, 2, GROUPED, 5>(a, ksplit, nslots);
+      return launch_tiled_t<256, 4, 1, 2, GROUPED, 3>(a, ksplit, nslots);
     default:
-      if (stages == 0) return launch_tiled_t<256, 2, 2, 2, GROUPED, 0>(a, ksplit);
-      if (stages == 2) return launch_tiled_t<256, 2, 2, 2, GROUPED, 2>(a, ksplit);
-      if (stages == 5) return launch_tiled_t<256, 2, 2, 2, GROUPED, 5>(a, ksplit);
-      if (stages == 6) return launch_tiled_t<256, 2, 2, 2, GROUPED, 6>(a, ksplit);
-      return launch_tiled_t<256, 2, 2, 2, GROUPED, 3>(a, ksplit);
+      if (stages == 0) return launch_tiled_t<256, 2, 2, 2, GROUPED, 0>(a, ksplit, nslots);
+      if (stages == 2) return launch_tiled_t<256, 2, 2, 2, GROUPED, 2>(a, ksplit, nslots);
+      if (stages == 5) return launch_tiled_t<256, 2, 2, 2, GROUPED, 5>(a, ksplit, nslots);
+      if (stages == 6) return launch_tiled_t<256, 2, 2, 2, GROUPED, 6>(a, ksplit, nslots);
+      return launch_tiled_t<256, 2, 2, 2, GROUPED, 3>(a, ksplit, nslots);
   }
 }
 
-static hipError_t launch_tiled(const LaunchArgs& a, bool grouped, int bm, int stages, int ksplit) {
-  return grouped ? launch_tiled_bm<true>(a, bm, stages, ksplit) : launch_tiled_bm<false>(a, bm, stages, ksplit);
+static hipError_t launch_tiled(const LaunchArgs& a, bool grouped, int bm, int stages, int ksplit, int nslots) {
+  return grouped ? launch_tiled_bm<true>(a, bm, stages, ksplit, nslots)
+                 : launch_tiled_bm<false>(a, bm, stages, ksplit, nslots);
 }
 
 static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, const void* s1,
-                                const void* s2, const void* s3, int prob_m, int prob_n, int prob_k,
-                                void* workspace, int groupsize, int dev, void* stream, int thread_k,
-                                int thread_n, int sms, int max_par, const qqq_tune_t* tune,
-                                int32_t* acc_out, const void* bias) {
-  (void)sms;
-  g_err[0] = 0;
-  const int rc = ref_shape_check(prob_m, prob_n, prob_k, groupsize, thread_k, thread_n);
-  if (rc != QQQ_OK) return rc;
-  if (prob_m == 0 || prob_n == 0 || prob_k == 0) return QQQ_OK;  // reference :1002-1003
-  if (!A || !B || !D || !s1 || !s2 || (groupsize != -1 && !s3)) {
-    snprintf(g_err, sizeof(g_err), "null pointer argument");
-    return QQQ_ERR_ARG;
-  }
-  const bool grouped = groupsize != -1;
-  qqq_tune_t t;
-  memset(&t, 0, sizeof(t));
-  if (tune) t = *tune;
+// The dispatch decision of one call, as plain data (pure host logic: also exported as qqq_w4a8_plan so
+// that it can be inspected and tested without a GPU).
+struct Plan {
+  int kernel;  // 1 stream, 2 tiled
+  int ksplit;
+  int fused;   // stream: 1 / 3 in-launch, 2 separate reduce.  tiled: 1 in-launch slots, 2 slabs + reduce
+  int mt, waves, pf;      // stream
+  int bm, stages, nslots; // tiled
+};
 
-  const int M = prob_m, N = prob_n, K = prob_k;
+static Plan make_plan(const int M, const int N, const int K, const bool grouped, const int max_par,
+                      const bool have_C, const bool have_ws, qqq_tune_t t) {
+  Plan pl;
+  memset(&pl, 0, sizeof(pl));
   const long long cap_rows = (long long)(max_par > 0 ? max_par : 0) * 64;  // rows of C we may use
-  const bool have_scratch = (C != nullptr) && cap_rows > 0;
+  const bool have_scratch = have_C && cap_rows > 0;
+  const void* workspace = have_ws ? reinterpret_cast<const void*>(1) : nullptr;
 
-  // ---- kernel choice (measured on MI355X, profiles/tune_r01.txt) ----
+  // ---- kernel choice (measured on MI355X, profiles/) ----
   // m <= 128: the HBM-bound "stream" kernel wins (weights straight to VGPRs); above, LDS tiles.
   int kernel = t.kernel;
   if (kernel == 0) kernel = (M <= 128 || (K % 128) != 0) ? 1 : 2;
   if (kernel == 2 && (K % 128) != 0) kernel = 1;
-
-  LaunchArgs a;
-  a.A = static_cast<const int8_t*>(A);
-  a.B = static_cast<const unsigned char*>(B);
-  a.C = static_cast<int32_t*>(C);
-  a.D = static_cast<_Float16*>(D);
-  a.s1 = static_cast<const float*>(s1);
-  a.s2 = static_cast<const float*>(s2);
-  a.s3 = static_cast<const _Float16*>(s3);
-  a.acc_out = acc_out;
-  a.bias = static_cast<const _Float16*>(bias);
-  a.tickets = static_cast<int*>(workspace);
-  a.M = M;
-  a.N = N;
-  a.K = K;
-  a.stream = static_cast<hipStream_t>(stream);
-
-  DeviceGuard guard(dev);
-  hipError_t e = hipSuccess;
+  pl.kernel = kernel;
   int ksplit = 1;
 
   if (kernel == 1) {
@@ -1434,31 +1493,37 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
     // tickets: one int per (m-block, strip); the reference guarantees n/128*max_par ints
     if ((fused == 1 || fused == 3) && (workspace == nullptr || (long long)mblocks * strips > (long long)(N / 128) * max_par))
       fused = 2;
-    const int pf = t.pf > 0 ? t.pf : (mt <= 2 ? 3 : 2);
-    // kernel arg: 0 = slabs only (separate reduce launch), 1 = in-launch + release fence, 2 = in-launch + write-through
-    e = launch_stream(a, grouped, mt, waves, pf, ksplit, fused == 1 ? 1 : (fused == 3 ? 2 : 0));
-    if (e != hipSuccess) return fail_hip(e, "qqq_stream_kernel launch");
-    if (ksplit > 1 && fused != 1 && fused != 3) {
-      const long long items = (long long)M * (N / 4);
-      const int blocks = (int)((items + 63) / 64 > 8192 ? 8192 : (items + 63) / 64);
-      hipLaunchKernelGGL(qqq_reduce_kernel, dim3(blocks), dim3(64), 0, a.stream, a.C, a.D, a.s1, a.s2,
-                         a.acc_out, a.bias, M, N, ksplit);
-      e = hipGetLastError();
-      if (e != hipSuccess) return fail_hip(e, "qqq_reduce_kernel launch");
-    }
-    return QQQ_OK;
+    pl.mt = mt;
+    pl.waves = waves;
+    pl.pf = t.pf > 0 ? t.pf : (mt <= 2 ? 3 : 2);
+    pl.ksplit = ksplit;
+    pl.fused = fused;
+    return pl;
   }
 
   // ---- tiled ----
+  // Split-K comes in two forms.  In-launch (default when it fits): the K slices of a tile meet in tile-sized
+  // int32 slots of C, tickets in `workspace`, the last arrival runs the epilogue -- needs one slot per tile
+  // (<= max_par*64 rows of C) whatever ksplit is.  Slabs + separate reduce launch: ksplit full [m, n] slabs.
+  const long long strips = (N + 255) / 256;
+  const long long cap_ints = cap_rows * (long long)N;
+  const long long cap_tickets = workspace ? (long long)(N / 128) * (max_par > 0 ? max_par : 0) : 0;
+  auto slot_count = [&](int rows, int ks) -> int {
+    if (!have_scratch || ks < 2 || t.fused == 2) return 0;
+    const long long tl = (long long)((M + rows - 1) / rows) * strips;
+    long long S = cap_ints / (tl * rows * 256);
+    if (S > ks - 1) S = ks - 1;
+    while (S > 0 && tl * (1 + S) > cap_tickets) --S;
+    return (int)S;
+  };
   int bm = t.bm;
   if (bm != 64 && bm != 128 && bm != 256 && bm != 258 && bm != 259 && bm != 130 && bm != 131) {
     // Pick the tile height (and its K split) by a small cost model in microseconds:
-    //   rounds(tiles x ksplit over 256 CUs) x tile_time(rows, K / ksplit, rate(shape)) + split-K reduce cost,
+    //   rounds(tiles x ksplit over 256 CUs) x tile_time(rows, K / ksplit, rate(shape)) + split-K cost,
     // per-shape rates (TOPS at large m) measured on MI355X (profiles/).  Bigger tiles are more efficient per
-    // MFMA but quantise worse over the CUs; split-K fills idle CUs at the price of int32 slab traffic.
+    // MFMA but quantise worse over the CUs; split-K fills idle CUs at the price of int32 partial-sum traffic.
     // Wave shapes per mode: per-channel keeps 64x128 wave tiles (least LDS traffic); per-group uses the
     // column-owner shapes (258 / 130): every weight re-quantised once per workgroup.
-    const long long strips = (N + 255) / 256;
     // {several workgroups co-resident per CU, a single one} -- small tiles lose efficiency when alone on a CU
     const double rate256 = grouped ? 1800.0 : 2300.0;
     const double rate128[2] = {grouped ? 1360.0 : 2050.0, grouped ? 1320.0 : 1650.0};
@@ -1467,21 +1532,21 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
     double best = 1e30;
     auto consider = [&](int rows, const double* rates, int code) {
       const long long tl = (long long)((M + rows - 1) / rows) * strips;
-      int ks = 1;
-      if (tl < 192 && have_scratch) {
-        ks = (int)((256 + tl - 1) / tl);
-        ks = clampi(ks, 1, (K / 128) / 4 > 0 ? (K / 128) / 4 : 1);
-        if ((long long)ks * M > cap_rows) ks = (int)(cap_rows / M);
-        if (ks < 1) ks = 1;
-      }
-      const double rate = (rows == 256) ? rates[0] : rates[(tl * ks <= 256) ? 1 : 0];
-      const double tile_us = (double)rows * ((double)K / ks) * 131072.0 / (rate * 1e6) + 6.0;  // + prologue/epilogue
-      double us = (double)((tl * ks + 255) / 256) * tile_us;
-      if (ks > 1) us += 5.0 + (double)ks * M * N * 8.0 / 3.0e6;  // slabs written + read at ~3 TB/s, + launch
-      if (us < best) {
-        best = us;
-        bm = code;
-        best_ks = ks;
+      const int ks_max = (tl < 192 && have_scratch) ? clampi((int)((256 + tl - 1) / tl), 1, (K / 128) / 4 > 0 ? (K / 128) / 4 : 1) : 1;
+      for (int ks = 1; ks <= ks_max; ++ks) {
+        const int S = slot_count(rows, ks);
+        if (ks > 1 && S == 0 && (long long)ks * M > cap_rows) break;
+        const double rate = (rows == 256) ? rates[0] : rates[(tl * ks <= 256) ? 1 : 0];
+        const double tile_us = (double)rows * ((double)K / ks) * 131072.0 / (rate * 1e6) + 6.0;  // + prologue/epilogue
+        double us = (double)((tl * ks + 255) / 256) * tile_us;
+        if (ks > 1 && S > 0)  // every deposit is written once and read once (~4.2 TB/s chip-wide) + serial hops
+          us += 3.0 + 2.0 * (ks - 1) * (double)tl * rows * 1024.0 / 4.2e6 + 3.0 * (double)((ks - 1 + S - 1) / S);
+        else if (ks > 1) us += 5.0 + (double)ks * M * N * 8.0 / 3.0e6;  // slabs written + read at ~3 TB/s, + launch
+        if (us < best) {
+          best = us;
+          bm = code;
+          best_ks = ks;
+        }
       }
     };
     consider(256, &rate256, grouped ? 258 : 256);
@@ -1497,7 +1562,7 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
   else stages = (bm == 256) ? 5 : (bm == 258) ? 3 : (bm == 130) ? 4 : 0;  // measured best per shape
   if (bm >= 256 && stages == 4) stages = 3;
   const int bm_rows = (bm >= 256) ? 256 : (bm >= 128 ? 128 : bm);
-  const long long tiles = (long long)((M + bm_rows - 1) / bm_rows) * ((N + 255) / 256);
+  const long long tiles = (long long)((M + bm_rows - 1) / bm_rows) * strips;
   ksplit = t.ksplit;
   if (ksplit <= 0) {
     ksplit = tiles >= 192 ? 1 : (int)((256 + tiles - 1) / tiles);
@@ -1505,15 +1570,97 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
   }
   ksplit = clampi(ksplit, 1, K / 128);
   if (!have_scratch) ksplit = 1;
-  if (ksplit > 1 && (long long)ksplit * M > cap_rows) ksplit = (int)(cap_rows / M);
+  const int nslots = slot_count(bm_rows, ksplit);
+  if (nslots == 0 && ksplit > 1 && (long long)ksplit * M > cap_rows) ksplit = (int)(cap_rows / M);
   if (ksplit < 1) ksplit = 1;
-  e = launch_tiled(a, grouped, bm, stages, ksplit);
-  if (e != hipSuccess) return fail_hip(e, "qqq_tiled_kernel launch");
-  if (ksplit > 1) {
+  pl.bm = bm;
+  pl.stages = stages;
+  pl.ksplit = ksplit;
+  pl.nslots = ksplit > 1 ? nslots : 0;
+  pl.fused = pl.nslots > 0 ? 1 : 2;
+  return pl;
+}
+
+extern "C" int qqq_w4a8_plan(int prob_m, int prob_n, int prob_k, int groupsize, int max_par, int have_scratch,
+                             int have_workspace, const qqq_tune_t* tune, qqq_tune_t* plan_out) {
+  g_err[0] = 0;
+  if (!plan_out || prob_m <= 0 || prob_n <= 0 || prob_k <= 0) {
+    snprintf(g_err, sizeof(g_err), "qqq_w4a8_plan: bad argument");
+    return QQQ_ERR_ARG;
+  }
+  qqq_tune_t t;
+  memset(&t, 0, sizeof(t));
+  if (tune) t = *tune;
+  const Plan pl = make_plan(prob_m, prob_n, prob_k, groupsize != -1, max_par, have_scratch != 0, have_workspace != 0, t);
+  memset(plan_out, 0, sizeof(*plan_out));
+  plan_out->kernel = pl.kernel;
+  plan_out->ksplit = pl.ksplit;
+  plan_out->fused = pl.fused;
+  plan_out->waves = pl.waves;
+  plan_out->pf = pl.pf;
+  plan_out->mt = pl.mt;
+  plan_out->bm = pl.bm;
+  plan_out->stages = pl.stages;
+  plan_out->glds = pl.kernel == 2 ? (pl.stages == 0 ? 2 : 1) : 0;
+  plan_out->reserved[0] = pl.nslots;
+  return QQQ_OK;
+}
+
+extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, const void* s1,
+                                const void* s2, const void* s3, int prob_m, int prob_n, int prob_k,
+                                void* workspace, int groupsize, int dev, void* stream, int thread_k,
+                                int thread_n, int sms, int max_par, const qqq_tune_t* tune,
+                                int32_t* acc_out, const void* bias) {
+  (void)sms;
+  g_err[0] = 0;
+  const int rc = ref_shape_check(prob_m, prob_n, prob_k, groupsize, thread_k, thread_n);
+  if (rc != QQQ_OK) return rc;
+  if (prob_m == 0 || prob_n == 0 || prob_k == 0) return QQQ_OK;  // reference :1002-1003
+  if (!A || !B || !D || !s1 || !s2 || (groupsize != -1 && !s3)) {
+    snprintf(g_err, sizeof(g_err), "null pointer argument");
+    return QQQ_ERR_ARG;
+  }
+  const bool grouped = groupsize != -1;
+  qqq_tune_t t;
+  memset(&t, 0, sizeof(t));
+  if (tune) t = *tune;
+  const int M = prob_m, N = prob_n, K = prob_k;
+  const Plan pl = make_plan(M, N, K, grouped, max_par, C != nullptr, workspace != nullptr, t);
+
+  LaunchArgs a;
+  a.A = static_cast<const int8_t*>(A);
+  a.B = static_cast<const unsigned char*>(B);
+  a.C = static_cast<int32_t*>(C);
+  a.D = static_cast<_Float16*>(D);
+  a.s1 = static_cast<const float*>(s1);
+  a.s2 = static_cast<const float*>(s2);
+  a.s3 = static_cast<const _Float16*>(s3);
+  a.acc_out = acc_out;
+  a.bias = static_cast<const _Float16*>(bias);
+  a.tickets = static_cast<int*>(workspace);
+  a.M = M;
+  a.N = N;
+  a.K = K;
+  a.stream = static_cast<hipStream_t>(stream);
+
+  DeviceGuard guard(dev);
+  hipError_t e = hipSuccess;
+  bool reduce_launch;
+  if (pl.kernel == 1) {
+    // kernel arg: 0 = slabs only (separate reduce launch), 1 = in-launch + release fence, 2 = in-launch + write-through
+    e = launch_stream(a, grouped, pl.mt, pl.waves, pl.pf, pl.ksplit, pl.fused == 1 ? 1 : (pl.fused == 3 ? 2 : 0));
+    if (e != hipSuccess) return fail_hip(e, "qqq_stream_kernel launch");
+    reduce_launch = pl.ksplit > 1 && pl.fused != 1 && pl.fused != 3;
+  } else {
+    e = launch_tiled(a, grouped, pl.bm, pl.stages, pl.ksplit, pl.nslots);
+    if (e != hipSuccess) return fail_hip(e, "qqq_tiled_kernel launch");
+    reduce_launch = pl.ksplit > 1 && pl.nslots == 0;
+  }
+  if (reduce_launch) {
     const long long items = (long long)M * (N / 4);
     const int blocks = (int)((items + 63) / 64 > 8192 ? 8192 : (items + 63) / 64);
     hipLaunchKernelGGL(qqq_reduce_kernel, dim3(blocks), dim3(64), 0, a.stream, a.C, a.D, a.s1, a.s2,
-                       a.acc_out, a.bias, M, N, ksplit);
+                       a.acc_out, a.bias, M, N, pl.ksplit);
     e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "qqq_reduce_kernel launch");
   }

@@ -77,7 +77,13 @@ def variants(M, K, N):
             v.append(dict(kernel=2, bm=256, glds=1, stages=6, ksplit=2))
             v.append(dict(kernel=2, bm=128, glds=1, stages=3, ksplit=2))
             v.append(dict(kernel=2, bm=64, glds=2, ksplit=2))
+            # tiled split-K: fused=1 in-launch (slots + tickets; also the default), fused=2 slabs + reduce launch
+            v.append(dict(kernel=2, bm=256, glds=1, stages=5, ksplit=2, fused=2))
+            v.append(dict(kernel=2, bm=131, glds=2, ksplit=2, fused=1))
+            v.append(dict(kernel=2, bm=64, glds=2, ksplit=2, fused=2))
         if K // 128 >= 4:
             v.append(dict(kernel=2, bm=64, glds=1, stages=4, ksplit=3))
+            v.append(dict(kernel=2, bm=130, glds=1, stages=4, ksplit=4, fused=1))
+            v.append(dict(kernel=2, bm=64, glds=1, stages=4, ksplit=3, fused=2))
     v.append(dict())  # fully automatic (== qqq_w4a8_gemm)
     return v

@@ -55,3 +55,39 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(build, "LIB", str(tmp_path / "nope.so"))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _lib.lib()
+
+
+def test_dispatch_plan_respects_scratch_contract(L):
+    """qqq_w4a8_plan is pure host logic: for every shape the plan must stay inside what the reference's
+    buffers guarantee (C = max_par*64 rows x n int32, workspace = n/128*max_par ints; qlinear_marlin.py:117-133)."""
+    from qqq_amd import _lib
+
+    for grouped in (False, True):
+        for n, k in ((8192, 21760), (4096, 4096), (11008, 4096), (4096, 11008), (256, 128), (320, 1536)):
+            for max_par in (1, 4, 16):
+                for m in (1, 7, 16, 64, 128, 129, 200, 256, 300, 512, 640, 1000, 1024, 1025, 2048, 4096, 32768):
+                    p = _lib.plan(m, n, k, 128 if grouped else -1, max_par)
+                    assert p["kernel"] in (1, 2) and p["ksplit"] >= 1
+                    cap_rows, cap_tk = max_par * 64, (n // 128) * max_par
+                    if p["kernel"] == 1:
+                        assert m <= 128 or k % 128
+                        if p["ksplit"] > 1:
+                            assert p["ksplit"] * m <= cap_rows and p["fused"] == 2
+                        continue
+                    rows = 256 if p["bm"] >= 256 else 128 if p["bm"] >= 128 else 64
+                    tiles = -(-m // rows) * -(-n // 256)
+                    assert p["ksplit"] <= k // 128
+                    if p["ksplit"] > 1 and p["nslots"] > 0:  # in-launch: slots + tickets must fit
+                        assert p["nslots"] * tiles * rows * 256 <= cap_rows * n
+                        assert tiles * (1 + p["nslots"]) <= cap_tk and p["nslots"] <= p["ksplit"] - 1
+                    elif p["ksplit"] > 1:  # slabs
+                        assert p["ksplit"] * m <= cap_rows
+                    # without scratch there is never a split
+                    assert _lib.plan(m, n, k, 128 if grouped else -1, max_par, have_scratch=False)["ksplit"] == 1
+    # forced variants are honoured, and an impossible in-launch request falls back to slabs or no split
+    p = _lib.plan(1024, 8192, 21760, -1, 16, tune=dict(kernel=2, bm=256, ksplit=2, fused=1))
+    assert (p["bm"], p["ksplit"], p["nslots"], p["fused"]) == (256, 2, 1, 1)
+    p = _lib.plan(1024, 8192, 21760, -1, 16, tune=dict(kernel=2, bm=256, ksplit=2, fused=2))
+    assert p["nslots"] == 0 and p["ksplit"] == 1  # 2 slabs of 1024 rows do not fit in 1024 rows
+    p = _lib.plan(2048, 8192, 21760, -1, 16, tune=dict(kernel=2, bm=256, ksplit=2, fused=1))
+    assert p["ksplit"] == 1

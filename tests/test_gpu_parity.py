@@ -127,6 +127,42 @@ def test_random_shapes_against_oracle(dev):
                 assert ulp_distance(D, eD) == 0, (M, N, K, grouped, tune)
 
 
+def test_tiled_inlaunch_splitk_slot_chains(dev):
+    """In-launch split-K of the tiled kernel: K slices of a tile meet in tile-sized int32 slots of C, in
+    arrival order.  Shrinking max_par (rows of C = max_par*64, tickets = n/128*max_par) forces the
+    single-slot case where deposits chain (read-add-write) and, below one slot, the fall-back to slabs;
+    every combination must stay bit-exact, leave the workspace zero, and survive repeated calls."""
+    from oracle import c_oracle as C
+    from oracle import qqq_ref as R
+
+    rng = np.random.default_rng(77)
+    for (M, N, K, max_pars) in [(64, 256, 1024, (1, 2, 16)), (300, 768, 2048, (5, 8, 16)), (513, 320, 1536, (9, 16)),
+                                (200, 1024, 4096, (4, 16))]:
+        for grouped in (False, True):
+            if grouped:
+                codes = rng.integers(0, 16, size=(K, N), dtype=np.int8)
+                s3 = (rng.random((K // 128, N), dtype=np.float32) * 15 + 0.5).astype(np.float16)
+            else:
+                codes = rng.integers(-8, 8, size=(K, N), dtype=np.int8)
+                s3 = np.zeros((0,), np.float16)
+            B = R.pack_codes(codes, grouped)
+            A = rng.integers(-128, 128, size=(M, K), dtype=np.int8)
+            s1 = (rng.random((M, 1), dtype=np.float32) * 0.05 + 0.001)
+            s2 = (rng.random((1, N), dtype=np.float32) * 2e-4 + 1e-5)
+            eD, eacc = C.qqq_gemm(A, B, s1, s2, s3 if grouped else None, return_acc=True)
+            for max_par in max_pars:
+                h = GemmHarness(B, s2, s3, dev, max_par=max_par)
+                for bm, extra in ((64, dict(glds=2)), (131, dict(glds=2)), (130, dict(glds=1, stages=4)),
+                                  (256, dict(glds=1, stages=5)), (258, dict(glds=1, stages=3))):
+                    for ks in (2, 3, 5, 8):
+                        for fused in (1, 2):
+                            tune = dict(kernel=2, bm=bm, ksplit=ks, fused=fused, **extra)
+                            for rep in range(2):
+                                D, acc = h.run(A, s1, tune)
+                                assert np.array_equal(acc, eacc), (M, N, K, grouped, max_par, tune, rep)
+                                assert ulp_distance(D, eD) == 0, (M, N, K, grouped, max_par, tune, rep)
+
+
 # ------------------------------------------------------------------------------------------------
 # BASELINE sizes: N=8192, K=21760
 # ------------------------------------------------------------------------------------------------

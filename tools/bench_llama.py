@@ -26,20 +26,34 @@ def make_ql(dev, N, K, group_size, seed):
     return ql
 
 
-def time_fn(fn, iters=10):
+def time_fn(fn, iters=10, reps=8):
+    """median per-call GPU time with the launches replayed from a hipGraph (`reps` calls per graph), i.e.
+    without Python / launch-enqueue gaps between the kernels -- the way a serving stack issues a layer.
+    Both the QuantLinear and the fp16 nn.Linear are timed this way."""
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            for _ in range(reps):
+                fn()
+    torch.cuda.current_stream().wait_stream(side)
+    g.replay()
+    torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
     for a, b in ev:
-        a.record(); fn(); b.record()
+        a.record(); g.replay(); b.record()
     torch.cuda.synchronize()
-    return float(np.median([a.elapsed_time(b) for a, b in ev]) * 1e3)
+    return float(np.median([a.elapsed_time(b) for a, b in ev]) * 1e3 / reps)
 
 
 def main():
     dev = torch.device("cuda:0")
-    out = {"device": torch.cuda.get_device_name(dev), "layers": {}}
+    out = {"device": torch.cuda.get_device_name(dev), "launch": "hipGraph replay (8 calls per graph)", "layers": {}}
     for gs in (-1, 128):
         mode = "per_channel" if gs == -1 else "g128"
         tot = {}
