@@ -1559,7 +1559,7 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
   int stages;
   if (t.glds == 2) stages = 0;
   else if (t.glds == 1) stages = ((t.stages >= 2 && t.stages <= 4) || (t.stages == 5 && bm != 64 && bm != 128) || (t.stages == 6 && bm == 256)) ? t.stages : (bm >= 256 ? 3 : 4);
-  else stages = (bm == 256) ? 5 : (bm == 258) ? 3 : (bm == 130) ? 4 : 0;  // measured best per shape
+  else stages = (bm == 256) ? 6 : (bm == 258) ? 2 : (bm == 130) ? 4 : 0;  // measured best per shape (profiles/r01_tune_sweep_*.txt)
   if (bm >= 256 && stages == 4) stages = 3;
   const int bm_rows = (bm >= 256) ? 256 : (bm >= 128 ? 128 : bm);
   const long long tiles = (long long)((M + bm_rows - 1) / bm_rows) * strips;
