@@ -68,7 +68,9 @@ typedef struct qqq_tune {
   int pf;      /* stream: prefetch depth in 4 KiB steps per wave (3, 5, 7); 0 auto               */
   int stages;  /* tiled + LDS-DMA: ring depth 2..4 (0 auto)                                      */
   int mt;      /* stream: 16-token tiles per workgroup (1..4); 0 auto                           */
-  int reserved[3];
+  int pw;      /* tiled: weight strips per XCD panel of the tile order (4, 8, 16, 32); 0 auto          */
+  int nslots;  /* out (qqq_w4a8_plan only): tile-sized slots of C used by the tiled in-launch split-K  */
+  int reserved[1];
 } qqq_tune_t;
 
 /* As qqq_w4a8_gemm; `tune` may be NULL; if `acc_out` != NULL the raw int32 accumulators
@@ -82,8 +84,8 @@ int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, const void*
 
 /* The dispatch decision qqq_w4a8_gemm_ex would take for this problem, without touching the GPU (pure host
  * logic; used by tests and tools).  have_scratch / have_workspace: whether C / workspace would be non-NULL.
- * plan_out: kernel, ksplit, fused, waves, pf, mt (stream) or bm, glds, stages (tiled) as chosen;
- * reserved[0] = number of tile-sized slots of C used by the tiled in-launch split-K (0 = slabs or no split). */
+ * plan_out: kernel, ksplit, fused, waves, pf, mt (stream) or bm, glds, stages, pw (tiled) as chosen;
+ * nslots = number of tile-sized slots of C used by the tiled in-launch split-K (0 = slabs or no split). */
 int qqq_w4a8_plan(int prob_m, int prob_n, int prob_k, int groupsize, int max_par, int have_scratch,
                   int have_workspace, const qqq_tune_t* tune, qqq_tune_t* plan_out);
 

@@ -14,7 +14,8 @@ class QQQTune(ctypes.Structure):
     _fields_ = [
         ("kernel", ctypes.c_int), ("ksplit", ctypes.c_int), ("waves", ctypes.c_int),
         ("fused", ctypes.c_int), ("bm", ctypes.c_int), ("glds", ctypes.c_int),
-        ("pf", ctypes.c_int), ("stages", ctypes.c_int), ("mt", ctypes.c_int), ("reserved", ctypes.c_int * 3),
+        ("pf", ctypes.c_int), ("stages", ctypes.c_int), ("mt", ctypes.c_int), ("pw", ctypes.c_int),
+        ("nslots", ctypes.c_int), ("reserved", ctypes.c_int * 1),
     ]
 
 
@@ -76,6 +77,4 @@ def plan(m, n, k, groupsize=-1, max_par=16, have_scratch=True, have_workspace=Tr
                              ctypes.byref(tn) if tn is not None else None, ctypes.byref(out))
     if rc:
         raise RuntimeError(f"qqq_w4a8_plan failed ({rc}): {last_error()}")
-    d = {f: getattr(out, f) for f, _ in QQQTune._fields_ if f != "reserved"}
-    d["nslots"] = out.reserved[0]
-    return d
+    return {f: getattr(out, f) for f, _ in QQQTune._fields_ if f != "reserved"}

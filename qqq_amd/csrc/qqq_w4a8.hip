@@ -448,7 +448,7 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * (2 / NB) * 64) void 
     _Float16* __restrict__ D, const float* __restrict__ s1, const float* __restrict__ s2,
     const _Float16* __restrict__ s3, int32_t* __restrict__ acc_out,
     const _Float16* __restrict__ bias, const int M, const int N, const int K, const int ksplit,
-    const int tiles_m, const int tiles_n, int* __restrict__ tickets, const int nslots) {
+    const int tiles_m, const int tiles_n, int* __restrict__ tickets, const int nslots, const int PW) {
   // wave tile: MTW m-tiles of 32 tokens x JW column tiles (jt) x NB column halves (b).  NB == 1: the two
   // b halves of a packed word go to two different waves (per-group mode: every weight is re-quantised
   // by exactly one wave of the workgroup).
@@ -487,7 +487,7 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * (2 / NB) * 64) void 
   const int bsel = (wave % WN) % (2 / NB);  // which b half (NB == 1 only; 0 otherwise)
 
   // ---- XCD-aware tile order: block b runs on XCD b % 8; give each XCD a contiguous run of the
-  // panel-major tile sequence (panels of 4 strips x all m-tiles) so co-resident workgroups of one
+  // panel-major tile sequence (panels of PW strips x all m-tiles) so co-resident workgroups of one
   // XCD share weight strips / activation rows in that XCD's L2.  Speed only, never correctness.
   const int ntiles = tiles_m * tiles_n;
   int bid = blockIdx.x;
@@ -499,7 +499,6 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * (2 / NB) * 64) void 
   }
   int tile_m, tile_n;
   {
-    constexpr int PW = 4;
     const int full = (tiles_n / PW) * PW * tiles_m;
     if (lin < full) {
       const int panel = lin / (PW * tiles_m), within = lin % (PW * tiles_m);
@@ -1365,7 +1364,7 @@ static hipError_t launch_stream(const LaunchArgs& a, bool grouped, int mt, int w
 }
 
 template <int BM, int MTW, int JW, int NB, bool GROUPED, int NS>
-static hipError_t launch_tiled_t(const LaunchArgs& a, int ksplit, int nslots) {
+static hipError_t launch_tiled_t(const LaunchArgs& a, int ksplit, int nslots, int pw) {
   constexpr int WAVES = (BM / (32 * MTW)) * (4 / JW) * (2 / NB);
   constexpr int NT = WAVES * 64;
   constexpr int STAGE = 8 * 2048 + BM * 128 + ((NS > 0 && GROUPED) ? WAVES * 512 : 0);
@@ -1385,58 +1384,58 @@ static hipError_t launch_tiled_t(const LaunchArgs& a, int ksplit, int nslots) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + 255) / 256;
   dim3 grid(tiles_m * tiles_n, ksplit, 1);
   hipLaunchKernelGGL(kern, grid, dim3(NT), LDS, a.stream, a.A, a.B, a.C, a.D, a.s1, a.s2, a.s3,
-                     a.acc_out, a.bias, a.M, a.N, a.K, ksplit, tiles_m, tiles_n, a.tickets, nslots);
+                     a.acc_out, a.bias, a.M, a.N, a.K, ksplit, tiles_m, tiles_n, a.tickets, nslots, pw);
   return hipGetLastError();
 }
 
 // stages: 0 = register-staged; 2..4 = LDS-DMA ring depth (clamped to what fits in 160 KiB of LDS)
 template <bool GROUPED>
-static hipError_t launch_tiled_bm(const LaunchArgs& a, int bm, int stages, int ksplit, int nslots) {
+static hipError_t launch_tiled_bm(const LaunchArgs& a, int bm, int stages, int ksplit, int nslots, int pw) {
   switch (bm) {
     case 64:
-      if (stages == 0) return launch_tiled_t<64, 1, 2, 2, GROUPED, 0>(a, ksplit, nslots);
-      if (stages == 2) return launch_tiled_t<64, 1, 2, 2, GROUPED, 2>(a, ksplit, nslots);
-      if (stages == 3) return launch_tiled_t<64, 1, 2, 2, GROUPED, 3>(a, ksplit, nslots);
-      return launch_tiled_t<64, 1, 2, 2, GROUPED, 4>(a, ksplit, nslots);
+      if (stages == 0) return launch_tiled_t<64, 1, 2, 2, GROUPED, 0>(a, ksplit, nslots, pw);
+      if (stages == 2) return launch_tiled_t<64, 1, 2, 2, GROUPED, 2>(a, ksplit, nslots, pw);
+      if (stages == 3) return launch_tiled_t<64, 1, 2, 2, GROUPED, 3>(a, ksplit, nslots, pw);
+      return launch_tiled_t<64, 1, 2, 2, GROUPED, 4>(a, ksplit, nslots, pw);
     case 128:
-      if (stages == 0) return launch_tiled_t<128, 2, 2, 2, GROUPED, 0>(a, ksplit, nslots);
-      if (stages == 2) return launch_tiled_t<128, 2, 2, 2, GROUPED, 2>(a, ksplit, nslots);
-      if (stages == 3) return launch_tiled_t<128, 2, 2, 2, GROUPED, 3>(a, ksplit, nslots);
-      return launch_tiled_t<128, 2, 2, 2, GROUPED, 4>(a, ksplit, nslots);
+      if (stages == 0) return launch_tiled_t<128, 2, 2, 2, GROUPED, 0>(a, ksplit, nslots, pw);
+      if (stages == 2) return launch_tiled_t<128, 2, 2, 2, GROUPED, 2>(a, ksplit, nslots, pw);
+      if (stages == 3) return launch_tiled_t<128, 2, 2, 2, GROUPED, 3>(a, ksplit, nslots, pw);
+      return launch_tiled_t<128, 2, 2, 2, GROUPED, 4>(a, ksplit, nslots, pw);
     case 130:  // 128-row tile, 8 waves, each wave owns ONE (jt, b) column set over all 128 rows
-      if (stages == 0) return launch_tiled_t<128, 4, 1, 1, GROUPED, 0>(a, ksplit, nslots);
-      if (stages == 2) return launch_tiled_t<128, 4, 1, 1, GROUPED, 2>(a, ksplit, nslots);
-      if (stages == 3) return launch_tiled_t<128, 4, 1, 1, GROUPED, 3>(a, ksplit, nslots);
-      if (stages == 5) return launch_tiled_t<128, 4, 1, 1, GROUPED, 5>(a, ksplit, nslots);
-      return launch_tiled_t<128, 4, 1, 1, GROUPED, 4>(a, ksplit, nslots);
+      if (stages == 0) return launch_tiled_t<128, 4, 1, 1, GROUPED, 0>(a, ksplit, nslots, pw);
+      if (stages == 2) return launch_tiled_t<128, 4, 1, 1, GROUPED, 2>(a, ksplit, nslots, pw);
+      if (stages == 3) return launch_tiled_t<128, 4, 1, 1, GROUPED, 3>(a, ksplit, nslots, pw);
+      if (stages == 5) return launch_tiled_t<128, 4, 1, 1, GROUPED, 5>(a, ksplit, nslots, pw);
+      return launch_tiled_t<128, 4, 1, 1, GROUPED, 4>(a, ksplit, nslots, pw);
     case 131:  // 128-row tile, 8 waves as 2 (m) x 4 (jt): wave = 64 rows x one jt, both b
-      if (stages == 0) return launch_tiled_t<128, 2, 1, 2, GROUPED, 0>(a, ksplit, nslots);
-      if (stages == 2) return launch_tiled_t<128, 2, 1, 2, GROUPED, 2>(a, ksplit, nslots);
-      if (stages == 3) return launch_tiled_t<128, 2, 1, 2, GROUPED, 3>(a, ksplit, nslots);
-      if (stages == 5) return launch_tiled_t<128, 2, 1, 2, GROUPED, 5>(a, ksplit, nslots);
-      return launch_tiled_t<128, 2, 1, 2, GROUPED, 4>(a, ksplit, nslots);
+      if (stages == 0) return launch_tiled_t<128, 2, 1, 2, GROUPED, 0>(a, ksplit, nslots, pw);
+      if (stages == 2) return launch_tiled_t<128, 2, 1, 2, GROUPED, 2>(a, ksplit, nslots, pw);
+      if (stages == 3) return launch_tiled_t<128, 2, 1, 2, GROUPED, 3>(a, ksplit, nslots, pw);
+      if (stages == 5) return launch_tiled_t<128, 2, 1, 2, GROUPED, 5>(a, ksplit, nslots, pw);
+      return launch_tiled_t<128, 2, 1, 2, GROUPED, 4>(a, ksplit, nslots, pw);
     case 258:  // 256-row tile, 8 waves, each wave owns ONE (jt, b) column set over all 256 rows
-      if (stages == 0) return launch_tiled_t<256, 8, 1, 1, GROUPED, 0>(a, ksplit, nslots);
-      if (stages == 2) return launch_tiled_t<256, 8, 1, 1, GROUPED, 2>(a, ksplit, nslots);
-      if (stages == 5) return launch_tiled_t<256, 8, 1, 1, GROUPED, 5>(a, ksplit, nslots);
-      return launch_tiled_t<256, 8, 1, 1, GROUPED, 3>(a, ksplit, nslots);
+      if (stages == 0) return launch_tiled_t<256, 8, 1, 1, GROUPED, 0>(a, ksplit, nslots, pw);
+      if (stages == 2) return launch_tiled_t<256, 8, 1, 1, GROUPED, 2>(a, ksplit, nslots, pw);
+      if (stages == 5) return launch_tiled_t<256, 8, 1, 1, GROUPED, 5>(a, ksplit, nslots, pw);
+      return launch_tiled_t<256, 8, 1, 1, GROUPED, 3>(a, ksplit, nslots, pw);
     case 259:  // 256-row tile, 8 waves as 2 (m) x 4 (jt): wave = 128 rows x one jt, both b
-      if (stages == 0) return launch_tiled_t<256, 4, 1, 2, GROUPED, 0>(a, ksplit, nslots);
-      if (stages == 2) return launch_tiled_t<256, 4, 1, 2, GROUPED, 2>(a, ksplit, nslots);
-      if (stages == 5) return launch_tiled_t<256, 4, 1, 2, GROUPED, 5>(a, ksplit, nslots);
-      return launch_tiled_t<256, 4, 1, 2, GROUPED, 3>(a, ksplit, nslots);
+      if (stages == 0) return launch_tiled_t<256, 4, 1, 2, GROUPED, 0>(a, ksplit, nslots, pw);
+      if (stages == 2) return launch_tiled_t<256, 4, 1, 2, GROUPED, 2>(a, ksplit, nslots, pw);
+      if (stages == 5) return launch_tiled_t<256, 4, 1, 2, GROUPED, 5>(a, ksplit, nslots, pw);
+      return launch_tiled_t<256, 4, 1, 2, GROUPED, 3>(a, ksplit, nslots, pw);
     default:
-      if (stages == 0) return launch_tiled_t<256, 2, 2, 2, GROUPED, 0>(a, ksplit, nslots);
-      if (stages == 2) return launch_tiled_t<256, 2, 2, 2, GROUPED, 2>(a, ksplit, nslots);
-      if (stages == 5) return launch_tiled_t<256, 2, 2, 2, GROUPED, 5>(a, ksplit, nslots);
-      if (stages == 6) return launch_tiled_t<256, 2, 2, 2, GROUPED, 6>(a, ksplit, nslots);
-      return launch_tiled_t<256, 2, 2, 2, GROUPED, 3>(a, ksplit, nslots);
+      if (stages == 0) return launch_tiled_t<256, 2, 2, 2, GROUPED, 0>(a, ksplit, nslots, pw);
+      if (stages == 2) return launch_tiled_t<256, 2, 2, 2, GROUPED, 2>(a, ksplit, nslots, pw);
+      if (stages == 5) return launch_tiled_t<256, 2, 2, 2, GROUPED, 5>(a, ksplit, nslots, pw);
+      if (stages == 6) return launch_tiled_t<256, 2, 2, 2, GROUPED, 6>(a, ksplit, nslots, pw);
+      return launch_tiled_t<256, 2, 2, 2, GROUPED, 3>(a, ksplit, nslots, pw);
   }
 }
 
-static hipError_t launch_tiled(const LaunchArgs& a, bool grouped, int bm, int stages, int ksplit, int nslots) {
-  return grouped ? launch_tiled_bm<true>(a, bm, stages, ksplit, nslots)
-                 : launch_tiled_bm<false>(a, bm, stages, ksplit, nslots);
+static hipError_t launch_tiled(const LaunchArgs& a, bool grouped, int bm, int stages, int ksplit, int nslots, int pw) {
+  return grouped ? launch_tiled_bm<true>(a, bm, stages, ksplit, nslots, pw)
+                 : launch_tiled_bm<false>(a, bm, stages, ksplit, nslots, pw);
 }
 
 static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -1448,7 +1447,7 @@ struct Plan {
   int ksplit;
   int fused;   // stream: 1 / 3 in-launch, 2 separate reduce.  tiled: 1 in-launch slots, 2 slabs + reduce
   int mt, waves, pf;      // stream
-  int bm, stages, nslots; // tiled
+  int bm, stages, nslots, pw; // tiled
 };
 
 static Plan make_plan(const int M, const int N, const int K, const bool grouped, const int max_par,
@@ -1575,6 +1574,10 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
   if (ksplit < 1) ksplit = 1;
   pl.bm = bm;
   pl.stages = stages;
+  // Tile order: an XCD runs 32 workgroups at a time = (32 / PW) m-tiles x PW weight strips.  Per 128-k block a
+  // strip costs 16 KB of L2 fill and an m-tile rows/2 KB, so 4 x 8 is the cheapest split for 256- and 128-row
+  // tiles (measured M=4096: L2 miss traffic 892 -> 714 MB per launch, profiles/r01_hbm_traffic.txt), 8 x 4 for 64 rows.
+  pl.pw = (t.pw == 4 || t.pw == 8 || t.pw == 16 || t.pw == 32) ? t.pw : (bm == 64 ? 4 : 8);
   pl.ksplit = ksplit;
   pl.nslots = ksplit > 1 ? nslots : 0;
   pl.fused = pl.nslots > 0 ? 1 : 2;
@@ -1602,7 +1605,8 @@ extern "C" int qqq_w4a8_plan(int prob_m, int prob_n, int prob_k, int groupsize, 
   plan_out->bm = pl.bm;
   plan_out->stages = pl.stages;
   plan_out->glds = pl.kernel == 2 ? (pl.stages == 0 ? 2 : 1) : 0;
-  plan_out->reserved[0] = pl.nslots;
+  plan_out->nslots = pl.nslots;
+  plan_out->pw = pl.pw;
   return QQQ_OK;
 }
 
@@ -1652,7 +1656,7 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
     if (e != hipSuccess) return fail_hip(e, "qqq_stream_kernel launch");
     reduce_launch = pl.ksplit > 1 && pl.fused != 1 && pl.fused != 3;
   } else {
-    e = launch_tiled(a, grouped, pl.bm, pl.stages, pl.ksplit, pl.nslots);
+    e = launch_tiled(a, grouped, pl.bm, pl.stages, pl.ksplit, pl.nslots, pl.pw);
     if (e != hipSuccess) return fail_hip(e, "qqq_tiled_kernel launch");
     reduce_launch = pl.ksplit > 1 && pl.nslots == 0;
   }
