@@ -589,7 +589,9 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * (2 / NB) * 64) void 
 
   v4u wreg[WPT], xreg[XPT];  // register staging (unused with GLDS)
 
-  auto issue_loads = [&](const int kb, const int buf) {
+  // part / nparts: issue only the part-th of nparts contiguous groups of this thread's DMA instructions
+  // (compile-time constants at every call site); the default issues the whole stage.
+  auto issue_loads = [&](const int kb, const int buf, const int part = 0, const int nparts = 1) {
     const unsigned char* wb = B + (size_t)(kb * 8) * rowbytes;
     const unsigned char* xb = Abase + (size_t)kb * 128;
 #if defined(QQQ_ABLATE) && (QQQ_ABLATE & 2)  // ablation: no global->LDS traffic
@@ -597,10 +599,14 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * (2 / NB) * 64) void 
 #endif
     if constexpr (GLDS) {
       const unsigned st = lds_base + buf * STAGE + wave * 1024;
+      const int lo = (WPT + XPT) * part / nparts, hi = (WPT + XPT) * (part + 1) / nparts;
 #pragma unroll
-      for (int i = 0; i < WPT; ++i) glds16(wb + wsrc[i], st + i * (NT * 16));
+      for (int i = 0; i < WPT; ++i)
+        if (i >= lo && i < hi) glds16(wb + wsrc[i], st + i * (NT * 16));
 #pragma unroll
-      for (int i = 0; i < XPT; ++i) glds16(xb + xsrc[i], st + W_BYTES + i * (NT * 16));
+      for (int i = 0; i < XPT; ++i)
+        if (WPT + i >= lo && WPT + i < hi) glds16(xb + xsrc[i], st + W_BYTES + i * (NT * 16));
+      if (part != nparts - 1) return;
       if constexpr (GROUPED) {
         // this wave's private copy of the tile's 256 group scales (512 B): lanes 0..31, 16 B each
         const unsigned scdst =
@@ -773,6 +779,21 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * (2 / NB) * 64) void 
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NL > 63 ? 63 : 3 * NL) : "memory");
       }
     };
+#ifdef QQQ_TRACE
+    int tr_n = 0;
+    auto stamp = [&](int tag) {
+      if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && C && tr_n < 400) {  // C is idle when ksplit == 1
+        const unsigned long long tm = __builtin_readcyclecounter();
+        C[(wave * 400 + tr_n) * 4 + 0] = tag;
+        C[(wave * 400 + tr_n) * 4 + 1] = (int)(tm & 0xffffffffu);
+        C[(wave * 400 + tr_n) * 4 + 2] = (int)(tm >> 32);
+        ++tr_n;
+      }
+    };
+#define QQQ_STAMP(x) stamp(x)
+#else
+#define QQQ_STAMP(x)
+#endif
     const int nkb = kb_end - kb_begin;
     if constexpr (CONTPIPE) {
       // ---- continuous fragment pipeline over a 3-stage DMA ring.
@@ -839,12 +860,25 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * (2 / NB) * 64) void 
         const unsigned char* stn = has_next ? smem + ((i + 1) % 3) * STAGE : st;  // redirect past-the-end reads
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
+          QQQ_STAMP(0 + t);
           if (t == 2) {
             if (has_next) {
               wait_younger(0);  // this wave's DMA of stage i+1 (the only one in flight) has landed
+              QQQ_STAMP(10);
               __syncthreads();  // ... and everybody else's
+              QQQ_STAMP(11);
             }
-            if (i + 2 < nkb) issue_loads(kb_begin + i + 2, (i + 2) % 3);
+            QQQ_STAMP(12);
+          }
+          {
+            // DMA issue of a stage spread over the 3 k-steps behind the barrier (2 of the wave's 6 instructions
+            // each): a burst of all 8 waves x 6 KB right behind the barrier overruns the address pipe (~30
+            // cycles per 1 KB instruction, measured with QQQ_TRACE), and an in-order wave stuck in VMEM issue
+            // cannot issue its MFMAs either.  -3 % cycles, 1-3 % time on real data.
+            constexpr int SPREAD = 3;
+            const int part = (t + 2) & 3;  // t=2 -> 0, t=3 -> 1, t=0 -> 2, t=1 -> 3
+            const int stg = (t >= 2) ? i + 2 : i + 1;
+            if (part < SPREAD && stg < nkb && stg >= 2) issue_loads(kb_begin + stg, stg % 3, part, SPREAD);
           }
           __builtin_amdgcn_sched_barrier(0);
           // fragment reads: W two steps ahead, X one step ahead
@@ -853,6 +887,7 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * (2 / NB) * 64) void 
           if constexpr (GROUPED)
             if (t == 3) sc_cur = *reinterpret_cast<const hsc*>(stn + scrd);  // scales of the block being unpacked
           __builtin_amdgcn_sched_barrier(0);
+          QQQ_STAMP(20 + t);
           // hand-interleaved issue order: one MFMA of step u, then the unpack of one packed word of step
           // u+1 (hipcc otherwise issues the 8 MFMAs back to back and leaves the VALU work uncovered)
           constexpr int NM = MTW * JW * NB;  // MFMAs per step
@@ -930,21 +965,6 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * (2 / NB) * 64) void 
       };
       Frag fr[2] = {};
       Ops ops;
-#ifdef QQQ_TRACE
-      int tr_n = 0;
-      auto stamp = [&](int tag) {
-        if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && C && tr_n < 400) {  // C is idle when ksplit == 1
-          const unsigned long long tm = __builtin_readcyclecounter();
-          C[(wave * 400 + tr_n) * 4 + 0] = tag;
-          C[(wave * 400 + tr_n) * 4 + 1] = (int)(tm & 0xffffffffu);
-          C[(wave * 400 + tr_n) * 4 + 2] = (int)(tm >> 32);
-          ++tr_n;
-        }
-      };
-#define QQQ_STAMP(x) stamp(x)
-#else
-#define QQQ_STAMP(x)
-#endif
       if (nkb > 0) {
         issue_loads(kb_begin, 0);
         if (nkb > 1) issue_loads(kb_begin + 1, 1);
