@@ -54,22 +54,48 @@ def algorithmic_ops(M, N, K):
     return 2 * M * N * K
 
 
-def make_weights(dev, grouped, nbuf, seed=0, N=N_FULL, K=K_FULL):
+def make_weights(dev, grouped, nbuf, seed=0, N=N_FULL, K=K_FULL, dist=None):
+    """`nbuf` independent packed weight buffers + the scales of buffer 0.
+    dist "gptq" (default): W ~ N(0, 0.02^2) fp16 [N,K] quantised the way the reference's GPTQ
+    flow does it -- per-channel scale = max_k|W|/7, w4 = clamp(round(W/scale), -7, 7), s_channel = scale/16
+    (qlinear_marlin.py:222-226); per-group scale_g = 2 max|W_g|/15, u = clamp(round(W/scale_g)+8, 0, 15),
+    s_extra = max_k|W_fq|/127, s_group = half(scale_g/s_extra), s_channel = s_extra (gptq.py:204-216,
+    qlinear_marlin.py:209-219).  dist "uniform": uniformly random nibbles (worst case for MFMA toggling power)."""
     from qqq_amd import pack as P
 
+    dist = dist or os.environ.get("QQQ_BENCH_WEIGHTS", "gptq")
     g = torch.Generator(device=dev).manual_seed(seed)
-    Bs = []
+    Bs, s2, s3 = [], None, None
     for i in range(nbuf):
-        if grouped:
-            codes = torch.randint(0, 16, (K, N), generator=g, dtype=torch.int8, device=dev)
+        if dist == "uniform":
+            if grouped:
+                codes = torch.randint(0, 16, (K, N), generator=g, dtype=torch.int8, device=dev)
+            else:
+                codes = torch.randint(-7, 8, (K, N), generator=g, dtype=torch.int8, device=dev)
+            if i == 0:
+                s2 = (torch.rand((1, N), generator=g, device=dev) * 2e-4 + 1e-5).to(torch.float32)
+                if grouped:
+                    s3 = (torch.rand((K // 128, N), generator=g, device=dev) * 15.0 + 0.5).to(torch.float16)
         else:
-            codes = torch.randint(-7, 8, (K, N), generator=g, dtype=torch.int8, device=dev)
+            W = (torch.randn((N, K), generator=g, device=dev, dtype=torch.float32) * 0.02).half().float()
+            if grouped:
+                Wg = W.view(N, K // 128, 128)
+                scale_g = 2.0 * Wg.abs().amax(dim=2) / 15.0  # [N, G]
+                u = torch.clamp(torch.round(Wg / scale_g[..., None]) + 8, 0, 15)
+                if i == 0:
+                    s_extra = ((u - 8) * scale_g[..., None]).abs().amax(dim=(1, 2)) / 127.0  # [N]
+                    s3 = (scale_g / s_extra[:, None]).t().contiguous().to(torch.float16)
+                    s2 = s_extra[None, :].contiguous().to(torch.float32)
+                codes = u.view(N, K).t().contiguous().to(torch.int8)
+                del Wg, u, scale_g
+            else:
+                scale = W.abs().amax(dim=1, keepdim=True) / 7.0
+                codes = torch.clamp(torch.round(W / scale), -7, 7).t().contiguous().to(torch.int8)
+                if i == 0:
+                    s2 = (scale.t() / 16.0).contiguous().to(torch.float32)
+            del W
         Bs.append(P.pack_codes(codes, grouped))
         del codes
-    s2 = (torch.rand((1, N), generator=g, device=dev) * 2e-4 + 1e-5).to(torch.float32)
-    s3 = None
-    if grouped:
-        s3 = (torch.rand((K // 128, N), generator=g, device=dev) * 15.0 + 0.5).to(torch.float16)
     return Bs, s2, s3
 
 
@@ -343,7 +369,10 @@ def main():
         "scaling": "strong", "vs_baseline": None, "dtype": "i8 x i4 -> i32 -> f16", "data": "synthetic",
         "config": {
             "workload": "qqq_gemm per-channel sweep M in {1,16,128,1024,4096}, N=8192, K=21760 (BASELINE configs[1]); one step = the 5 calls",
-            "weights": f"{NBUF} rotating packed-int4 buffers of 89 MB (cold Infinity Cache)",
+            "weights": f"{NBUF} rotating packed-int4 buffers of 89 MB (cold Infinity Cache); "
+                       + ("W ~ N(0, 0.02^2) quantised GPTQ-style (SURVEY 8d)" if os.environ.get("QQQ_BENCH_WEIGHTS", "gptq") != "uniform"
+                          else "uniformly random int4 codes"),
+            "tokens": "x ~ N(0,1) fp16 through the fused dynamic int8 quantiser",
             "launch": "hipGraph replay" if graph is not None else "eager",
             "parallelism": "single GPU" if world == 1 else f"M-sharded over {world} GPUs + RCCL all-gather of fp16 shards (points with M >= {64*world})",
         },
