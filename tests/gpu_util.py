@@ -63,6 +63,10 @@ def variants(M, K, N):
     if M <= 16:
         v += [dict(kernel=1, ksplit=1, waves=16)]
     v += [dict(kernel=1)]  # auto split
+    if N % 64 == 0:  # column kernel (decode): 32 columns x all of K per workgroup
+        v += [dict(kernel=3), dict(kernel=3, mt=1, pf=4), dict(kernel=3, mt=2, pf=4), dict(kernel=3, mt=1, pf=12, ksplit=2)]
+        if K // 64 >= 3:
+            v += [dict(kernel=3, mt=2, pf=8, ksplit=3), dict(kernel=3, mt=1, pf=2), dict(kernel=3, mt=1, pf=6)]
     if K % 128 == 0:
         for bm in (64, 128, 256):
             v.append(dict(kernel=2, bm=bm, glds=2, ksplit=1))

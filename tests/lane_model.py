@@ -1,7 +1,7 @@
 """Lane-level numpy model of the two HIP kernels' data movement (tests only).
 
 It mirrors, formula by formula, the address arithmetic of qqq_amd/csrc/qqq_w4a8.hip
-(`qqq_stream_kernel`, `qqq_tiled_kernel`): which bytes each lane loads, how the LDS image is
+(`qqq_stream_kernel`, `qqq_column_kernel`, `qqq_tiled_kernel`): which bytes each lane loads, how the LDS image is
 swizzled, which MFMA operand slot they land in, and where each accumulator register is stored.
 The MFMA lane maps assumed here (and checked on the device by tests/test_gpu_probe.py):
 
@@ -132,6 +132,74 @@ def stream_kernel_model(A, B, s3, M, N, K, MT, WAVES, ksplit, grouped):
                     n = strip * 128 + 64 * (qd >> 1) + 16 * jt + 8 * b + 4 * (qd & 1)
                     if m < M and n < N:
                         out[m, n : n + 4] += red[q * 4 : q * 4 + 4, ln]
+    return out
+
+
+def _quad_perm(v, perm):
+    """DPP quad_perm: lane l reads lane (l & ~3) + perm[l & 3]."""
+    l = np.arange(64)
+    return v[(l & ~3) + np.asarray(perm)[l & 3]]
+
+
+def column_kernel_model(A, B, s3, M, N, K, MT, WAVES, ksplit, grouped):
+    """qqq_column_kernel: 16-byte weight loads by lane (h, c', kq), 4x4 register/lane transpose in two
+    DPP butterfly stages, MFMA row i = 4*c' + jt, D lane -> (c' = lane >> 4, jt = register)."""
+    Bb = np.ascontiguousarray(B).view(np.uint8).reshape(-1)
+    Ab = np.ascontiguousarray(A).view(np.uint8).reshape(-1)
+    s3h = None if not grouped else np.ascontiguousarray(s3).reshape(-1)
+    rowbytes = N * 8
+    KS = K >> 6
+    lane = np.arange(64)
+    h, cq, q4 = lane >> 4, (lane >> 2) & 3, lane & 3
+    odd, hi = (lane & 1) != 0, (lane & 2) != 0
+    out = np.zeros((M, N), np.int64)
+    mblocks = (M + 16 * MT - 1) // (16 * MT)
+    for mb in range(mblocks):
+        mbase = mb * 16 * MT
+        for wg in range(N // 32):
+            ng, half = wg >> 1, wg & 1
+            bptr = h * rowbytes + ng * 512 + (4 * half + cq) * 64 + q4 * 16
+            for sp in range(ksplit):
+                ks_begin = (KS * sp) // ksplit
+                ks_end = (KS * (sp + 1)) // ksplit
+                red = np.zeros((MT * 2 * 4, 64), np.int64)
+                for wave in range(WAVES):
+                    acc = np.zeros((MT, 2, 64, 4), np.int64)
+                    for s in range(ks_begin + wave, ks_end, WAVES):
+                        src = bptr + 4 * s * rowbytes
+                        w = Bb[src[:, None] + np.arange(16)[None, :]].reshape(64, 4, 4)
+                        w = (w.astype(np.uint32) << (8 * np.arange(4, dtype=np.uint32))).sum(-1).astype(np.uint32)  # [lane, e]
+                        z = np.zeros_like(w)
+                        y = np.zeros_like(w)
+                        for e in range(4):
+                            t = _quad_perm(w[:, e ^ 1], [1, 0, 3, 2])
+                            z[:, e] = np.where(odd == bool(e & 1), w[:, e], t)
+                        for e in range(4):
+                            t = _quad_perm(z[:, e ^ 2], [2, 3, 0, 1])
+                            y[:, e] = np.where(hi == bool(e & 2), z[:, e], t)
+                        if grouped:
+                            so = ng * 64 + (4 * half + cq) * 8 + 2 * q4 + (s >> 1) * N
+                            w0, w1 = unpack_pair(y, True, s3h[so][:, None], s3h[so + 1][:, None])
+                        else:
+                            w0, w1 = unpack_pair(y, False)
+                        a0, a1 = _bytes_to_i8(w0), _bytes_to_i8(w1)
+                        for mt in range(MT):
+                            row = np.minimum(mbase + 16 * mt + (lane & 15), M - 1)
+                            xo = row * K + 16 * h + 64 * s
+                            x = Ab[xo[:, None] + np.arange(16)[None, :]].view(np.int8)
+                            acc[mt, 0] += mfma_16x16x64(a0, x)
+                            acc[mt, 1] += mfma_16x16x64(a1, x)
+                    for mt in range(MT):
+                        for b in range(2):
+                            for r in range(4):
+                                red[(mt * 2 + b) * 4 + r] += acc[mt, b, :, r]
+                for it in range(MT * 2 * 64):
+                    q, jt, tok = it >> 6, (it >> 4) & 3, it & 15
+                    mt, b = q >> 1, q & 1
+                    m = mbase + 16 * mt + tok
+                    n = 64 * ng + 16 * jt + 8 * b + 4 * half
+                    if m < M:
+                        out[m, n : n + 4] += red[q * 4 + jt, tok + 16 * np.arange(4)]
     return out
 
 

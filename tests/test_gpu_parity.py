@@ -117,7 +117,7 @@ def test_random_shapes_against_oracle(dev):
             s2 = (rng.random((1, N), dtype=np.float32) * 2e-4 + 1e-5)
             eD, eacc = C.qqq_gemm(A, B, s1, s2, s3 if grouped else None, return_acc=True)
             h = GemmHarness(B, s2, s3, dev)
-            tunes = [None, dict(kernel=1), dict(kernel=1, ksplit=2, fused=1)]
+            tunes = [None, dict(kernel=1), dict(kernel=1, ksplit=2, fused=1), dict(kernel=3), dict(kernel=3, mt=2, ksplit=2)]
             if K % 128 == 0:
                 tunes += [dict(kernel=2), dict(kernel=2, bm=64, glds=1, stages=3), dict(kernel=2, bm=130, glds=1, stages=5),
                           dict(kernel=2, bm=258, glds=1, stages=3, ksplit=2)]

@@ -30,6 +30,14 @@ def test_stream_kernel_model(grouped):
 
 
 @pytest.mark.parametrize("grouped", [False, True])
+def test_column_kernel_model(grouped):
+    rng = np.random.default_rng(13)
+    A, B, s3, acc = _case(rng, 20, 192, 384, grouped)  # ragged m (2 m-blocks at MT=1), odd number of 64-k steps
+    assert np.array_equal(LM.column_kernel_model(A, B, s3, 20, 192, 384, MT=1, WAVES=4, ksplit=1, grouped=grouped), acc)
+    assert np.array_equal(LM.column_kernel_model(A, B, s3, 20, 192, 384, MT=2, WAVES=8, ksplit=2, grouped=grouped), acc)
+
+
+@pytest.mark.parametrize("grouped", [False, True])
 def test_tiled_kernel_model(grouped):
     rng = np.random.default_rng(12)
     A, B, s3, acc = _case(rng, 70, 320, 256, grouped)  # N % 256 == 64 edge, ragged m
