@@ -17,7 +17,7 @@ scaling: the total work is fixed.
 
 Extra objects on the JSON line: `roofline` (dominant kernel = the tiled MFMA kernel at M=4096, durations
 from HIP event pairs recorded on the launch stream inside this process), `roofline_hbm` (the HBM-bound
-stream kernel at M=16), `cpu_baseline` (the C oracle timed on the host cores, bounded sample) and
+decode kernel at M=1), `cpu_baseline` (the C oracle timed on the host cores, bounded sample) and
 `per_m` (per sweep point: us, TOPS, GB/s, speedup vs torch fp16 GEMM on the same GPU).
 """
 from __future__ import annotations
@@ -406,13 +406,13 @@ def main():
             "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/hbm_traffic.json)",
             "algorithmic_bytes": algorithmic_bytes(4096, N_FULL, K_FULL), "avg_launch_us": a["us"],
         }
-        h = per_m["16"]
+        h = per_m["1"]
         result["roofline_hbm"] = {
-            "kernel": "qqq_stream_kernel (M=16)", "bound": "hbm", "achieved": h["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
-            "frac": h["gbs"] / PEAK_HBM_GBS, "traffic": measured_traffic("qqq_stream_kernel_M16"),
+            "kernel": "qqq_column_kernel (M=1, decode)", "bound": "hbm", "achieved": h["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": h["gbs"] / PEAK_HBM_GBS, "traffic": measured_traffic("qqq_column_kernel_M1"),
             "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/hbm_traffic.json)",
-            "algorithmic_bytes": algorithmic_bytes(16, N_FULL, K_FULL), "avg_launch_us": h["us"],
-            "note": "whole qqq_gemm call (stream kernel + split-K reduce launch); the stream kernel alone averages 17 us = 5.3 TB/s (profiles/r01_bench_kernel_stats.csv)",
+            "algorithmic_bytes": algorithmic_bytes(1, N_FULL, K_FULL), "avg_launch_us": h["us"],
+            "note": "one launch per call (no split-K); the figure is the whole call incl. launch latency, cold Infinity Cache",
         }
         # per-group (BASELINE configs[2]) detail
         try:
