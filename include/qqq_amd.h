@@ -123,6 +123,13 @@ int qqq_probe_mfma(int kind, const void* a, const void* b, void* out, int dev, v
 /* copies 64 x 16 B through LDS with global_load_lds; lane l reads src chunk perm[l] */
 int qqq_probe_glds(const void* src, const void* perm, void* dst, int dev, void* stream);
 
+/* Read-bandwidth probe (tools/probe_fill.py): `nwg` workgroups of 512 threads each stream `bytes_per_wg` bytes
+ * `reps` times from src + wg_stride * workgroup (wg_stride 0: a shared L2-resident window = per-CU L2->L1 fill rate;
+ * wg_stride == bytes_per_wg: disjoint windows = HBM streaming); `unroll` 2 or 8 independent 16-byte loads per thread.
+ * Writes the duration of one launch in milliseconds to ms_out (host memory). */
+int qqq_probe_fill(const void* src, size_t wg_stride, size_t bytes_per_wg, int nwg, int reps, int unroll, void* sink,
+                   int dev, void* stream, float* ms_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,6 +50,8 @@ def lib():
     L.qqq_probe_mfma.restype = ci
     L.qqq_probe_glds.argtypes = [vp, vp, vp, ci, vp]
     L.qqq_probe_glds.restype = ci
+    L.qqq_probe_fill.argtypes = [vp, ctypes.c_size_t, ctypes.c_size_t, ci, ci, ci, vp, ci, vp, ctypes.POINTER(ctypes.c_float)]
+    L.qqq_probe_fill.restype = ci
     L.qqq_bench_gemm.argtypes = [vp, ctypes.POINTER(vp), ci, vp, vp, vp, vp, vp, ci, ci, ci, vp, ci, ci, vp, ci,
                                  ctypes.POINTER(QQQTune), ci, ctypes.POINTER(ctypes.c_float)]
     L.qqq_bench_gemm.restype = ci

@@ -1428,6 +1428,28 @@ __global__ void qqq_probe_mfma32_kernel(const v4i* a, const v4i* b, v16i* out) {
   acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[l], b[l], acc, 0, 0, 0);
   out[l] = acc;
 }
+// Read-bandwidth probe: every workgroup (512 threads, UNR independent 16-byte loads in flight per thread) streams
+// `bytes_per_wg` bytes starting at src + wg_stride * blockIdx.x, `reps` times, and folds them into one word.
+// wg_stride == 0: all workgroups read the same L2-resident window (per-CU L2 -> L1 fill rate);
+// wg_stride == bytes_per_wg: disjoint windows (HBM / Infinity-Cache streaming rate).
+template <int UNR>
+__global__ __launch_bounds__(512) void qqq_probe_fill_kernel(const v4u* __restrict__ src, const size_t wg_stride,
+                                                             const size_t bytes_per_wg, const int reps,
+                                                             unsigned* __restrict__ sink) {
+  const v4u* p = reinterpret_cast<const v4u*>(reinterpret_cast<const unsigned char*>(src) + wg_stride * blockIdx.x);
+  const size_t nvec = bytes_per_wg / 16;
+  v4u acc = {0, 0, 0, 0};
+  for (int r = 0; r < reps; ++r)
+    for (size_t i = threadIdx.x; i + (UNR - 1) * 512 < nvec; i += UNR * 512) {
+      v4u v[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) v[u] = p[i + u * 512];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) acc ^= v[u];
+    }
+  if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345u) sink[0] = 1;  // keep the loads alive
+}
+
 __global__ void qqq_probe_glds_kernel(const v4u* src, const int* perm, v4u* dst) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2048];
   const int l = threadIdx.x;
@@ -1997,6 +2019,32 @@ extern "C" int qqq_probe_mfma(int kind, const void* a, const void* b, void* out,
     return QQQ_ERR_ARG;
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail_hip(e, "probe launch");
+  return QQQ_OK;
+}
+
+extern "C" int qqq_probe_fill(const void* src, size_t wg_stride, size_t bytes_per_wg, int nwg, int reps, int unroll,
+                              void* sink, int dev, void* stream, float* ms_out) {
+  DeviceGuard guard(dev);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail_hip(hipGetLastError(), "event");
+  auto launch = [&]() {
+    if (unroll >= 8)
+      hipLaunchKernelGGL(qqq_probe_fill_kernel<8>, dim3(nwg), dim3(512), 0, st, static_cast<const v4u*>(src), wg_stride,
+                         bytes_per_wg, reps, static_cast<unsigned*>(sink));
+    else
+      hipLaunchKernelGGL(qqq_probe_fill_kernel<2>, dim3(nwg), dim3(512), 0, st, static_cast<const v4u*>(src), wg_stride,
+                         bytes_per_wg, reps, static_cast<unsigned*>(sink));
+  };
+  launch();  // warm-up
+  (void)hipEventRecord(e0, st);
+  launch();
+  (void)hipEventRecord(e1, st);
+  hipError_t e = hipStreamSynchronize(st);
+  if (e == hipSuccess) e = hipEventElapsedTime(ms_out, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (e != hipSuccess) return fail_hip(e, "qqq_probe_fill");
   return QQQ_OK;
 }
 
