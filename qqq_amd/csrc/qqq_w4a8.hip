@@ -1712,7 +1712,7 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
     // measured (profiles/r01_tune_decode.txt): every column workgroup re-reads the m x K activations, so beyond
     // m = 8 it only wins while that stays small; very wide layers at m > 8 are better off with strips
     const bool column = column_ok && M <= 16 && N / 32 >= 64 &&
-                        (M <= 8 || ((long long)M * K <= 262144 && N / 32 <= 512));
+                        (M <= 8 || ((long long)M * K <= (grouped ? 524288 : 262144) && N / 32 <= 512));
     if (column) kernel = 3;
     else kernel = (M <= 128 || (K % 128) != 0) ? 1 : 2;
   }
