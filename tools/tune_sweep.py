@@ -27,6 +27,9 @@ def variants(M, grouped, N=8192):
                         continue
                     for fused in ((1, 2) if ks > 1 else (1,)):
                         v.append(dict(kernel=1, waves=waves, ksplit=ks, fused=fused, pf=pf))
+    if M <= 32 and N % 64 == 0:
+        for pf in (2, 3, 4, 6, 8):
+            v.append(dict(kernel=3, pf=pf, ksplit=1))
     if M >= 16:
         for bm in (64, 128, 131, 130, 256, 258, 259):
             rows = 256 if bm >= 256 else (128 if bm >= 128 else 64)
