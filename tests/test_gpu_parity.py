@@ -215,6 +215,12 @@ def test_baseline_sizes_against_oracle(grouped, dev):
     for lo in (0, 2048, 4096 - 16):
         Ds, accs = h.run(A[lo : lo + 16].numpy(), s1[lo : lo + 16].numpy(), dict(kernel=1))
         assert np.array_equal(accs, acc[lo : lo + 16]) and np.array_equal(Ds.view(np.uint16), D[lo : lo + 16].view(np.uint16))
+    # property: the decode (column) kernel and the stream kernel agree bit-for-bit at full size, any m <= 16
+    A, s1, D, acc = ref_rows[16]
+    for m in (1, 5, 16):
+        for tune in (dict(kernel=3), dict(kernel=3, pf=8, ksplit=2), dict(kernel=1)):
+            Dm, accm = h.run(A[:m].numpy(), s1[:m].numpy(), tune)
+            assert np.array_equal(accm, acc[:m]) and np.array_equal(Dm.view(np.uint16), D[:m].view(np.uint16)), (m, tune)
     # property: token order does not matter (rows independent) -- permute the M=128 batch
     A, s1, D, acc = ref_rows[128]
     perm = np.random.default_rng(3).permutation(128)
