@@ -1358,16 +1358,21 @@ __global__ __launch_bounds__(256) void qqq_dynamic_quant_kernel(const _Float16* 
   const int nvec = K >> 3;
   const h8* xr = reinterpret_cast<const h8*>(x + (size_t)row * K);
   h8 v[VPT];
-  float amax = 0.f;
+  // |x| max in packed fp16 (max is exact in any precision): clear the sign bits, v_pk_max_f16
+  typedef unsigned u4v __attribute__((ext_vector_type(4)));
+  h2 amax2 = {(_Float16)0, (_Float16)0};
 #pragma unroll
   for (int i = 0; i < VPT; ++i) {
     const int idx = tid + i * 256;
     if (idx < nvec) {
       v[i] = xr[idx];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf((float)v[i][e]));
+      const u4v bits = __builtin_bit_cast(u4v, v[i]);
+      const h2 m0 = __builtin_elementwise_max(__builtin_bit_cast(h2, bits.x & 0x7fff7fffu), __builtin_bit_cast(h2, bits.y & 0x7fff7fffu));
+      const h2 m1 = __builtin_elementwise_max(__builtin_bit_cast(h2, bits.z & 0x7fff7fffu), __builtin_bit_cast(h2, bits.w & 0x7fff7fffu));
+      amax2 = __builtin_elementwise_max(amax2, __builtin_elementwise_max(m0, m1));
     }
   }
+  float amax = fmaxf((float)amax2[0], (float)amax2[1]);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
   if ((tid & 63) == 0) wmax[tid >> 6] = amax;
@@ -1376,19 +1381,32 @@ __global__ __launch_bounds__(256) void qqq_dynamic_quant_kernel(const _Float16* 
   // torch on GPU lowers `.div(127.0)` to a multiply by the fp32 reciprocal; result kept in fp16
   const float scale = (float)(_Float16)__fmul_rn(amax, 1.0f / 127.0f);
   if (tid == 0) s1[row] = scale;
+  // x / scale must be the correctly rounded fp32 quotient before rint() (torch semantics).  An IEEE division costs
+  // ~12 VALU ops per element and made this kernel compute-bound; rint(x * (1/scale)) equals rint(x / scale) unless
+  // the product lies within ~1e-4 of a half-integer (|q| <= 128 and the reciprocal-multiply is good to a few ulp),
+  // so only vectors with such an element (a few per thousand) take the exact division.
+  const float rinv = (scale > 0.f) ? __frcp_rn(scale) : 0.f;  // all-zero row: reference gives NaN -> int8 (UB); we emit 0
   int2* qr = reinterpret_cast<int2*>(xq + (size_t)row * K);
 #pragma unroll
   for (int i = 0; i < VPT; ++i) {
     const int idx = tid + i * 256;
     if (idx < nvec) {
+      float q[8];
+      bool near_tie = false;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float p = (float)v[i][e] * rinv;
+        q[e] = rintf(p);
+        near_tie |= fabsf(p - q[e]) > 0.4995f;
+      }
+      if (near_tie) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) q[e] = (scale > 0.f) ? rintf(__fdiv_rn((float)v[i][e], scale)) : 0.f;
+      }
       unsigned lo = 0, hi = 0;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        // all-zero row: the reference computes 0/0 = NaN -> int8 (undefined); we emit 0
-        float q = (scale > 0.f) ? __fdiv_rn((float)v[i][e], scale) : 0.f;
-        q = rintf(q);
-        q = fminf(fmaxf(q, -128.f), 127.f);
-        const unsigned byte = (unsigned)((int)q) & 0xFFu;
+        const unsigned byte = (unsigned)((int)fminf(fmaxf(q[e], -128.f), 127.f)) & 0xFFu;
         if (e < 4)
           lo |= byte << (8 * e);
         else
