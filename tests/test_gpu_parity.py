@@ -252,3 +252,31 @@ def test_llama7b_linear_shapes(dev):
             eD, eacc = C.qqq_gemm(A.numpy()[rows], B.cpu().numpy(), s1.numpy()[rows], s2.numpy(), None, return_acc=True)
             assert np.array_equal(acc[rows], eacc), (N, K, M)
             assert ulp_distance(D[rows], eD) == 0
+
+
+def test_maximum_batch_and_grouped_llama_shape(dev):
+    """BASELINE config 4 at its largest batch (32 x 1024 = 32768 tokens) and a per-group layer at 8192 tokens:
+    many tile rounds, grid.y > 1 never needed; rows subsampled for the CPU oracle."""
+    from oracle import c_oracle as C
+    from qqq_amd import pack as P
+
+    for (N, K, M, grouped) in ((4096, 4096, 32768, False), (11008, 4096, 8192, True)):
+        g = torch.Generator(device="cpu").manual_seed(7 * N + K + M)
+        if grouped:
+            codes = torch.randint(0, 16, (K, N), generator=g, dtype=torch.int8)
+            s3 = (torch.rand((K // 128, N), generator=g) * 15.0 + 0.5).to(torch.float16)
+        else:
+            codes = torch.randint(-7, 8, (K, N), generator=g, dtype=torch.int8)
+            s3 = None
+        B = P.pack_codes(codes.to(dev), grouped)
+        s2 = (torch.rand((1, N), generator=g) * 2e-4 + 1e-5).to(torch.float32)
+        h = GemmHarness(B, s2, None if s3 is None else s3.to(dev), dev)
+        A = torch.randint(-128, 128, (M, K), generator=g, dtype=torch.int8)
+        s1 = (torch.rand((M, 1), generator=g) * 0.05 + 0.001).to(torch.float32)
+        D, acc = h.run(A.numpy(), s1.numpy(), None)
+        rows = np.unique(np.r_[0, M - 1, np.random.default_rng(M).integers(0, M, 30)])
+        eD, eacc = C.qqq_gemm(A.numpy()[rows], B.cpu().numpy(), s1.numpy()[rows], s2.numpy(),
+                              None if s3 is None else s3.numpy(), return_acc=True)
+        assert np.array_equal(acc[rows], eacc), (N, K, M, grouped)
+        assert ulp_distance(D[rows], eD) == 0
+        assert not np.isnan(D.astype(np.float32)).any()
