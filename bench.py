@@ -162,6 +162,27 @@ def fp16_gemm_us(dev, M, iters=10, N=N_FULL, K=K_FULL):
     return float(np.median(t))
 
 
+def int8_gemm_us(dev, M, iters=10, N=N_FULL, K=K_FULL):
+    """vendor int8 x int8 -> int32 GEMM (torch._int_mm = hipBLASLt) on the same GPU and shape: what a library kernel
+    gets out of the int8 matrix pipe under the same power limit (2x the weight bytes, no scales, no fp16 epilogue --
+    a ceiling reference, not an equivalent operator).  None when the op rejects the shape (it needs M > 16)."""
+    try:
+        Ws = [torch.randint(-128, 128, (K, N), device=dev, dtype=torch.int8) for _ in range(3)]
+        x = torch.randint(-128, 128, (M, K), device=dev, dtype=torch.int8)
+        for i in range(3):
+            torch._int_mm(x, Ws[i % 3])
+        torch.cuda.synchronize()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+        for i, (a, b) in enumerate(evs):
+            a.record()
+            torch._int_mm(x, Ws[i % 3])
+            b.record()
+        torch.cuda.synchronize()
+        return float(np.median([a.elapsed_time(b) for a, b in evs]) * 1e3)
+    except Exception:
+        return None
+
+
 def cpu_baseline(sample_rows=64, budget_s=12.0):
     """The C oracle (restatement of the reference arithmetic, `kind: port`) on the host cores, on a bounded
     sample of the same workload: `sample_rows` tokens x the full N x K weight matrix, repeated until
@@ -396,6 +417,11 @@ def main():
             if not args.no_fp16:
                 f = fp16_gemm_us(dev, M)
                 entry["fp16_gemm_us"] = f
+                if M > 16:
+                    v8 = int8_gemm_us(dev, M)
+                    if v8:
+                        entry["vendor_int8_gemm_us"] = v8
+                        entry["speedup_vs_vendor_int8"] = v8 / entry["us"]
                 entry["speedup_vs_fp16"] = f / us
             per_m[str(M)] = entry
         result["per_m"] = per_m
