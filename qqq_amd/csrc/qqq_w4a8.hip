@@ -20,14 +20,19 @@
 //    int32 partial-sum stores.  The integer dot products do not care about the k order inside
 //    an operand as long as both operands use the same order ("k-slot freedom"), and the
 //    packed order [kq][r] IS natural k order, so the activation operand is 16 contiguous bytes.
-//  * "stream" kernel (m <= 64): HBM-bound.  v_mfma_i32_16x16x64_i8; a lane (i = 8*g + c, h)
+//  * "column" kernel (decode, m <= 16): HBM-bound.  32 weight columns x all of K per workgroup, so a wide layer
+//    fills the chip without split-K (one launch per call); packed words re-distributed between lanes with DPP.
+//  * "stream" kernel (m <= 128): HBM-bound.  v_mfma_i32_16x16x64_i8; a lane (i = 8*g + c, h)
 //    loads its 64 weight bytes of k-tile 4*s + h straight from HBM into VGPRs (no LDS: the
 //    weights are used once), a wave eats 128 columns x 64 k = 4 KiB per step, waves of a
 //    workgroup split K and reduce through LDS, workgroups split K through int32 slabs in the
 //    reduce buffer C (int32 addition is associative: bit-exact for every split).
-//  * "tiled" kernel (m > 64): MFMA-bound.  v_mfma_i32_32x32x32_i8; BMx256 tiles, BK = 128,
-//    activations and RAW packed weights staged in LDS (XOR-swizzled 16-byte chunks so that every
-//    ds_read_b128 is bank-conflict free), 2-stage software pipeline, XCD-aware tile order.
+//  * "tiled" kernel (m > 128): MFMA-bound.  v_mfma_i32_32x32x32_i8; BMx256 tiles, BK = 128,
+//    activations and RAW packed weights staged in LDS by LDS-DMA (XOR-swizzled 16-byte chunks so that
+//    every fragment read is bank-conflict free), continuous fragment pipeline, XCD-aware tile order,
+//    in-launch split-K through tile-sized slots of C.
+//  Host side: make_plan() picks family / tile / split from a small measured cost model; the C-ABI entry points
+//  are at the end of the file.
 //
 // The accumulators are the reference's: per-channel weights enter as 16*w4 (high nibble of each
 // byte) and pack() has pre-divided s_channel by 16; per-group weights are re-quantised to int8
