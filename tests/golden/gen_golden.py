@@ -79,6 +79,7 @@ def main():
         (128, 256): [1, 5, 16, 17, 33, 64],
         (256, 256): [16, 40],
         (256, 512): [1, 16],
+        (128, 1024): [100, 128],  # 8 scale groups of 128, token counts past one MFMA tile (SURVEY 8c list)
     }
     names = []
     for group_size in (-1, 128):
