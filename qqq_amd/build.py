@@ -9,7 +9,7 @@ import shutil
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(_HERE, "csrc", "qqq_w4a8.hip")
+SRC = os.path.join(_HERE, "csrc", "qqq_w4a8.hip")  # the one translation unit; it includes csrc/*.hip.h
 HDR = os.path.join(os.path.dirname(_HERE), "include", "qqq_amd.h")
 LIB = os.environ.get("QQQ_AMD_LIB") or os.path.join(_HERE, "libqqq_amd.so")  # override: tuning builds only
 ARCH = "gfx950"
@@ -26,7 +26,9 @@ def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(p) > t for p in (SRC, HDR))
+    csrc = os.path.dirname(SRC)
+    deps = [HDR] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h"))]
+    return any(os.path.getmtime(p) > t for p in deps)
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

@@ -1,0 +1,115 @@
+// qqq_common.hip.h -- vector types and the device helpers shared by every kernel (scale index maps, fused epilogue, int4 unpack, LDS-DMA)
+// Part of the single translation unit qqq_w4a8.hip (see its header comment for the design).
+#ifndef QQQ_AMD_QQQ_COMMON_HIP_H_
+#define QQQ_AMD_QQQ_COMMON_HIP_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/qqq_amd.h"
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+#define QQQ_NIB_MASK 0xF0F0F0F0u
+
+// ------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------
+
+// stored position of logical column n's per-channel scale (inverse of _scale_perm_single,
+// qlinear_marlin.py:173-175):  n%32 = 2*i + 8*q + e  ->  32*(n/32) + 8*i + 2*q + e
+__device__ __forceinline__ int s2_stored_index(int n) {
+  const int w = n & 31;
+  return (n & ~31) + 8 * ((w & 7) >> 1) + 2 * (w >> 3) + (w & 1);
+}
+
+// One lane's 4 consecutive outputs (n % 4 == 0): the fused dequant epilogue
+// (csrc/qqq_gemm.cu:695-700): two separate fp32 RN multiplies, then RN to fp16.
+__device__ __forceinline__ h4 epilogue_vals4(const int v0, const int v1, const int v2, const int v3,
+                                             const int n, const float a_s,
+                                             const float* __restrict__ s2) {
+  const int i0 = s2_stored_index(n);  // n%4==0: (n, n+1) -> (i0, i0+1); (n+2, n+3) -> (i0+8, i0+9)
+  const float2 sa = *reinterpret_cast<const float2*>(s2 + i0);
+  const float2 sb = *reinterpret_cast<const float2*>(s2 + i0 + 8);
+  h4 o;
+  o[0] = (_Float16)__fmul_rn(__fmul_rn((float)v0, sa.x), a_s);
+  o[1] = (_Float16)__fmul_rn(__fmul_rn((float)v1, sa.y), a_s);
+  o[2] = (_Float16)__fmul_rn(__fmul_rn((float)v2, sb.x), a_s);
+  o[3] = (_Float16)__fmul_rn(__fmul_rn((float)v3, sb.y), a_s);
+  return o;
+}
+
+// ... stored straight from the lane; `bias` (may be null) is added in fp16 AFTER the fp16 round, exactly
+// like the reference's separate `D + self.bias` (qlinear_marlin.py:287).
+__device__ __forceinline__ void epilogue_store4(const int v0, const int v1, const int v2,
+                                                const int v3, const int m, const int n,
+                                                const int N, const float a_s,
+                                                const float* __restrict__ s2,
+                                                _Float16* __restrict__ D,
+                                                int32_t* __restrict__ acc_out,
+                                                const _Float16* __restrict__ bias = nullptr) {
+  h4 o = epilogue_vals4(v0, v1, v2, v3, n, a_s, s2);
+  if (bias) o = o + *reinterpret_cast<const h4*>(bias + n);
+  *reinterpret_cast<h4*>(D + (size_t)m * N + n) = o;
+  if (acc_out) {
+    v4i a = {v0, v1, v2, v3};
+    *reinterpret_cast<v4i*>(acc_out + (size_t)m * N + n) = a;
+  }
+}
+
+// per-group int4 -> int8 re-quantisation of 4 weights (nibbles p0,p4,p1,p5 of q):
+// u -> fp16(u-8) exactly, ONE fp16 FMA (u-8)*s + 1152, low byte, ^0x80
+// (bit-identical to dequant_per_group, csrc/qqq_gemm.cu:167-210).
+__device__ __forceinline__ unsigned dequant_group4(const unsigned q, const h2 s) {
+  const unsigned t0 = (q & 0x000f000fu) | 0x64006400u;  // {1024+p0, 1024+p4}
+  const unsigned t1 = (q & 0x00f000f0u) | 0x64006400u;  // {1024+16*p1, 1024+16*p5}
+  const h2 c_sub = {(_Float16)-1032.0f, (_Float16)-1032.0f};
+  const h2 c_mul = {(_Float16)0.0625f, (_Float16)0.0625f};
+  const h2 c_add = {(_Float16)-72.0f, (_Float16)-72.0f};
+  const h2 c_mag = {(_Float16)1152.0f, (_Float16)1152.0f};
+  h2 a = __builtin_bit_cast(h2, t0) + c_sub;                                  // exact
+  h2 b = __builtin_elementwise_fma(__builtin_bit_cast(h2, t1), c_mul, c_add);  // exact
+  a = __builtin_elementwise_fma(a, s, c_mag);
+  b = __builtin_elementwise_fma(b, s, c_mag);
+  // bytes: [a.lo, a.hi, b.lo, b.hi] low bytes  (v_perm pool: src1 = bytes 0-3, src0 = bytes 4-7)
+  return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, b), __builtin_bit_cast(unsigned, a),
+                               0x06040200u) ^
+         0x80808080u;
+}
+
+// LDS-DMA of 16 bytes per lane: LDS destination = lds_dst (wave-uniform byte address) + 16*lane, the
+// global source is per lane.  Issued through inline asm on purpose: hipcc cannot prove that the LDS
+// image being filled (stage buf^1) does not alias the ds_reads of the stage being consumed, and would
+// drain it with s_waitcnt vmcnt(0) before the first ds_read -- serialising load and compute.  Being asm,
+// these loads are invisible to the compiler's wait-count bookkeeping: the kernel waits for them itself
+// (one explicit vmcnt(0) in front of the stage barrier).  M0 is saved/restored around the DMA.
+__device__ __forceinline__ void glds16(const void* gsrc, const unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+
+template <bool GROUPED>
+__device__ __forceinline__ void unpack_pair(const unsigned q, const h2 s_b0, const h2 s_b1,
+                                            int& w_b0, int& w_b1) {
+  if constexpr (GROUPED) {
+    w_b0 = (int)dequant_group4(q, s_b0);
+    w_b1 = (int)dequant_group4(q >> 8, s_b1);
+  } else {
+    w_b0 = (int)(q & QQQ_NIB_MASK);         // odd nibbles  -> 16*w4 of column n      (b = 0)
+    w_b1 = (int)((q << 4) & QQQ_NIB_MASK);  // even nibbles -> 16*w4 of column n + 8  (b = 1)
+  }
+}
+
+
+#endif  // QQQ_AMD_QQQ_COMMON_HIP_H_

@@ -1,0 +1,258 @@
+// qqq_stream.hip.h -- "stream" kernel (m <= 128, HBM-bound, weights HBM -> VGPR -> MFMA 16x16x64)
+// Part of the single translation unit qqq_w4a8.hip (see its header comment for the design).
+#ifndef QQQ_AMD_QQQ_STREAM_HIP_H_
+#define QQQ_AMD_QQQ_STREAM_HIP_H_
+
+// ------------------------------------------------------------------------------------------
+// "stream" kernel: small m, weights HBM -> VGPR -> MFMA 16x16x64
+// ------------------------------------------------------------------------------------------
+//
+// grid = (ceil(N/128) strips, ksplit, ceil(M / (16*MT)));  block = WAVES * 64.
+// MFMA A operand lane l = (i = l & 15, h = l >> 4): i = 8*g + c  <->  weight columns
+//     n = 128*strip + 64*g + 16*jt + 8*b + c   for the 8 MFMAs (jt, b) of a step,
+//     k = 64*s + 16*h + [0,16)   (k-tile 4*s + h).
+// MFMA B operand lane l = (j = l & 15, h): token m = mbase + 16*mt + j, same 16 k.
+// MFMA D: lane l holds column j = l & 15 (token) and rows i = 4*(l >> 4) + r, r = 0..3, i.e.
+//     g = l >> 5, c = 4*((l >> 4) & 1) + r  ->  4 consecutive n.
+
+template <int MT>
+struct StreamStep {
+  v4u w[4];   // w[kq][jt]
+  v4i x[MT];  // activation operands
+  h8 sc;      // per-group scales [2*jt + b]
+};
+
+template <int MT, bool GROUPED, int WAVES, int PF>
+__global__ __launch_bounds__(WAVES * 64) void qqq_stream_kernel(
+    const int8_t* __restrict__ A, const unsigned char* __restrict__ B, int32_t* __restrict__ C,
+    _Float16* __restrict__ D, const float* __restrict__ s1, const float* __restrict__ s2,
+    const _Float16* __restrict__ s3, int32_t* __restrict__ acc_out, int* __restrict__ tickets,
+    const _Float16* __restrict__ bias, const int M, const int N, const int K, const int ksplit,
+    const int fused) {
+  constexpr int NQ = MT * 8;  // MFMA output tiles per wave
+  __shared__ int red[NQ * 4 * 64 + 64];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int strip = blockIdx.x;
+  const int sp = blockIdx.y;
+  const int mbase = blockIdx.z * (16 * MT);
+
+  if constexpr (WAVES > 1) {
+    for (int i = tid; i < NQ * 4 * 64; i += WAVES * 64) red[i] = 0;
+    __syncthreads();
+  }
+
+  const int j = lane & 15;
+  const int h = lane >> 4;
+  const int g = j >> 3;
+  const int c = j & 7;
+  const int ngroups = N >> 6;
+  int ng = strip * 2 + g;
+  if (ng >= ngroups) ng = ngroups - 1;  // clamp (N % 128 == 64): loads stay legal, output dropped
+  const size_t rowbytes = (size_t)N * 8;
+  const unsigned char* bptr = B + (size_t)h * rowbytes + (size_t)ng * 512 + c * 64;
+
+  const int8_t* xptr[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    int row = mbase + 16 * mt + j;
+    if (row >= M) row = M - 1;
+    xptr[mt] = A + (size_t)row * K + 16 * h;
+  }
+  const _Float16* sptr = GROUPED ? (s3 + (size_t)ng * 64 + c * 8) : nullptr;
+
+  const int KS = K >> 6;  // 64-k steps
+  const int ks_begin = (int)(((long long)KS * sp) / ksplit);
+  const int ks_end = (int)(((long long)KS * (sp + 1)) / ksplit);
+
+  v4i acc[MT][4][2];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      acc[mt][jt][0] = (v4i){0, 0, 0, 0};
+      acc[mt][jt][1] = (v4i){0, 0, 0, 0};
+    }
+
+  auto load_step = [&](const int s, StreamStep<MT>& r) {
+    const unsigned char* p = bptr + (size_t)(4 * s) * rowbytes;
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) {
+#ifdef QQQ_STREAM_NT
+      r.w[kq] = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(p + 16 * kq));  // streamed once
+#else
+      r.w[kq] = *reinterpret_cast<const v4u*>(p + 16 * kq);
+#endif
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) r.x[mt] = *reinterpret_cast<const v4i*>(xptr[mt] + 64 * s);
+    if constexpr (GROUPED) r.sc = *reinterpret_cast<const h8*>(sptr + (size_t)(s >> 1) * N);
+  };
+
+  auto compute_step = [&](const StreamStep<MT>& r) {
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      v4i a0, a1;
+      h2 sb0 = {(_Float16)0, (_Float16)0}, sb1 = sb0;
+      if constexpr (GROUPED) {
+        sb0 = (h2){r.sc[2 * jt], r.sc[2 * jt]};
+        sb1 = (h2){r.sc[2 * jt + 1], r.sc[2 * jt + 1]};
+      }
+#pragma unroll
+      for (int kq = 0; kq < 4; ++kq) {
+        int w0, w1;
+        unpack_pair<GROUPED>(r.w[kq][jt], sb0, sb1, w0, w1);
+        a0[kq] = w0;
+        a1[kq] = w1;
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        acc[mt][jt][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, r.x[mt], acc[mt][jt][0], 0, 0, 0);
+        acc[mt][jt][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, r.x[mt], acc[mt][jt][1], 0, 0, 0);
+      }
+    }
+  };
+
+  // software pipeline: PF steps (4 KiB of weights each) in flight per wave.  The steady-state loop is
+  // branch-free so that hipcc can place COUNTED s_waitcnt vmcnt(N) (loads of the younger ring slots
+  // stay in flight while the oldest slot is consumed); the ragged tail takes the checked path.
+  StreamStep<MT> ring[PF];
+  int s = ks_begin + wave;
+  if (s + (2 * PF - 1) * WAVES < ks_end) {
+    // unconditional prologue + branch-free loop: the wait counters are exact on every path
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+      load_step(s + p * WAVES, ring[p]);
+      __builtin_amdgcn_sched_barrier(0);  // ring order == issue order, so vmcnt(N) can be counted
+    }
+    for (; s + (2 * PF - 1) * WAVES < ks_end; s += PF * WAVES) {
+#pragma unroll
+      for (int p = 0; p < PF; ++p) {
+        compute_step(ring[p]);
+        __builtin_amdgcn_sched_barrier(0);  // keep the refill right behind its consumer (hipcc would
+        load_step(s + (p + PF) * WAVES, ring[p]);  // otherwise sink all loads to the loop end)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int p = 0; p < PF; ++p)
+      if (s + p * WAVES < ks_end) load_step(s + p * WAVES, ring[p]);
+  }
+  for (; s < ks_end; s += PF * WAVES) {
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+      const int sc = s + p * WAVES;
+      if (sc < ks_end) {
+        compute_step(ring[p]);
+        const int sn = sc + PF * WAVES;
+        if (sn < ks_end) load_step(sn, ring[p]);
+      }
+    }
+  }
+
+  // ---- reduce the waves of this workgroup through LDS (int adds: order-independent) ----
+  if constexpr (WAVES > 1) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            __hip_atomic_fetch_add(&red[(((mt * 4 + jt) * 2 + b) * 4 + r) * 64 + lane],
+                                   acc[mt][jt][b][r], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+    __syncthreads();
+  } else {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            red[(((mt * 4 + jt) * 2 + b) * 4 + r) * 64 + lane] = acc[mt][jt][b][r];
+    __syncthreads();
+  }
+
+  // ---- write out: item = (q = (mt, jt, b), lane) -> 4 consecutive n of one token ----
+  auto item_coords = [&](const int it, int& m, int& n) {
+    const int q = it >> 6, ln = it & 63;
+    const int mt = q >> 3, jt = (q >> 1) & 3, b = q & 1;
+    const int qd = ln >> 4;
+    m = mbase + 16 * mt + (ln & 15);
+    n = strip * 128 + 64 * (qd >> 1) + 16 * jt + 8 * b + 4 * (qd & 1);
+  };
+
+  if (ksplit == 1) {
+    for (int it = tid; it < NQ * 64; it += WAVES * 64) {
+      int m, n;
+      item_coords(it, m, n);
+      if (m < M && n < N) {
+        const int q = it >> 6, ln = it & 63;
+        const int* rp = &red[(q * 4) * 64 + ln];
+        epilogue_store4(rp[0], rp[64], rp[128], rp[192], m, n, N, s1[m], s2, D, acc_out, bias);
+      }
+    }
+    return;
+  }
+
+  // split-K: partial sums -> slab sp of C  (C[(sp*M + m)*N + n])
+  for (int it = tid; it < NQ * 64; it += WAVES * 64) {
+    int m, n;
+    item_coords(it, m, n);
+    if (m < M && n < N) {
+      const int q = it >> 6, ln = it & 63;
+      const int* rp = &red[(q * 4) * 64 + ln];
+      v4i v = {rp[0], rp[64], rp[128], rp[192]};
+      int32_t* dst = C + ((size_t)sp * M + m) * N + n;
+      if (fused == 2) {
+        // write-through (sc0 sc1) slab store: reaches memory without a later L2 write-back, so the
+        // publish below needs no agent-scope release fence (MI355X hand-off recipe R1)
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+      } else {
+        *reinterpret_cast<v4i*>(dst) = v;
+      }
+    }
+  }
+  if (!fused) return;  // a separate reduce launch finishes the job
+
+  // in-launch reduction by the last-arriving workgroup of this (strip, m-block) tile:
+  // (fused == 1) plain stores -> agent-scope release -> ticket, or (fused == 2) write-through stores ->
+  // drained -> ticket; then one agent-scope acquire in the last arriver (placement independent).
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int* flag = &red[NQ * 4 * 64];
+  if (tid == 0) {
+    if (fused == 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int* tk = tickets + (blockIdx.z * gridDim.x + strip);
+    const int t = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = (t == ksplit - 1);
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // workspace zero on return
+    }
+    *flag = last;
+  }
+  __syncthreads();
+  if (!*flag) return;
+  for (int it = tid; it < NQ * 64; it += WAVES * 64) {
+    int m, n;
+    item_coords(it, m, n);
+    if (m < M && n < N) {
+      v4i sum = {0, 0, 0, 0};
+      for (int p = 0; p < ksplit; ++p)
+        sum += *reinterpret_cast<const v4i*>(C + ((size_t)p * M + m) * N + n);
+      epilogue_store4(sum[0], sum[1], sum[2], sum[3], m, n, N, s1[m], s2, D, acc_out, bias);
+    }
+  }
+}
+
+
+#endif  // QQQ_AMD_QQQ_STREAM_HIP_H_

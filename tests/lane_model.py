@@ -1,6 +1,6 @@
 """Lane-level numpy model of the two HIP kernels' data movement (tests only).
 
-It mirrors, formula by formula, the address arithmetic of qqq_amd/csrc/qqq_w4a8.hip
+It mirrors, formula by formula, the address arithmetic of qqq_amd/csrc/qqq_{stream,column,tiled}.hip.h
 (`qqq_stream_kernel`, `qqq_column_kernel`, `qqq_tiled_kernel`): which bytes each lane loads, how the LDS image is
 swizzled, which MFMA operand slot they land in, and where each accumulator register is stored.
 The MFMA lane maps assumed here (and checked on the device by tests/test_gpu_probe.py):
