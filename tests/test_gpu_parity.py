@@ -8,6 +8,7 @@ import torch
 
 from conftest import gpu_dump
 from gpu_util import GemmHarness, ulp_distance, variants
+from qqq_amd import ops
 
 pytestmark = pytest.mark.gpu
 MAX_ULP = 1  # north_star: "fp16 outputs within 1 ulp of the reference dequant"
@@ -280,3 +281,47 @@ def test_maximum_batch_and_grouped_llama_shape(dev):
         assert np.array_equal(acc[rows], eacc), (N, K, M, grouped)
         assert ulp_distance(D[rows], eD) == 0
         assert not np.isnan(D.astype(np.float32)).any()
+
+
+def test_inlaunch_splitk_stress_two_streams(dev):
+    """The slot / ticket hand-off of the tiled kernel's in-launch split-K under load: two layers (own scratch each, as
+    two QuantLinear modules would have) hammered back to back from two streams, 300 calls with varying m and K
+    splits; every result must equal the unsplit kernel's bit for bit and the workspaces must end all-zero."""
+    from qqq_amd import pack as P
+
+    g = torch.Generator(device="cpu").manual_seed(99)
+    N, K = 2048, 4096
+    layers = []
+    for i in range(2):
+        codes = torch.randint(-7, 8, (K, N), generator=g, dtype=torch.int8)
+        B = P.pack_codes(codes.to(dev), False)
+        s2 = (torch.rand((1, N), generator=g) * 2e-4 + 1e-5).to(torch.float32)
+        layers.append(GemmHarness(B, s2, None, dev))
+    Ms = [129, 200, 256, 300, 512, 777, 1024]
+    toks, want = {}, {}
+    for M in Ms:
+        A = torch.randint(-128, 128, (M, K), generator=g, dtype=torch.int8).to(dev)
+        s1 = (torch.rand((M, 1), generator=g) * 0.05 + 0.001).to(torch.float32).to(dev)
+        toks[M] = (A, s1)
+        for li, h in enumerate(layers):
+            D = torch.empty((M, N), dtype=torch.float16, device=dev)
+            ops.qqq_gemm_ex(A, h.B, h.C, D, s1, h.s2, h.s3, h.ws, -1, -1, -1, 16, tune=dict(kernel=2, bm=64, ksplit=1))
+            want[(li, M)] = D
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    outs = []
+    for it in range(150):
+        for li, h in enumerate(layers):
+            M = Ms[(it + 3 * li) % len(Ms)]
+            A, s1 = toks[M]
+            tune = [None, dict(kernel=2, bm=256, ksplit=2 + it % 3), dict(kernel=2, bm=131, ksplit=2 + it % 4),
+                    dict(kernel=2, bm=64, ksplit=2)][it % 4]
+            D = torch.empty((M, N), dtype=torch.float16, device=dev)
+            with torch.cuda.stream(streams[li]):
+                ops.qqq_gemm_ex(A, h.B, h.C, D, s1, h.s2, h.s3, h.ws, -1, -1, -1, 16, tune=tune)
+            outs.append((li, M, D))
+    torch.cuda.synchronize()
+    for li, M, D in outs:
+        assert torch.equal(D.view(torch.int16), want[(li, M)].view(torch.int16)), (li, M)
+    for h in layers:
+        assert int(h.ws.abs().sum().item()) == 0
