@@ -19,13 +19,14 @@ ERR_KERN_SHAPE = 2
 
 
 def _ptr(t: Optional[torch.Tensor]):
+    # plain ints: the argtypes declared in _lib.py convert them to void* (cheaper than building c_void_p objects)
     if t is None or t.numel() == 0:
         return None
-    return ctypes.c_void_p(t.data_ptr())
+    return t.data_ptr()
 
 
 def _stream_for(t: torch.Tensor):
-    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return torch.cuda.current_stream(t.device).cuda_stream
 
 
 def _check_common(A, B, C, D, s1, s2, s3, workspace, max_par):
@@ -129,14 +130,28 @@ def _qqq_gemm_bias_op(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, D: torc
     qqq_gemm_ex(A, B, C, D, s1, s2, s3, workspace, -1, -1, -1, max_par, bias=bias)
 
 
+def _compiling() -> bool:
+    # Under torch.compile the calls must go through the registered custom ops (no graph break, fake-tensor
+    # propagation).  In eager mode the dispatcher round trip of a Python custom op costs ~9 us per call -- more
+    # than a decode GEMM on a 4096x4096 layer takes on the GPU (tools/host_overhead.py) -- so eager calls go
+    # straight to the ctypes binding.
+    return torch.compiler.is_compiling()
+
+
 def qqq_gemm_bias(A, B, C, D, s1, s2, s3, workspace, bias, max_par=16) -> None:
     """qqq_gemm + the reference's `D + self.bias` (qlinear_marlin.py:287) fused into the epilogue."""
-    _qqq_gemm_bias_op(A, B, C, D, s1, s2, s3, workspace, bias, max_par)
+    if _compiling():
+        _qqq_gemm_bias_op(A, B, C, D, s1, s2, s3, workspace, bias, max_par)
+    else:
+        qqq_gemm_ex(A, B, C, D, s1, s2, s3, workspace, -1, -1, -1, max_par, bias=bias)
 
 
 def qqq_gemm(A, B, C, D, s1, s2, s3, workspace, thread_k=-1, thread_n=-1, sms=-1, max_par=8) -> None:
     """Drop-in for `QQQ._CUDA.qqq_gemm` (qqq_gemm.h:23-36): writes fp16 `D` in place, returns None."""
-    _qqq_gemm_op(A, B, C, D, s1, s2, s3, workspace, thread_k, thread_n, sms, max_par)
+    if _compiling():
+        _qqq_gemm_op(A, B, C, D, s1, s2, s3, workspace, thread_k, thread_n, sms, max_par)
+    else:
+        _qqq_gemm_impl(A, B, C, D, s1, s2, s3, workspace, thread_k, thread_n, sms, max_par)
 
 
 def mul(A, B, C, D, s1, s2, s3, workspace, thread_k=-1, thread_n=-1, sms=-1, max_par=16):
@@ -156,8 +171,7 @@ def marlin_qqq_gemm(a, b_q_weight, s_tok, s_ch, s_group, workspace, size_m, size
     return D
 
 
-@torch.library.custom_op("qqq_amd::dynamic_quant", mutates_args=())
-def _dynamic_quant_op(x: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+def _dynamic_quant_impl(x: torch.Tensor):
     L = _lib.lib()
     if x.dtype != torch.float16 or not x.is_cuda or x.dim() != 2:
         raise RuntimeError("dynamic_quant: expected a 2-D fp16 tensor on the GPU (there is no CPU path)")
@@ -171,6 +185,11 @@ def _dynamic_quant_op(x: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
     return xq, s1
 
 
+@torch.library.custom_op("qqq_amd::dynamic_quant", mutates_args=())
+def _dynamic_quant_op(x: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    return _dynamic_quant_impl(x)
+
+
 @_dynamic_quant_op.register_fake
 def _(x):
     return x.new_empty(x.shape, dtype=torch.int8), x.new_empty((x.shape[0], 1), dtype=torch.float32)
@@ -178,7 +197,7 @@ def _(x):
 
 def dynamic_quant(x: torch.Tensor):
     """Fused replacement of QuantLinear.dynamic_quant (qlinear_marlin.py:265-268): (int8 [m,k], f32 [m,1])."""
-    return _dynamic_quant_op(x)
+    return _dynamic_quant_op(x) if _compiling() else _dynamic_quant_impl(x)
 
 
 def add_bias_(D: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
