@@ -100,6 +100,14 @@ int qqq_w4a8_plan(int prob_m, int prob_n, int prob_k, int groupsize, int max_par
  */
 int qqq_dynamic_quant(const void* x, void* xq, void* s1, int m, int k, int dev, void* stream);
 
+/* QuantLinear.forward in one host call (qlinear_marlin.py:270-288): qqq_dynamic_quant(x -> xq, s1) followed by
+ * qqq_w4a8_gemm_ex(xq, ..., bias) on the same stream.  x fp16 [m,k]; xq int8 [m,k] and s1 f32 [m] are caller-owned
+ * scratch/outputs; the other arguments as in qqq_w4a8_gemm_ex.  Exists because at decode sizes the two kernels take
+ * less GPU time than two trips through a Python binding take on the host. */
+int qqq_quantlinear_forward(const void* x, void* xq, void* s1, const void* B, void* C, void* D, const void* s2,
+                            const void* s3, int m, int n, int k, void* workspace, int groupsize, int dev,
+                            void* stream, int max_par, const void* bias);
+
 /* out[i,j] += bias[j] in fp16 (the reference's `D + self.bias`, qlinear_marlin.py:287). */
 int qqq_add_bias(void* D, const void* bias, int m, int n, int dev, void* stream);
 

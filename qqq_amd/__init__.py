@@ -6,6 +6,7 @@ Public surface (mirrors the reference's hot path, HandH1998/QQQ):
     QuantLinear                                                                    # qlinear_marlin.QuantLinear
     marlin_qqq_gemm(...)                                                           # vLLM-style wrapper
     dynamic_quant(x)                                                               # fused per-token int8 quant
+    quantlinear_forward(x, B, C, s2, s3, workspace, bias)                          # QuantLinear.forward, one call
 """
 from .ops import (  # noqa: F401
     dynamic_quant,
@@ -14,8 +15,9 @@ from .ops import (  # noqa: F401
     qqq_gemm,
     qqq_gemm_bias,
     qqq_gemm_ex,
+    quantlinear_forward,
 )
 from .qlinear import QuantLinear, fuse_quant_linears  # noqa: F401
 
-__all__ = ["qqq_gemm", "qqq_gemm_bias", "qqq_gemm_ex", "mul", "marlin_qqq_gemm", "dynamic_quant", "QuantLinear",
-           "fuse_quant_linears"]
+__all__ = ["qqq_gemm", "qqq_gemm_bias", "qqq_gemm_ex", "mul", "marlin_qqq_gemm", "dynamic_quant", "quantlinear_forward",
+           "QuantLinear", "fuse_quant_linears"]

@@ -44,6 +44,8 @@ def lib():
     L.qqq_w4a8_plan.restype = ci
     L.qqq_dynamic_quant.argtypes = [vp, vp, vp, ci, ci, ci, vp]
     L.qqq_dynamic_quant.restype = ci
+    L.qqq_quantlinear_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp, ci, ci, vp, ci, vp]
+    L.qqq_quantlinear_forward.restype = ci
     L.qqq_add_bias.argtypes = [vp, vp, ci, ci, ci, vp]
     L.qqq_add_bias.restype = ci
     L.qqq_probe_mfma.argtypes = [ci, vp, vp, vp, ci, vp]

@@ -571,6 +571,15 @@ extern "C" int qqq_dynamic_quant(const void* x, void* xq, void* s1, int m, int k
   return QQQ_OK;
 }
 
+extern "C" int qqq_quantlinear_forward(const void* x, void* xq, void* s1, const void* B, void* C, void* D,
+                                       const void* s2, const void* s3, int m, int n, int k, void* workspace,
+                                       int groupsize, int dev, void* stream, int max_par, const void* bias) {
+  const int rc = qqq_dynamic_quant(x, xq, s1, m, k, dev, stream);
+  if (rc != QQQ_OK) return rc;
+  return qqq_w4a8_gemm_ex(xq, B, C, D, s1, s2, s3, m, n, k, workspace, groupsize, dev, stream, -1, -1, -1, max_par,
+                          nullptr, nullptr, bias);
+}
+
 extern "C" int qqq_add_bias(void* D, const void* bias, int m, int n, int dev, void* stream) {
   g_err[0] = 0;
   if (m == 0 || n == 0) return QQQ_OK;

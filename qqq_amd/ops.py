@@ -207,3 +207,34 @@ def add_bias_(D: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
     if err:
         raise RuntimeError(f"qqq_amd: add_bias error {err}: {_lib.last_error()}")
     return D
+
+
+def quantlinear_forward(x: torch.Tensor, B, C, s2, s3, workspace, bias=None, max_par: int = 16) -> torch.Tensor:
+    """QuantLinear.forward (qlinear_marlin.py:270-288) for a 2-D fp16 input in ONE binding call: fused dynamic int8
+    quantisation + W4A8 GEMM (+ fp16 bias).  The buffers are a module's own (qlinear.QuantLinear): only the cheap
+    checks are made here.  Under torch.compile the two registered custom ops are used instead."""
+    if _compiling():
+        xq, s1 = _dynamic_quant_op(x)
+        D = torch.empty((x.shape[0], C.size(1)), dtype=torch.float16, device=x.device)
+        if bias is not None:
+            _qqq_gemm_bias_op(xq, B, C, D, s1, s2, s3, workspace, bias, max_par)
+        else:
+            _qqq_gemm_op(xq, B, C, D, s1, s2, s3, workspace, -1, -1, -1, max_par)
+        return D
+    if x.dtype != torch.float16 or not x.is_cuda or x.dim() != 2 or not x.is_contiguous():
+        raise RuntimeError("quantlinear_forward: expected a contiguous 2-D fp16 tensor on the GPU (there is no CPU path)")
+    m, k = x.shape
+    n = C.size(1)
+    if B.numel() != (k // 16) * (n * 2) or B.device != x.device:
+        raise RuntimeError("quantlinear_forward: B must be the packed [k/16, 2n] weight on x's device")
+    groupsize = -1 if s3.numel() == 0 else k // s3.size(0)
+    xq = torch.empty((m, k), dtype=torch.int8, device=x.device)
+    s1 = torch.empty((m, 1), dtype=torch.float32, device=x.device)
+    D = torch.empty((m, n), dtype=torch.float16, device=x.device)
+    if m == 0:
+        return D
+    err = _lib.lib().qqq_quantlinear_forward(
+        x.data_ptr(), xq.data_ptr(), s1.data_ptr(), B.data_ptr(), C.data_ptr(), D.data_ptr(), s2.data_ptr(),
+        _ptr(s3), m, n, k, workspace.data_ptr(), groupsize, x.device.index or 0, _stream_for(x), max_par, _ptr(bias))
+    _raise_for(err, m, n, k, -1, -1, groupsize)
+    return D

@@ -108,17 +108,12 @@ class QuantLinear(nn.Module):
         return ops.dynamic_quant(x)
 
     def forward(self, A):
+        # reference: dynamic_quant (:265-268) -> mul (:28-45) -> `D + self.bias` (:287); here one binding call that
+        # launches the fused quantiser and the GEMM with the bias in its epilogue (fp16 add after the fp16 round)
         out_shape = A.shape[:-1] + (self.outfeatures,)
-        A = A.reshape(-1, A.shape[-1]).half()
-        quant_A, s1 = self.dynamic_quant(A)
-        D = torch.empty(A.shape[0], self.outfeatures, dtype=A.dtype, device=A.device)
-        if self.bias is not None:
-            # fp16 add after the fp16 round, as the reference's `D + self.bias` (:287), fused in the epilogue
-            ops.qqq_gemm_bias(quant_A, self.B, self.reduce_buffer, D, s1, self.s_channel, self.s_group,
-                              self.workspace, self.bias, max_par=self.max_par)
-        else:
-            ops.mul(quant_A, self.B, self.reduce_buffer, D, s1, self.s_channel, self.s_group, self.workspace,
-                    max_par=self.max_par)
+        A = A.reshape(-1, A.shape[-1]).half().contiguous()
+        D = ops.quantlinear_forward(A, self.B, self.reduce_buffer, self.s_channel, self.s_group, self.workspace,
+                                    self.bias, max_par=self.max_par)
         return D.reshape(out_shape)
 
 

@@ -28,3 +28,7 @@ import numpy as np
 print("native loop: %.1f us/call (HIP events)" % float(np.mean(layer.time_calls(A, s1, D, 200)) * 1e3))
 x = torch.randn((1, 4096), device=dev, dtype=torch.float16)
 print("dynamic_quant custom op: enqueue %.1f us/call, wall %.1f us/call" % loop(lambda: ops.dynamic_quant(x)))
+from qqq_amd import QuantLinear
+ql = QuantLinear(4, -1, 4096, 4096, bias=False).to(dev)
+ql.B.copy_(layer.Bs[0]); ql.s_channel.copy_(layer.s2)
+print("QuantLinear.forward (one binding call): enqueue %.1f us/call, wall %.1f us/call" % loop(lambda: ql(x)))
