@@ -21,14 +21,14 @@
 extern "C" {
 #endif
 
-#define QQQ_AMD_ABI_VERSION 1
+#define QQQ_AMD_ABI_VERSION 2
 
 /* return codes; 0/1/2 are the reference's (csrc/qqq_gemm.cu:947-948, :1002-1003) */
 #define QQQ_OK 0
 #define QQQ_ERR_PROB_SHAPE 1 /* (m,n,k) not compatible with thread_k/thread_n / group size  */
 #define QQQ_ERR_KERN_SHAPE 2 /* no kernel for thread_k/thread_n/groupsize                    */
 #define QQQ_ERR_HIP 16       /* a HIP runtime call failed; see qqq_amd_last_error()          */
-#define QQQ_ERR_ARG 17       /* NULL / misaligned pointer or scratch too small               */
+#define QQQ_ERR_ARG 17       /* NULL or misaligned pointer (A/B/C/D/s3/bias: 16 B, s2: 8 B)   */
 
 /*
  * Replaces `int qqq_cuda(...)` (csrc/qqq_gemm.cu:950-969), argument for argument:
@@ -108,35 +108,21 @@ int qqq_quantlinear_forward(const void* x, void* xq, void* s1, const void* B, vo
                             const void* s3, int m, int n, int k, void* workspace, int groupsize, int dev,
                             void* stream, int max_par, const void* bias);
 
-/* out[i,j] += bias[j] in fp16 (the reference's `D + self.bias`, qlinear_marlin.py:287). */
-int qqq_add_bias(void* D, const void* bias, int m, int n, int dev, void* stream);
-
-/* Measurement helper for bench.py: runs `iters` calls of qqq_w4a8_gemm_ex back to back on `stream`,
- * call i using the weight buffer Bs[i % nB] (rotate >= 4 x 89 MB buffers to defeat the 256 MiB
- * Infinity Cache), each bracketed by its own hipEvent pair recorded on `stream`; synchronises the
- * stream and writes the `iters` durations in milliseconds to ms_each (host memory). */
-int qqq_bench_gemm(const void* A, const void* const* Bs, int nB, void* C, void* D, const void* s1,
-                   const void* s2, const void* s3, int prob_m, int prob_n, int prob_k, void* workspace,
-                   int groupsize, int dev, void* stream, int max_par, const qqq_tune_t* tune, int iters,
-                   float* ms_each);
+/*
+ * int4 packer / unpacker for the Marlin/QQQ weight layout -- replaces the python-loop interleave of
+ * QuantLinear.pack (qlinear_marlin.py:228-248; layout from _get_perms, :147-176):
+ *   codes int8 [k,n] row-major (signed int4 in [-8,7] per-channel, unsigned u in [0,15] per-group)
+ *   B     int32 [k/16, 2n]; word B[kt][128*ng + 16*c + 4*kq + jt] holds k = 16*kt + 4*kq + r (r = 0..3) of columns
+ *         n = 64*ng + 16*jt + 8*b + c (b = 0,1); nibble p <-> (b,r) = (1-(p&1), p>>1) per-channel,
+ *         ((p&3)>>1, 2*(p&1) + (p>>2)) per-group.
+ * on_device != 0: both buffers are device memory, the work is enqueued on `stream`; on_device == 0: both are host
+ * memory and the call is synchronous (offline checkpoint conversion).  k % 16 == 0, n % 64 == 0, 8-byte aligned.
+ */
+int qqq_pack_int4(const void* codes, void* B, int k, int n, int grouped, int on_device, int dev, void* stream);
+int qqq_unpack_int4(const void* B, void* codes, int k, int n, int grouped, int on_device, int dev, void* stream);
 
 int qqq_amd_abi_version(void);
 const char* qqq_amd_last_error(void);
-
-/* Hardware self-tests used by tests/test_gpu_probe.py: run one MFMA / one LDS-DMA copy on raw
- * per-lane operands so the lane<->element maps the kernels rely on are checked on the device.
- * kind 16: v_mfma_i32_16x16x64_i8 (a,b: 64 lanes x 16 B; out: 64 x 4 int32)
- * kind 32: v_mfma_i32_32x32x32_i8 (a,b: 64 lanes x 16 B; out: 64 x 16 int32) */
-int qqq_probe_mfma(int kind, const void* a, const void* b, void* out, int dev, void* stream);
-/* copies 64 x 16 B through LDS with global_load_lds; lane l reads src chunk perm[l] */
-int qqq_probe_glds(const void* src, const void* perm, void* dst, int dev, void* stream);
-
-/* Read-bandwidth probe (tools/probe_fill.py): `nwg` workgroups of 512 threads each stream `bytes_per_wg` bytes
- * `reps` times from src + wg_stride * workgroup (wg_stride 0: a shared L2-resident window = per-CU L2->L1 fill rate;
- * wg_stride == bytes_per_wg: disjoint windows = HBM streaming); `unroll` 2 or 8 independent 16-byte loads per thread.
- * Writes the duration of one launch in milliseconds to ms_out (host memory). */
-int qqq_probe_fill(const void* src, size_t wg_stride, size_t bytes_per_wg, int nwg, int reps, int unroll, void* sink,
-                   int dev, void* stream, float* ms_out);
 
 #ifdef __cplusplus
 }

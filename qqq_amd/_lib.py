@@ -8,6 +8,7 @@ import os
 from . import build as _build
 
 _lib = None
+ABI_VERSION = 2  # QQQ_AMD_ABI_VERSION in include/qqq_amd.h
 
 
 class QQQTune(ctypes.Structure):
@@ -46,20 +47,13 @@ def lib():
     L.qqq_dynamic_quant.restype = ci
     L.qqq_quantlinear_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp, ci, ci, vp, ci, vp]
     L.qqq_quantlinear_forward.restype = ci
-    L.qqq_add_bias.argtypes = [vp, vp, ci, ci, ci, vp]
-    L.qqq_add_bias.restype = ci
-    L.qqq_probe_mfma.argtypes = [ci, vp, vp, vp, ci, vp]
-    L.qqq_probe_mfma.restype = ci
-    L.qqq_probe_glds.argtypes = [vp, vp, vp, ci, vp]
-    L.qqq_probe_glds.restype = ci
-    L.qqq_probe_fill.argtypes = [vp, ctypes.c_size_t, ctypes.c_size_t, ci, ci, ci, vp, ci, vp, ctypes.POINTER(ctypes.c_float)]
-    L.qqq_probe_fill.restype = ci
-    L.qqq_bench_gemm.argtypes = [vp, ctypes.POINTER(vp), ci, vp, vp, vp, vp, vp, ci, ci, ci, vp, ci, ci, vp, ci,
-                                 ctypes.POINTER(QQQTune), ci, ctypes.POINTER(ctypes.c_float)]
-    L.qqq_bench_gemm.restype = ci
+    L.qqq_pack_int4.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp]
+    L.qqq_pack_int4.restype = ci
+    L.qqq_unpack_int4.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp]
+    L.qqq_unpack_int4.restype = ci
     L.qqq_amd_abi_version.restype = ci
     L.qqq_amd_last_error.restype = ctypes.c_char_p
-    if L.qqq_amd_abi_version() != 1:
+    if L.qqq_amd_abi_version() != ABI_VERSION:
         raise RuntimeError("libqqq_amd.so ABI version mismatch; rebuild")
     _lib = L
     return L

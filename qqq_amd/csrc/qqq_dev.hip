@@ -1,0 +1,189 @@
+// qqq_dev.hip -- test / tuning companion of the operator library (libqqq_amd_dev.so; include/qqq_amd_dev.h).
+//
+// Nothing in here is part of the product: hardware probes for tests/test_gpu_probe.py (MFMA lane maps, LDS-DMA
+// destination semantics, the per-group re-quantiser on raw operands), a read-bandwidth probe, and the event-timed
+// call loop bench.py / tools use.  The GEMM itself is NOT compiled into this library: qqq_dev_bench_gemm calls the
+// operator library's qqq_w4a8_gemm_ex through a function pointer handed in by the caller, so what is timed is the
+// shipped kernel.
+#include "qqq_common.hip.h"
+#include "../../include/qqq_amd_dev.h"
+
+static thread_local char g_dev_err[256] = "";
+
+static int dev_fail(hipError_t e, const char* what) {
+  snprintf(g_dev_err, sizeof(g_dev_err), "%s: %s", what, hipGetErrorString(e));
+  return QQQ_ERR_HIP;
+}
+
+struct DevGuard {
+  int prev = -1;
+  bool changed = false;
+  explicit DevGuard(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != dev && dev >= 0) changed = (hipSetDevice(dev) == hipSuccess);
+  }
+  ~DevGuard() {
+    if (changed) (void)hipSetDevice(prev);
+  }
+};
+
+__global__ void qqq_probe_mfma16_kernel(const v4i* a, const v4i* b, v4i* out) {
+  const int l = threadIdx.x;
+  v4i acc = {0, 0, 0, 0};
+  acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[l], b[l], acc, 0, 0, 0);
+  out[l] = acc;
+}
+__global__ void qqq_probe_mfma32_kernel(const v4i* a, const v4i* b, v16i* out) {
+  const int l = threadIdx.x;
+  v16i acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0;
+  acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[l], b[l], acc, 0, 0, 0);
+  out[l] = acc;
+}
+
+// Read-bandwidth probe: every workgroup (512 threads, UNR independent 16-byte loads in flight per thread) streams
+// `bytes_per_wg` bytes starting at src + wg_stride * blockIdx.x, `reps` times, and folds them into one word.
+template <int UNR>
+__global__ __launch_bounds__(512) void qqq_probe_fill_kernel(const v4u* __restrict__ src, const size_t wg_stride,
+                                                             const size_t bytes_per_wg, const int reps,
+                                                             unsigned* __restrict__ sink) {
+  const v4u* p = reinterpret_cast<const v4u*>(reinterpret_cast<const unsigned char*>(src) + wg_stride * blockIdx.x);
+  const size_t nvec = bytes_per_wg / 16;
+  v4u acc = {0, 0, 0, 0};
+  for (int r = 0; r < reps; ++r)
+    for (size_t i = threadIdx.x; i + (UNR - 1) * 512 < nvec; i += UNR * 512) {
+      v4u v[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) v[u] = p[i + u * 512];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) acc ^= v[u];
+    }
+  if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345u) sink[0] = 1;  // keep the loads alive
+}
+
+__global__ void qqq_probe_glds_kernel(const v4u* src, const int* perm, v4u* dst) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2048];
+  const int l = threadIdx.x;
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+  // same helper the tiled kernel uses; destination deliberately not at the start of the array
+  glds16(src + perm[l], lds_base + 1024);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  dst[l] = reinterpret_cast<const v4u*>(lds + 1024)[l];
+}
+
+// the kernels' per-group re-quantiser on raw operands: out[2i] / out[2i+1] = the b = 0 / b = 1 int8 quadruples
+// unpack_pair<true> makes of word q[i] with scales {s0[i], s1[i]} (what every GEMM kernel feeds its MFMAs)
+__global__ __launch_bounds__(256) void qqq_probe_dequant_kernel(const unsigned* __restrict__ q,
+                                                                const unsigned short* __restrict__ s0,
+                                                                const unsigned short* __restrict__ s1,
+                                                                unsigned* __restrict__ out, const int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const _Float16 a = __builtin_bit_cast(_Float16, s0[i]), b = __builtin_bit_cast(_Float16, s1[i]);
+  int w0, w1;
+  unpack_pair<true>(q[i], (h2){a, a}, (h2){b, b}, w0, w1);
+  out[2 * i] = (unsigned)w0;
+  out[2 * i + 1] = (unsigned)w1;
+}
+
+extern "C" int qqq_dev_probe_mfma(int kind, const void* a, const void* b, void* out, int dev, void* stream) {
+  DevGuard guard(dev);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (kind == 16)
+    hipLaunchKernelGGL(qqq_probe_mfma16_kernel, dim3(1), dim3(64), 0, st, static_cast<const v4i*>(a),
+                       static_cast<const v4i*>(b), static_cast<v4i*>(out));
+  else if (kind == 32)
+    hipLaunchKernelGGL(qqq_probe_mfma32_kernel, dim3(1), dim3(64), 0, st, static_cast<const v4i*>(a),
+                       static_cast<const v4i*>(b), static_cast<v16i*>(out));
+  else
+    return QQQ_ERR_ARG;
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return dev_fail(e, "probe launch");
+  return QQQ_OK;
+}
+
+extern "C" int qqq_dev_probe_glds(const void* src, const void* perm, void* dst, int dev, void* stream) {
+  DevGuard guard(dev);
+  hipLaunchKernelGGL(qqq_probe_glds_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const v4u*>(src), static_cast<const int*>(perm), static_cast<v4u*>(dst));
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return dev_fail(e, "probe launch");
+  return QQQ_OK;
+}
+
+extern "C" int qqq_dev_probe_dequant(const void* q, const void* s0, const void* s1, void* out, int n, int dev,
+                                     void* stream) {
+  DevGuard guard(dev);
+  if (n <= 0) return QQQ_OK;
+  hipLaunchKernelGGL(qqq_probe_dequant_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const unsigned*>(q), static_cast<const unsigned short*>(s0),
+                     static_cast<const unsigned short*>(s1), static_cast<unsigned*>(out), n);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return dev_fail(e, "probe launch");
+  return QQQ_OK;
+}
+
+extern "C" int qqq_dev_probe_fill(const void* src, size_t wg_stride, size_t bytes_per_wg, int nwg, int reps, int unroll,
+                                  void* sink, int dev, void* stream, float* ms_out) {
+  DevGuard guard(dev);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return dev_fail(hipGetLastError(), "event");
+  auto launch = [&]() {
+    if (unroll >= 8)
+      hipLaunchKernelGGL(qqq_probe_fill_kernel<8>, dim3(nwg), dim3(512), 0, st, static_cast<const v4u*>(src), wg_stride,
+                         bytes_per_wg, reps, static_cast<unsigned*>(sink));
+    else
+      hipLaunchKernelGGL(qqq_probe_fill_kernel<2>, dim3(nwg), dim3(512), 0, st, static_cast<const v4u*>(src), wg_stride,
+                         bytes_per_wg, reps, static_cast<unsigned*>(sink));
+  };
+  launch();  // warm-up
+  (void)hipEventRecord(e0, st);
+  launch();
+  (void)hipEventRecord(e1, st);
+  hipError_t e = hipStreamSynchronize(st);
+  if (e == hipSuccess) e = hipEventElapsedTime(ms_out, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (e != hipSuccess) return dev_fail(e, "qqq_dev_probe_fill");
+  return QQQ_OK;
+}
+
+extern "C" int qqq_dev_bench_gemm(qqq_gemm_ex_fn gemm_ex, const void* A, const void* const* Bs, int nB, void* C, void* D,
+                                  const void* s1, const void* s2, const void* s3, int prob_m, int prob_n, int prob_k,
+                                  void* workspace, int groupsize, int dev, void* stream, int max_par,
+                                  const qqq_tune_t* tune, int iters, float* ms_each) {
+  g_dev_err[0] = 0;
+  if (!gemm_ex || iters <= 0 || nB <= 0 || !Bs || !ms_each) return QQQ_ERR_ARG;
+  DevGuard guard(dev);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipEvent_t* ev = new hipEvent_t[2 * iters];
+  int made = 0, rc = QQQ_OK;
+  for (; made < 2 * iters; ++made)
+    if (hipEventCreate(&ev[made]) != hipSuccess) {
+      rc = dev_fail(hipGetLastError(), "hipEventCreate");
+      break;
+    }
+  if (rc == QQQ_OK) {
+    for (int i = 0; i < iters && rc == QQQ_OK; ++i) {
+      (void)hipEventRecord(ev[2 * i], st);
+      rc = gemm_ex(A, Bs[i % nB], C, D, s1, s2, s3, prob_m, prob_n, prob_k, workspace, groupsize, dev, stream, -1, -1, -1,
+                   max_par, tune, nullptr, nullptr);
+      (void)hipEventRecord(ev[2 * i + 1], st);
+    }
+    hipError_t e = hipStreamSynchronize(st);
+    if (e != hipSuccess && rc == QQQ_OK) rc = dev_fail(e, "hipStreamSynchronize");
+    if (rc == QQQ_OK)
+      for (int i = 0; i < iters; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]) != hipSuccess) ms = -1.f;
+        ms_each[i] = ms;
+      }
+  }
+  for (int i = 0; i < made; ++i) (void)hipEventDestroy(ev[i]);
+  delete[] ev;
+  return rc;
+}
+
+extern "C" const char* qqq_dev_last_error(void) { return g_dev_err; }

@@ -1,4 +1,4 @@
-// qqq_small.hip.h -- small kernels: split-K reduce, fused dynamic int8 quantisation, bias add, hardware probes
+// qqq_small.hip.h -- small kernels: split-K reduce, fused dynamic int8 quantisation, int4 packer / unpacker
 // Part of the single translation unit qqq_w4a8.hip (see its header comment for the design).
 #ifndef QQQ_AMD_QQQ_SMALL_HIP_H_
 #define QQQ_AMD_QQQ_SMALL_HIP_H_
@@ -108,66 +108,60 @@ __global__ __launch_bounds__(256) void qqq_dynamic_quant_kernel(const _Float16* 
   }
 }
 
-__global__ __launch_bounds__(256) void qqq_add_bias_kernel(_Float16* __restrict__ D,
-                                                           const _Float16* __restrict__ bias,
-                                                           const long long total_vec, const int nvec) {
-  for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < total_vec;
-       it += (long long)gridDim.x * 256) {
-    h8 d = reinterpret_cast<h8*>(D)[it];
-    const h8 b = reinterpret_cast<const h8*>(bias)[it % nvec];
-    d = d + b;  // fp16 add, RN -- same as torch's half + half
-    reinterpret_cast<h8*>(D)[it] = d;
+
+// ------------------------------------------------------------------------------------------
+// int4 packer / unpacker for the Marlin/QQQ layout (replaces the python loops of
+// QuantLinear.pack, qlinear_marlin.py:228-248).  Closed form (qlinear_marlin.py:147-176):
+//   word B[kt][128*ng + 16*c + 4*kq + jt] holds k = 16*kt + 4*kq + r, n = 64*ng + 16*jt + 8*b + c;
+//   nibble p of the word is (b, r) = (1-(p&1), p>>1) per-channel, ((p&3)>>1, 2*(p&1) + (p>>2)) per-group.
+// One workgroup = one (k-tile, 64-column group): 16 x 64 codes <-> 128 words, both sides coalesced.
+// ------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ void qqq_nibble_coords(const int p, const bool grouped, int& b, int& r) {
+  if (grouped) {
+    b = (p & 3) >> 1;
+    r = 2 * (p & 1) + (p >> 2);
+  } else {
+    b = 1 - (p & 1);
+    r = p >> 1;
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// hardware probes (tests/test_gpu_probe.py)
-// ------------------------------------------------------------------------------------------
-__global__ void qqq_probe_mfma16_kernel(const v4i* a, const v4i* b, v4i* out) {
-  const int l = threadIdx.x;
-  v4i acc = {0, 0, 0, 0};
-  acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[l], b[l], acc, 0, 0, 0);
-  out[l] = acc;
-}
-__global__ void qqq_probe_mfma32_kernel(const v4i* a, const v4i* b, v16i* out) {
-  const int l = threadIdx.x;
-  v16i acc;
+__global__ __launch_bounds__(128) void qqq_pack_int4_kernel(const int8_t* __restrict__ codes,
+                                                            unsigned* __restrict__ B, const int N,
+                                                            const int grouped) {
+  __shared__ __attribute__((aligned(8))) int8_t tile[16][64];
+  const int tid = threadIdx.x, ng = blockIdx.x, kt = blockIdx.y;
+  *reinterpret_cast<uint2*>(&tile[tid >> 3][(tid & 7) * 8]) = *reinterpret_cast<const uint2*>(
+      codes + (size_t)(16 * kt + (tid >> 3)) * N + 64 * ng + (tid & 7) * 8);
+  __syncthreads();
+  const int c = tid >> 4, kq = (tid >> 2) & 3, jt = tid & 3;
+  unsigned w = 0;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0;
-  acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[l], b[l], acc, 0, 0, 0);
-  out[l] = acc;
-}
-// Read-bandwidth probe: every workgroup (512 threads, UNR independent 16-byte loads in flight per thread) streams
-// `bytes_per_wg` bytes starting at src + wg_stride * blockIdx.x, `reps` times, and folds them into one word.
-// wg_stride == 0: all workgroups read the same L2-resident window (per-CU L2 -> L1 fill rate);
-// wg_stride == bytes_per_wg: disjoint windows (HBM / Infinity-Cache streaming rate).
-template <int UNR>
-__global__ __launch_bounds__(512) void qqq_probe_fill_kernel(const v4u* __restrict__ src, const size_t wg_stride,
-                                                             const size_t bytes_per_wg, const int reps,
-                                                             unsigned* __restrict__ sink) {
-  const v4u* p = reinterpret_cast<const v4u*>(reinterpret_cast<const unsigned char*>(src) + wg_stride * blockIdx.x);
-  const size_t nvec = bytes_per_wg / 16;
-  v4u acc = {0, 0, 0, 0};
-  for (int r = 0; r < reps; ++r)
-    for (size_t i = threadIdx.x; i + (UNR - 1) * 512 < nvec; i += UNR * 512) {
-      v4u v[UNR];
-#pragma unroll
-      for (int u = 0; u < UNR; ++u) v[u] = p[i + u * 512];
-#pragma unroll
-      for (int u = 0; u < UNR; ++u) acc ^= v[u];
-    }
-  if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345u) sink[0] = 1;  // keep the loads alive
+  for (int p = 0; p < 8; ++p) {
+    int b, r;
+    qqq_nibble_coords(p, grouped != 0, b, r);
+    w |= ((unsigned)tile[4 * kq + r][16 * jt + 8 * b + c] & 0xFu) << (4 * p);
+  }
+  B[(size_t)kt * (2 * (size_t)N) + 128 * ng + tid] = w;
 }
 
-__global__ void qqq_probe_glds_kernel(const v4u* src, const int* perm, v4u* dst) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2048];
-  const int l = threadIdx.x;
-  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
-  // same helper the tiled kernel uses; destination deliberately not at the start of the array
-  glds16(src + perm[l], lds_base + 1024);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+__global__ __launch_bounds__(128) void qqq_unpack_int4_kernel(const unsigned* __restrict__ B,
+                                                              int8_t* __restrict__ codes, const int N,
+                                                              const int grouped) {
+  __shared__ __attribute__((aligned(8))) int8_t tile[16][64];
+  const int tid = threadIdx.x, ng = blockIdx.x, kt = blockIdx.y;
+  const unsigned w = B[(size_t)kt * (2 * (size_t)N) + 128 * ng + tid];
+  const int c = tid >> 4, kq = (tid >> 2) & 3, jt = tid & 3;
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    int b, r;
+    qqq_nibble_coords(p, grouped != 0, b, r);
+    const int u = (int)((w >> (4 * p)) & 0xFu);
+    tile[4 * kq + r][16 * jt + 8 * b + c] = (int8_t)((grouped || u < 8) ? u : u - 16);
+  }
   __syncthreads();
-  dst[l] = reinterpret_cast<const v4u*>(lds + 1024)[l];
+  *reinterpret_cast<uint2*>(codes + (size_t)(16 * kt + (tid >> 3)) * N + 64 * ng + (tid & 7) * 8) =
+      *reinterpret_cast<const uint2*>(&tile[tid >> 3][(tid & 7) * 8]);
 }
 
 

@@ -173,9 +173,6 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * (2 / NB) * 64) void 
   auto issue_loads = [&](const int kb, const int buf, const int part = 0, const int nparts = 1) {
     const unsigned char* wb = B + (size_t)(kb * 8) * rowbytes;
     const unsigned char* xb = Abase + (size_t)kb * 128;
-#if defined(QQQ_ABLATE) && (QQQ_ABLATE & 2)  // ablation: no global->LDS traffic
-    if (kb >= 0) return;
-#endif
     if constexpr (GLDS) {
       const unsigned st = lds_base + buf * STAGE + wave * 1024;
       const int lo = (WPT + XPT) * part / nparts, hi = (WPT + XPT) * (part + 1) / nparts;
@@ -224,17 +221,6 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * (2 / NB) * 64) void 
     v4i xop[MTW];
   };
   auto read_frag = [&](const unsigned char* st, const int t, Frag& f) {
-#if defined(QQQ_ABLATE) && (QQQ_ABLATE & 1)  // ablation: no LDS fragment reads
-    if (t >= 0) {
-#pragma unroll
-      for (int kq = 0; kq < 4; ++kq)
-#pragma unroll
-        for (int jj = 0; jj < JW; ++jj) asm volatile("" : "+v"(f.wq[kq][jj]));
-#pragma unroll
-      for (int mt = 0; mt < MTW; ++mt) asm volatile("" : "+v"(f.xop[mt]));
-      return;
-    }
-#endif
 #pragma unroll
     for (int kq = 0; kq < 4; ++kq) {
       const unsigned char* p = st + wrd[kq] + t * 4096;
@@ -268,10 +254,6 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * (2 / NB) * 64) void 
 #pragma unroll
       for (int kq = 0; kq < 4; ++kq) {
         const unsigned q = f.wq[kq][jj];
-#if defined(QQQ_ABLATE) && (QQQ_ABLATE & 4)  // ablation: no unpack VALU
-#pragma unroll
-        for (int bi = 0; bi < NB; ++bi) o.a[jj][bi][kq] = (int)q;
-#else
         if constexpr (NB == 2) {
           int w0, w1;
           unpack_pair<GROUPED>(q, sb0, sb1, w0, w1);
@@ -282,7 +264,6 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * (2 / NB) * 64) void 
         } else {
           o.a[jj][0][kq] = (int)((q << (4 * bsel)) & QQQ_NIB_MASK);
         }
-#endif
       }
     }
   };
@@ -358,21 +339,6 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * (2 / NB) * 64) void 
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NL > 63 ? 63 : 3 * NL) : "memory");
       }
     };
-#ifdef QQQ_TRACE
-    int tr_n = 0;
-    auto stamp = [&](int tag) {
-      if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && C && tr_n < 400) {  // C is idle when ksplit == 1
-        const unsigned long long tm = __builtin_readcyclecounter();
-        C[(wave * 400 + tr_n) * 4 + 0] = tag;
-        C[(wave * 400 + tr_n) * 4 + 1] = (int)(tm & 0xffffffffu);
-        C[(wave * 400 + tr_n) * 4 + 2] = (int)(tm >> 32);
-        ++tr_n;
-      }
-    };
-#define QQQ_STAMP(x) stamp(x)
-#else
-#define QQQ_STAMP(x)
-#endif
     const int nkb = kb_end - kb_begin;
     if constexpr (CONTPIPE) {
       // ---- continuous fragment pipeline over a 3-stage DMA ring.
@@ -439,20 +405,14 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * (2 / NB) * 64) void 
         const unsigned char* stn = has_next ? smem + ((i + 1) % 3) * STAGE : st;  // redirect past-the-end reads
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          QQQ_STAMP(0 + t);
-          if (t == 2) {
-            if (has_next) {
-              wait_younger(0);  // this wave's DMA of stage i+1 (the only one in flight) has landed
-              QQQ_STAMP(10);
-              __syncthreads();  // ... and everybody else's
-              QQQ_STAMP(11);
-            }
-            QQQ_STAMP(12);
+          if (t == 2 && has_next) {
+            wait_younger(0);  // this wave's DMA of stage i+1 (the only one in flight) has landed
+            __syncthreads();  // ... and everybody else's
           }
           {
             // DMA issue of a stage spread over the 3 k-steps behind the barrier (2 of the wave's 6 instructions
             // each): a burst of all 8 waves x 6 KB right behind the barrier overruns the address pipe (~30
-            // cycles per 1 KB instruction, measured with QQQ_TRACE), and an in-order wave stuck in VMEM issue
+            // cycles per 1 KB instruction, measured with s_memtime stamps), and an in-order wave stuck in VMEM issue
             // cannot issue its MFMAs either.  -3 % cycles, 1-3 % time on real data.
             constexpr int SPREAD = 3;
             const int part = (t + 2) & 3;  // t=2 -> 0, t=3 -> 1, t=0 -> 2, t=1 -> 3
@@ -466,7 +426,6 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * (2 / NB) * 64) void 
           if constexpr (GROUPED)
             if (t == 3) sc_cur = *reinterpret_cast<const hsc*>(stn + scrd);  // scales of the block being unpacked
           __builtin_amdgcn_sched_barrier(0);
-          QQQ_STAMP(20 + t);
           // hand-interleaved issue order: one MFMA of step u, then the unpack of one packed word of step
           // u+1 (hipcc otherwise issues the 8 MFMAs back to back and leaves the VALU work uncovered)
           constexpr int NM = MTW * JW * NB;  // MFMAs per step
@@ -558,7 +517,6 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * (2 / NB) * 64) void 
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           // ---------------- LOAD phase ----------------
-          QQQ_STAMP(0 + t);
           if (t == 0) {
             if (i + 2 < nkb) issue_loads(kb_begin + i + 2, (i + 2) % 3);
             if constexpr (GROUPED) sc_cur = *reinterpret_cast<const hsc*>(st + scrd);
@@ -569,22 +527,13 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * (2 / NB) * 64) void 
           } else if (i + 1 < nkb) {
             read_frag(stn, 0, fr[0]);
           }
-          QQQ_STAMP(10 + t);
           unpack_frag(fr[t & 1], ops);
-          QQQ_STAMP(20 + t);
           phase_barrier();
-          QQQ_STAMP(30 + t);
           // ---------------- MFMA phase ----------------
-#ifndef QQQ_NO_SETPRIO
           __builtin_amdgcn_s_setprio(1);  // the partner wave on this SIMD is in its LOAD phase: MFMA issue first
-#endif
           mfma_ops(ops, fr[t & 1]);
-#ifndef QQQ_NO_SETPRIO
           __builtin_amdgcn_s_setprio(0);
-#endif
-          QQQ_STAMP(40 + t);
           phase_barrier();
-          QQQ_STAMP(50 + t);
         }
       }
       if (nkb > 0 && !late) phase_barrier();  // both groups execute the same number of barriers

@@ -38,6 +38,9 @@
 // byte) and pack() has pre-divided s_channel by 16; per-group weights are re-quantised to int8
 // with ONE packed-fp16 FMA exactly like dequant_per_group (csrc/qqq_gemm.cu:167-210).
 
+#include <thread>
+#include <vector>
+
 #include "qqq_common.hip.h"
 #include "qqq_stream.hip.h"
 #include "qqq_column.hip.h"
@@ -478,6 +481,13 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
     snprintf(g_err, sizeof(g_err), "null pointer argument");
     return QQQ_ERR_ARG;
   }
+  // the kernels use 16-byte vector / LDS-DMA accesses on A, B, C, D, bias, acc_out, s3 and 8-byte loads on s2
+  if ((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)D | (uintptr_t)bias | (uintptr_t)acc_out |
+        (groupsize != -1 ? (uintptr_t)s3 : 0)) & 15) != 0 ||
+      (((uintptr_t)s2) & 7) != 0 || (((uintptr_t)s1 | (uintptr_t)workspace) & 3) != 0) {
+    snprintf(g_err, sizeof(g_err), "misaligned pointer argument (A/B/C/D/s3/bias/acc_out: 16 bytes, s2: 8, s1/workspace: 4)");
+    return QQQ_ERR_ARG;
+  }
   const bool grouped = groupsize != -1;
   qqq_tune_t t;
   memset(&t, 0, sizeof(t));
@@ -504,6 +514,10 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
   DeviceGuard guard(dev);
   hipError_t e = hipSuccess;
   bool reduce_launch;
+  if ((pl.kernel == 1 || pl.kernel == 3) && (M + 16 * pl.mt - 1) / (16 * pl.mt) > 65535) {
+    snprintf(g_err, sizeof(g_err), "m=%d exceeds the grid of the small-m kernels (forced by tune)", M);
+    return QQQ_ERR_ARG;
+  }
   if (pl.kernel == 3) {
     e = launch_column(a, grouped, pl.mt, pl.pf, pl.ksplit);
     if (e != hipSuccess) return fail_hip(e, "qqq_column_kernel launch");
@@ -541,8 +555,8 @@ extern "C" int qqq_dynamic_quant(const void* x, void* xq, void* s1, int m, int k
                                  void* stream) {
   g_err[0] = 0;
   if (m == 0 || k == 0) return QQQ_OK;
-  if (!x || !xq || !s1 || (k % 8) != 0) {
-    snprintf(g_err, sizeof(g_err), "qqq_dynamic_quant: bad argument (k must be a multiple of 8)");
+  if (!x || !xq || !s1 || (k % 8) != 0 || ((uintptr_t)x & 15) != 0 || ((uintptr_t)xq & 7) != 0 || ((uintptr_t)s1 & 3) != 0) {
+    snprintf(g_err, sizeof(g_err), "qqq_dynamic_quant: bad argument (k must be a multiple of 8, x 16-byte / xq 8-byte aligned)");
     return QQQ_ERR_ARG;
   }
   DeviceGuard guard(dev);
@@ -580,109 +594,86 @@ extern "C" int qqq_quantlinear_forward(const void* x, void* xq, void* s1, const 
                           nullptr, nullptr, bias);
 }
 
-extern "C" int qqq_add_bias(void* D, const void* bias, int m, int n, int dev, void* stream) {
-  g_err[0] = 0;
-  if (m == 0 || n == 0) return QQQ_OK;
-  if (!D || !bias || (n % 8) != 0) {
-    snprintf(g_err, sizeof(g_err), "qqq_add_bias: bad argument");
-    return QQQ_ERR_ARG;
-  }
-  DeviceGuard guard(dev);
-  const long long total = (long long)m * (n / 8);
-  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-  hipLaunchKernelGGL(qqq_add_bias_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     static_cast<_Float16*>(D), static_cast<const _Float16*>(bias), total, n / 8);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail_hip(e, "qqq_add_bias_kernel launch");
-  return QQQ_OK;
-}
-
-extern "C" int qqq_probe_mfma(int kind, const void* a, const void* b, void* out, int dev,
-                              void* stream) {
-  DeviceGuard guard(dev);
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  if (kind == 16)
-    hipLaunchKernelGGL(qqq_probe_mfma16_kernel, dim3(1), dim3(64), 0, st, static_cast<const v4i*>(a),
-                       static_cast<const v4i*>(b), static_cast<v4i*>(out));
-  else if (kind == 32)
-    hipLaunchKernelGGL(qqq_probe_mfma32_kernel, dim3(1), dim3(64), 0, st, static_cast<const v4i*>(a),
-                       static_cast<const v4i*>(b), static_cast<v16i*>(out));
-  else
-    return QQQ_ERR_ARG;
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail_hip(e, "probe launch");
-  return QQQ_OK;
-}
-
-extern "C" int qqq_probe_fill(const void* src, size_t wg_stride, size_t bytes_per_wg, int nwg, int reps, int unroll,
-                              void* sink, int dev, void* stream, float* ms_out) {
-  DeviceGuard guard(dev);
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  hipEvent_t e0, e1;
-  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail_hip(hipGetLastError(), "event");
-  auto launch = [&]() {
-    if (unroll >= 8)
-      hipLaunchKernelGGL(qqq_probe_fill_kernel<8>, dim3(nwg), dim3(512), 0, st, static_cast<const v4u*>(src), wg_stride,
-                         bytes_per_wg, reps, static_cast<unsigned*>(sink));
-    else
-      hipLaunchKernelGGL(qqq_probe_fill_kernel<2>, dim3(nwg), dim3(512), 0, st, static_cast<const v4u*>(src), wg_stride,
-                         bytes_per_wg, reps, static_cast<unsigned*>(sink));
-  };
-  launch();  // warm-up
-  (void)hipEventRecord(e0, st);
-  launch();
-  (void)hipEventRecord(e1, st);
-  hipError_t e = hipStreamSynchronize(st);
-  if (e == hipSuccess) e = hipEventElapsedTime(ms_out, e0, e1);
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  if (e != hipSuccess) return fail_hip(e, "qqq_probe_fill");
-  return QQQ_OK;
-}
-
-extern "C" int qqq_probe_glds(const void* src, const void* perm, void* dst, int dev, void* stream) {
-  DeviceGuard guard(dev);
-  hipLaunchKernelGGL(qqq_probe_glds_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream),
-                     static_cast<const v4u*>(src), static_cast<const int*>(perm), static_cast<v4u*>(dst));
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail_hip(e, "probe launch");
-  return QQQ_OK;
-}
-
-extern "C" int qqq_bench_gemm(const void* A, const void* const* Bs, int nB, void* C, void* D,
-                              const void* s1, const void* s2, const void* s3, int prob_m, int prob_n,
-                              int prob_k, void* workspace, int groupsize, int dev, void* stream,
-                              int max_par, const qqq_tune_t* tune, int iters, float* ms_each) {
-  g_err[0] = 0;
-  if (iters <= 0 || nB <= 0 || !Bs || !ms_each) return QQQ_ERR_ARG;
-  DeviceGuard guard(dev);
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  hipEvent_t* ev = new hipEvent_t[2 * iters];
-  int made = 0, rc = QQQ_OK;
-  for (; made < 2 * iters; ++made)
-    if (hipEventCreate(&ev[made]) != hipSuccess) {
-      rc = fail_hip(hipGetLastError(), "hipEventCreate");
-      break;
-    }
-  if (rc == QQQ_OK) {
-    for (int i = 0; i < iters && rc == QQQ_OK; ++i) {
-      (void)hipEventRecord(ev[2 * i], st);
-      rc = qqq_w4a8_gemm_ex(A, Bs[i % nB], C, D, s1, s2, s3, prob_m, prob_n, prob_k, workspace, groupsize,
-                            dev, stream, -1, -1, -1, max_par, tune, nullptr, nullptr);
-      (void)hipEventRecord(ev[2 * i + 1], st);
-    }
-    hipError_t e = hipStreamSynchronize(st);
-    if (e != hipSuccess && rc == QQQ_OK) rc = fail_hip(e, "hipStreamSynchronize");
-    if (rc == QQQ_OK)
-      for (int i = 0; i < iters; ++i) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]) != hipSuccess) ms = -1.f;
-        ms_each[i] = ms;
+// ---- int4 packer / unpacker: device buffers go through the HIP kernels, host buffers through the
+// same closed form on the CPU (a thread per slice of k-tiles).  Offline format conversion, not part of the GEMM path.
+template <bool PACK>
+static void pack_host_range(const int8_t* codes_in, int8_t* codes_out, const unsigned* B_in, unsigned* B_out, int n,
+                            int grouped, int kt0, int kt1) {
+  int pb[8], pr[8];
+  for (int p = 0; p < 8; ++p) qqq_nibble_coords(p, grouped != 0, pb[p], pr[p]);
+  const size_t row_words = 2 * (size_t)n;
+  for (int kt = kt0; kt < kt1; ++kt)
+    for (int ng = 0; ng < n / 64; ++ng)
+      for (int wi = 0; wi < 128; ++wi) {
+        const int c = wi >> 4, kq = (wi >> 2) & 3, jt = wi & 3;
+        const size_t widx = (size_t)kt * row_words + 128 * (size_t)ng + wi;
+        if constexpr (PACK) {
+          unsigned w = 0;
+          for (int p = 0; p < 8; ++p)
+            w |= ((unsigned)codes_in[(size_t)(16 * kt + 4 * kq + pr[p]) * n + 64 * ng + 16 * jt + 8 * pb[p] + c] & 0xFu)
+                 << (4 * p);
+          B_out[widx] = w;
+        } else {
+          const unsigned w = B_in[widx];
+          for (int p = 0; p < 8; ++p) {
+            const int u = (int)((w >> (4 * p)) & 0xFu);
+            codes_out[(size_t)(16 * kt + 4 * kq + pr[p]) * n + 64 * ng + 16 * jt + 8 * pb[p] + c] =
+                (int8_t)((grouped || u < 8) ? u : u - 16);
+          }
+        }
       }
+}
+
+template <bool PACK>
+static int pack_entry(const void* src, void* dst, int k, int n, int grouped, int on_device, int dev, void* stream) {
+  g_err[0] = 0;
+  if (k == 0 || n == 0) return QQQ_OK;
+  if (!src || !dst || k < 0 || n < 0 || (k % 16) != 0 || (n % 64) != 0 || (k / 16) > 65535 ||
+      ((uintptr_t)src & 7) != 0 || ((uintptr_t)dst & 7) != 0) {
+    snprintf(g_err, sizeof(g_err), "qqq_%spack_int4: need k %% 16 == 0 (k <= 1048560), n %% 64 == 0, 8-byte aligned buffers",
+             PACK ? "" : "un");
+    return QQQ_ERR_ARG;
   }
-  for (int i = 0; i < made; ++i) (void)hipEventDestroy(ev[i]);
-  delete[] ev;
-  return rc;
+  if (on_device) {
+    DeviceGuard guard(dev);
+    const dim3 grid(n / 64, k / 16);
+    if constexpr (PACK)
+      hipLaunchKernelGGL(qqq_pack_int4_kernel, grid, dim3(128), 0, static_cast<hipStream_t>(stream),
+                         static_cast<const int8_t*>(src), static_cast<unsigned*>(dst), n, grouped);
+    else
+      hipLaunchKernelGGL(qqq_unpack_int4_kernel, grid, dim3(128), 0, static_cast<hipStream_t>(stream),
+                         static_cast<const unsigned*>(src), static_cast<int8_t*>(dst), n, grouped);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, PACK ? "qqq_pack_int4_kernel launch" : "qqq_unpack_int4_kernel launch");
+    return QQQ_OK;
+  }
+  const int kts = k / 16;
+  unsigned hw = std::thread::hardware_concurrency();
+  int nthr = (int)(hw ? hw : 1);
+  if (nthr > 32) nthr = 32;
+  if ((long long)k * n < (1 << 20)) nthr = 1;
+  if (nthr > kts) nthr = kts;
+  auto work = [&](int t) {
+    const int kt0 = (int)((long long)kts * t / nthr), kt1 = (int)((long long)kts * (t + 1) / nthr);
+    pack_host_range<PACK>(static_cast<const int8_t*>(src), static_cast<int8_t*>(dst), static_cast<const unsigned*>(src),
+                          static_cast<unsigned*>(dst), n, grouped, kt0, kt1);
+  };
+  if (nthr == 1) {
+    work(0);
+  } else {
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nthr; ++t) pool.emplace_back(work, t);
+    for (auto& th : pool) th.join();
+  }
+  return QQQ_OK;
+}
+
+extern "C" int qqq_pack_int4(const void* codes, void* B, int k, int n, int grouped, int on_device, int dev, void* stream) {
+  return pack_entry<true>(codes, B, k, n, grouped, on_device, dev, stream);
+}
+
+extern "C" int qqq_unpack_int4(const void* B, void* codes, int k, int n, int grouped, int on_device, int dev, void* stream) {
+  return pack_entry<false>(B, codes, k, n, grouped, on_device, dev, stream);
 }
 
 extern "C" int qqq_amd_abi_version(void) { return QQQ_AMD_ABI_VERSION; }

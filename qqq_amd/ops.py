@@ -8,6 +8,7 @@ the same messages.  It is also registered as the torch custom op `qqq_amd::qqq_g
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional
 
 import torch
@@ -16,6 +17,7 @@ from . import _lib
 
 ERR_PROB_SHAPE = 1
 ERR_KERN_SHAPE = 2
+_FORCE_DISPATCHER = os.environ.get("QQQ_AMD_FORCE_DISPATCHER", "0") == "1"
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -130,17 +132,27 @@ def _qqq_gemm_bias_op(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, D: torc
     qqq_gemm_ex(A, B, C, D, s1, s2, s3, workspace, -1, -1, -1, max_par, bias=bias)
 
 
-def _compiling() -> bool:
-    # Under torch.compile the calls must go through the registered custom ops (no graph break, fake-tensor
-    # propagation).  In eager mode the dispatcher round trip of a Python custom op costs ~9 us per call -- more
-    # than a decode GEMM on a 4096x4096 layer takes on the GPU (tools/host_overhead.py) -- so eager calls go
-    # straight to the ctypes binding.
-    return torch.compiler.is_compiling()
+_PLAIN = (torch.Tensor, torch.nn.Parameter)
+
+
+def _compiling(*tensors) -> bool:
+    # Under torch.compile / make_fx / FakeTensorMode / torch.export / any TorchDispatchMode, or with tensor
+    # subclasses among the arguments, the calls must go through the registered custom ops (no graph break,
+    # fake-tensor propagation, visible to dispatch-based tooling).  For plain eager tensors the dispatcher round
+    # trip of a Python custom op costs ~9 us per call -- more than a decode GEMM on a 4096x4096 layer takes on
+    # the GPU (tools/host_overhead.py) -- so those calls go straight to the ctypes binding.
+    # QQQ_AMD_FORCE_DISPATCHER=1 forces the dispatcher path everywhere.
+    if torch.compiler.is_compiling() or _FORCE_DISPATCHER or torch._C._len_torch_dispatch_stack() > 0:
+        return True
+    for t in tensors:
+        if t is not None and type(t) not in _PLAIN:
+            return True
+    return False
 
 
 def qqq_gemm_bias(A, B, C, D, s1, s2, s3, workspace, bias, max_par=16) -> None:
     """qqq_gemm + the reference's `D + self.bias` (qlinear_marlin.py:287) fused into the epilogue."""
-    if _compiling():
+    if _compiling(A, B, C, D, s1, s2, s3, workspace, bias):
         _qqq_gemm_bias_op(A, B, C, D, s1, s2, s3, workspace, bias, max_par)
     else:
         qqq_gemm_ex(A, B, C, D, s1, s2, s3, workspace, -1, -1, -1, max_par, bias=bias)
@@ -148,7 +160,7 @@ def qqq_gemm_bias(A, B, C, D, s1, s2, s3, workspace, bias, max_par=16) -> None:
 
 def qqq_gemm(A, B, C, D, s1, s2, s3, workspace, thread_k=-1, thread_n=-1, sms=-1, max_par=8) -> None:
     """Drop-in for `QQQ._CUDA.qqq_gemm` (qqq_gemm.h:23-36): writes fp16 `D` in place, returns None."""
-    if _compiling():
+    if _compiling(A, B, C, D, s1, s2, s3, workspace):
         _qqq_gemm_op(A, B, C, D, s1, s2, s3, workspace, thread_k, thread_n, sms, max_par)
     else:
         _qqq_gemm_impl(A, B, C, D, s1, s2, s3, workspace, thread_k, thread_n, sms, max_par)
@@ -173,16 +185,18 @@ def marlin_qqq_gemm(a, b_q_weight, s_tok, s_ch, s_group, workspace, size_m, size
 
 def _dynamic_quant_impl(x: torch.Tensor):
     L = _lib.lib()
-    if x.dtype != torch.float16 or not x.is_cuda or x.dim() != 2:
-        raise RuntimeError("dynamic_quant: expected a 2-D fp16 tensor on the GPU (there is no CPU path)")
-    x = x.contiguous()
-    m, k = x.shape
+    if x.dtype != torch.float16 or not x.is_cuda or x.dim() < 1:
+        raise RuntimeError("dynamic_quant: expected an fp16 tensor on the GPU (there is no CPU path)")
+    # any rank, like the reference method (max over the last dim with keepdim, qlinear_marlin.py:265-268)
+    k = x.shape[-1]
+    x2 = x.reshape(-1, k).contiguous()
+    m = x2.shape[0]
     xq = torch.empty((m, k), dtype=torch.int8, device=x.device)
     s1 = torch.empty((m, 1), dtype=torch.float32, device=x.device)
-    err = L.qqq_dynamic_quant(_ptr(x), _ptr(xq), _ptr(s1), m, k, x.device.index or 0, _stream_for(x))
+    err = L.qqq_dynamic_quant(_ptr(x2), _ptr(xq), _ptr(s1), m, k, x.device.index or 0, _stream_for(x))
     if err:
         raise RuntimeError(f"qqq_amd: dynamic_quant error {err}: {_lib.last_error()}")
-    return xq, s1
+    return xq.reshape(x.shape), s1.reshape(x.shape[:-1] + (1,))
 
 
 @torch.library.custom_op("qqq_amd::dynamic_quant", mutates_args=())
@@ -192,28 +206,22 @@ def _dynamic_quant_op(x: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
 
 @_dynamic_quant_op.register_fake
 def _(x):
-    return x.new_empty(x.shape, dtype=torch.int8), x.new_empty((x.shape[0], 1), dtype=torch.float32)
+    return x.new_empty(x.shape, dtype=torch.int8), x.new_empty(x.shape[:-1] + (1,), dtype=torch.float32)
 
 
 def dynamic_quant(x: torch.Tensor):
-    """Fused replacement of QuantLinear.dynamic_quant (qlinear_marlin.py:265-268): (int8 [m,k], f32 [m,1])."""
-    return _dynamic_quant_op(x) if _compiling() else _dynamic_quant_impl(x)
-
-
-def add_bias_(D: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
-    L = _lib.lib()
-    m, n = D.shape
-    err = L.qqq_add_bias(_ptr(D), _ptr(bias), m, n, D.device.index or 0, _stream_for(D))
-    if err:
-        raise RuntimeError(f"qqq_amd: add_bias error {err}: {_lib.last_error()}")
-    return D
+    """Fused replacement of QuantLinear.dynamic_quant (qlinear_marlin.py:265-268) for an fp16 tensor of any rank:
+    (int8 x.shape, f32 x.shape[:-1] + (1,)).  Deviations from the reference expression: an all-zero row quantises to
+    0 with scale 0 (reference: 0/0 = NaN -> int8, undefined), and the scale is the torch-GPU evaluation
+    fp16(amax * (1/127)) (a CPU run of the reference differs by one fp16 ulp of the scale on a few rows)."""
+    return _dynamic_quant_op(x) if _compiling(x) else _dynamic_quant_impl(x)
 
 
 def quantlinear_forward(x: torch.Tensor, B, C, s2, s3, workspace, bias=None, max_par: int = 16) -> torch.Tensor:
     """QuantLinear.forward (qlinear_marlin.py:270-288) for a 2-D fp16 input in ONE binding call: fused dynamic int8
     quantisation + W4A8 GEMM (+ fp16 bias).  The buffers are a module's own (qlinear.QuantLinear): only the cheap
     checks are made here.  Under torch.compile the two registered custom ops are used instead."""
-    if _compiling():
+    if _compiling(x, B, C, s2, s3, workspace, bias):
         xq, s1 = _dynamic_quant_op(x)
         D = torch.empty((x.shape[0], C.size(1)), dtype=torch.float16, device=x.device)
         if bias is not None:
@@ -228,6 +236,22 @@ def quantlinear_forward(x: torch.Tensor, B, C, s2, s3, workspace, bias=None, max
     if B.numel() != (k // 16) * (n * 2) or B.device != x.device:
         raise RuntimeError("quantlinear_forward: B must be the packed [k/16, 2n] weight on x's device")
     groupsize = -1 if s3.numel() == 0 else k // s3.size(0)
+    # the cheap subset of _check_common: everything the kernels would read as raw bits
+    dev = x.device
+    if (B.dtype != torch.int32 or C.dtype != torch.int32 or workspace.dtype != torch.int32 or s2.dtype != torch.float32
+            or C.device != dev or s2.device != dev or workspace.device != dev
+            or not (B.is_contiguous() and C.is_contiguous() and s2.is_contiguous() and workspace.is_contiguous())):
+        raise RuntimeError("quantlinear_forward: expected contiguous int32 B / C / workspace and float32 s2 on x's device")
+    if s2.numel() != n or C.size(0) < max_par * 64 or workspace.numel() < n // 128 * max_par:
+        raise RuntimeError(f"quantlinear_forward: s2 needs n={n} elements, C max_par*64={max_par * 64} rows, "
+                           f"workspace at least {n // 128 * max_par} entries")
+    if s3.numel() and (s3.dtype != torch.float16 or s3.device != dev or not s3.is_contiguous()
+                       or groupsize * s3.size(0) != k or s3.numel() != s3.size(0) * n):
+        raise RuntimeError("quantlinear_forward: s3 must be a contiguous fp16 [k/groupsize, n] tensor on x's device")
+    if bias is not None and (bias.dtype != torch.float16 or bias.numel() != n or bias.device != dev
+                             or not bias.is_contiguous()):
+        raise RuntimeError(f"quantlinear_forward: bias must be a contiguous fp16 [n] tensor on x's device "
+                           f"(got {bias.dtype}, {tuple(bias.shape)}, {bias.device})")
     xq = torch.empty((m, k), dtype=torch.int8, device=x.device)
     s1 = torch.empty((m, 1), dtype=torch.float32, device=x.device)
     D = torch.empty((m, n), dtype=torch.float16, device=x.device)

@@ -1,4 +1,4 @@
-"""Vectorised packer / unpacker for the Marlin/QQQ int4 layout (torch; runs on CPU or GPU).
+"""Packer / unpacker for the Marlin/QQQ int4 layout (native: HIP kernel on device tensors, threaded C++ on host tensors).
 
 Closed form of what QuantLinear.pack produces with python loops (qlinear_marlin.py:147-176, :228-248):
 word B[kt][128*ng + 16*c + 4*kq + jt] holds k = 16*kt + 4*kq + r, n = 64*ng + 16*jt + 8*b + c;
@@ -8,42 +8,43 @@ from __future__ import annotations
 
 import torch
 
-_B_OF_P = {False: [1, 0, 1, 0, 1, 0, 1, 0], True: [0, 0, 1, 1, 0, 0, 1, 1]}
-_R_OF_P = {False: [0, 0, 1, 1, 2, 2, 3, 3], True: [0, 2, 0, 2, 1, 3, 1, 3]}
+from . import _lib
+
+
+def _native(fn_name: str, src: torch.Tensor, dst: torch.Tensor, K: int, N: int, grouped: bool) -> None:
+    L = _lib.lib()
+    on_dev = src.is_cuda
+    stream = torch.cuda.current_stream(src.device).cuda_stream if on_dev else None
+    rc = getattr(L, fn_name)(src.data_ptr(), dst.data_ptr(), K, N, int(grouped), int(on_dev),
+                             (src.device.index or 0) if on_dev else 0, stream)
+    if rc:
+        raise RuntimeError(f"qqq_amd: {fn_name} error {rc}: {_lib.last_error()}")
 
 
 def pack_codes(codes: torch.Tensor, grouped: bool) -> torch.Tensor:
-    """codes [K,N] integer (signed int4 per-channel / unsigned u per-group) -> int32 [K/16, 2N]."""
+    """codes [K,N] integer (signed int4 per-channel / unsigned u per-group) -> int32 [K/16, 2N], on codes' device.
+    Native: HIP kernel for device tensors, threaded C++ for host tensors (qqq_pack_int4, include/qqq_amd.h)."""
     K, N = codes.shape
-    assert K % 16 == 0 and N % 64 == 0
-    dev = codes.device
-    t = (codes.to(torch.int64) & 0xF).reshape(K // 16, 4, 4, N // 64, 4, 2, 8)  # kt,kq,r,ng,jt,b,c
-    t = t.permute(0, 3, 6, 1, 4, 5, 2)  # kt,ng,c,kq,jt,b,r
-    bi = torch.tensor(_B_OF_P[grouped], device=dev)
-    ri = torch.tensor(_R_OF_P[grouped], device=dev)
-    nib = t[..., bi, ri]  # kt,ng,c,kq,jt,p
-    shifts = 4 * torch.arange(8, device=dev, dtype=torch.int64)
-    w = (nib << shifts).sum(-1)
-    w = torch.where(w >= 2**31, w - 2**32, w).to(torch.int32)
-    return w.reshape(K // 16, 2 * N).contiguous()
+    if K % 16 or N % 64:
+        raise ValueError("pack_codes: K must be a multiple of 16 and N of 64")
+    src = codes.to(torch.int8).contiguous()
+    out = torch.empty((K // 16, 2 * N), dtype=torch.int32, device=codes.device)
+    if K and N:
+        _native("qqq_pack_int4", src, out, K, N, grouped)
+    return out
 
 
 def unpack_codes(B: torch.Tensor, grouped: bool) -> torch.Tensor:
-    """int32 [K/16, 2N] -> int8 codes [K,N]."""
+    """int32 [K/16, 2N] -> int8 codes [K,N] (inverse of pack_codes; qqq_unpack_int4)."""
     KT, W = B.shape
-    N = W // 2
-    dev = B.device
-    w = B.to(torch.int64) & 0xFFFFFFFF
-    shifts = 4 * torch.arange(8, device=dev, dtype=torch.int64)
-    nib = ((w.reshape(KT, N // 64, 8, 4, 4, 1) >> shifts) & 0xF)  # kt,ng,c,kq,jt,p
-    out = torch.empty((KT, N // 64, 8, 4, 4, 2, 4), dtype=torch.int64, device=dev)  # kt,ng,c,kq,jt,b,r
-    bi = torch.tensor(_B_OF_P[grouped], device=dev)
-    ri = torch.tensor(_R_OF_P[grouped], device=dev)
-    out[..., bi, ri] = nib
-    if not grouped:
-        out = torch.where(out >= 8, out - 16, out)
-    out = out.permute(0, 3, 6, 1, 4, 5, 2)  # kt,kq,r,ng,jt,b,c
-    return out.reshape(KT * 16, N).to(torch.int8).contiguous()
+    K, N = KT * 16, W // 2
+    if W % 128:
+        raise ValueError("unpack_codes: B must be [K/16, 2N] with N a multiple of 64")
+    src = B.to(torch.int32).contiguous()
+    out = torch.empty((K, N), dtype=torch.int8, device=B.device)
+    if K and N:
+        _native("qqq_unpack_int4", src, out, K, N, grouped)
+    return out
 
 
 def s_channel_stored_index(n: torch.Tensor) -> torch.Tensor:

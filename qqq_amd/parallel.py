@@ -1,12 +1,17 @@
 """M-sharded W4A8 GEMM across GPUs: one process per GPU, RCCL (torch.distributed "nccl") over xGMI.
 
-Rows of A / D are independent (the per-token scale s1[m] is row-local, the weights are shared), so
-rank r owns rows [r*M/P, (r+1)*M/P) and computes its shard of D against the fully REPLICATED packed
-weights; the only communication is one all-gather of the fp16 output shards (BASELINE config 5).
-The reference has no distributed code at all -- this is new, specified by north_star.
+Rows of A / D are independent (the per-token scale s1[m] is row-local, the weights are shared), so every rank
+computes a set of rows of D against the fully REPLICATED packed weights; the only communication is the all-gather of
+the fp16 output rows (BASELINE configs[4]).  The reference has no distributed code at all -- this is new,
+specified by north_star.
 
-xGMI is point-to-point, so the gather is chunk-pipelined: the local rows are cut into `chunks`
-pieces, chunk i is gathered on a side stream while chunk i+1 is still in the GEMM.
+Row ownership is chunk-cyclic: the M rows are cut into `chunks` super-blocks of world*w rows (w = ceil(M / (world *
+chunks))), and inside super-block c rank p owns the w rows starting at (c*world + p)*w.  Every super-block is then ONE
+contiguous [world*w, N] slab of the output in which rank p's piece sits at offset p*w -- exactly the layout of an
+in-place `all_gather_into_tensor` (no list of views, no staging copies), and super-block c can be gathered on a side
+stream while super-block c+1 is still in the GEMM (xGMI is point-to-point: 7 links x ~153 GB/s per GPU, so a shard
+takes about as long to move as to compute).  Only a ragged last super-block (M not a multiple of world*w)
+goes through a padded scratch slab, copied out on the communication stream -- the host never synchronises.
 """
 from __future__ import annotations
 
@@ -17,88 +22,106 @@ import torch.distributed as dist
 
 
 def shard_rows(M: int, world: int, rank: int) -> Tuple[int, int]:
-    """Balanced contiguous row partition: the first M % world ranks get one extra row."""
+    """Balanced contiguous row partition: the first M % world ranks get one extra row (chunks == 1 ownership is
+    `row_spans`, which pads instead; this helper remains for callers that want a plain balanced split)."""
     base, extra = divmod(M, world)
     start = rank * base + min(rank, extra)
     return start, start + base + (1 if rank < extra else 0)
 
 
-def chunk_bounds(rows: int, chunks: int) -> List[Tuple[int, int]]:
-    chunks = max(1, min(chunks, rows)) if rows > 0 else 1
+def pick_chunks(M: int, N: int, world: int) -> int:
+    """Chunks of the pipeline: a chunk must stay a LARGE-m GEMM (>= 1024 rows per rank: below that the GEMM loses more
+    efficiency than the overlap wins back, profiles/) -- so small shards go in one piece, big ones in up to 4."""
+    rows = -(-M // max(world, 1))
+    return max(1, min(4, rows // 1024))
+
+
+def row_spans(M: int, world: int, rank: int, chunks: int) -> List[Tuple[int, int]]:
+    """global row spans [start, end) owned by `rank`, one per super-block (possibly empty at the ragged end)"""
+    chunks = max(1, chunks)
+    w = -(-M // (world * chunks)) if M > 0 else 0
     out = []
-    for i in range(chunks):
-        a = (rows * i) // chunks
-        b = (rows * (i + 1)) // chunks
-        out.append((a, b))
+    for c in range(chunks):
+        s = min((c * world + rank) * w, M)
+        e = min(s + w, M)
+        out.append((s, e))
     return out
 
 
-class ShardedGemm:
-    """D_full[M,N] = all_gather_rows( gemm(A_local) ).
+def take_rows(t: torch.Tensor, spans: List[Tuple[int, int]]) -> torch.Tensor:
+    """the local rows of a replicated [M, ...] tensor, in span order, as one contiguous tensor"""
+    parts = [t[s:e] for (s, e) in spans if e > s]
+    if not parts:
+        return t[:0].contiguous()
+    return torch.cat(parts, dim=0) if len(parts) > 1 else parts[0].contiguous()
 
-    gemm_fn(a_rows, s1_rows, d_rows_out) computes one contiguous block of local rows in place
-    (the product passes a closure over qqq_amd.qqq_gemm; the CPU/gloo tests pass the oracle).
+
+class ShardedGemm:
+    """D_full[M,N] = all_gather_rows( gemm(A_local) ) with the chunk-cyclic row ownership of `row_spans`.
+
+    gemm_fn(a_rows, s1_rows, d_rows_out) computes one contiguous block of local rows in place (the product passes a
+    closure over qqq_amd.qqq_gemm; the CPU/gloo tests pass the oracle).  A_local / s1_local hold this rank's rows in
+    span order (`take_rows`).
     """
 
-    def __init__(self, gemm_fn: Callable, group: Optional[dist.ProcessGroup] = None, chunks: int = 2,
+    def __init__(self, gemm_fn: Callable, group: Optional[dist.ProcessGroup] = None, chunks: Optional[int] = None,
                  comm_stream: Optional["torch.cuda.Stream"] = None):
         self.gemm_fn = gemm_fn
         self.group = group
-        self.chunks = chunks
+        self.chunks = chunks  # None: pick_chunks(M, N, world) per call
         self.comm_stream = comm_stream
+        self._tail = None  # scratch slab of a ragged last super-block
+
+    def spans(self, M_total: int, N: int) -> List[Tuple[int, int]]:
+        world = dist.get_world_size(self.group)
+        chunks = self.chunks if self.chunks else pick_chunks(M_total, N, world)
+        return row_spans(M_total, world, dist.get_rank(self.group), chunks)
 
     def __call__(self, A_local: torch.Tensor, s1_local: torch.Tensor, M_total: int, N: int,
                  D_full: Optional[torch.Tensor] = None) -> torch.Tensor:
         world = dist.get_world_size(self.group)
         rank = dist.get_rank(self.group)
-        r0, r1 = shard_rows(M_total, world, rank)
-        rows = r1 - r0
-        assert A_local.shape[0] == rows, (A_local.shape, rows)
+        chunks = self.chunks if self.chunks else pick_chunks(M_total, N, world)
+        spans = row_spans(M_total, world, rank, chunks)
+        assert A_local.shape[0] == sum(e - s for s, e in spans), (A_local.shape, spans)
         dev = A_local.device
+        w = -(-M_total // (world * chunks)) if M_total > 0 else 0
         if D_full is None:
             D_full = torch.empty((M_total, N), dtype=torch.float16, device=dev)
-        even = (M_total % world == 0)
+        assert D_full.is_contiguous() and D_full.shape == (M_total, N)
+        if M_total == 0:
+            return D_full
         use_streams = dev.type == "cuda"
         comm = None
         if use_streams:
             comm = self.comm_stream or torch.cuda.Stream(device=dev)
             self.comm_stream = comm
-        max_rows = -(-M_total // world)
-        for (a, b) in chunk_bounds(max_rows if not even else rows, self.chunks):
-            # local compute of rows [a, b) of this rank's shard (clipped for the short ranks)
-            la, lb = min(a, rows), min(b, rows)
-            if lb > la:
-                self.gemm_fn(A_local[la:lb], s1_local[la:lb], D_full[r0 + la : r0 + lb])
-            outs = []
-            for p in range(world):
-                p0, p1 = shard_rows(M_total, world, p)
-                pa, pb = min(a, p1 - p0), min(b, p1 - p0)
-                outs.append((p0 + pa, p0 + pb))
-            if even:
-                views = [D_full[s:e] for (s, e) in outs]
-                src = D_full[r0 + la : r0 + lb]
-                self._all_gather(views, src, comm, use_streams)
+        off = 0
+        for c, (s, e) in enumerate(spans):
+            blk0 = c * world * w  # first row of super-block c
+            if blk0 >= M_total:
+                break  # nobody owns rows here
+            full = blk0 + world * w <= M_total
+            if full:
+                slab = D_full[blk0 : blk0 + world * w]
             else:
-                # ragged shards: gather fixed-size padded pieces, then copy the valid rows out
-                width = b - a
-                pad = torch.zeros((width, N), dtype=torch.float16, device=dev)
-                if lb > la:
-                    pad[: lb - la] = D_full[r0 + la : r0 + lb]
-                bufs = [torch.empty_like(pad) for _ in range(world)]
-                self._all_gather(bufs, pad, comm, use_streams)
-                if use_streams:
-                    comm.synchronize()
-                for p, (s, e) in enumerate(outs):
-                    if e > s and p != rank:
-                        D_full[s:e] = bufs[p][: e - s]
+                if self._tail is None or self._tail.shape != (world * w, N) or self._tail.device != dev:
+                    self._tail = torch.empty((world * w, N), dtype=torch.float16, device=dev)
+                slab = self._tail
+            piece = slab[rank * w : (rank + 1) * w]  # in-place all-gather: this rank's piece inside the output slab
+            if e > s:
+                self.gemm_fn(A_local[off : off + (e - s)], s1_local[off : off + (e - s)], piece[: e - s])
+                off += e - s
+            if use_streams:
+                comm.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(comm):
+                    dist.all_gather_into_tensor(slab, piece, group=self.group)
+                    if not full:
+                        D_full[blk0:M_total].copy_(slab[: M_total - blk0], non_blocking=True)
+            else:
+                dist.all_gather_into_tensor(slab, piece, group=self.group)
+                if not full:
+                    D_full[blk0:M_total].copy_(slab[: M_total - blk0])
         if use_streams:
             torch.cuda.current_stream(dev).wait_stream(comm)
         return D_full
-
-    def _all_gather(self, outs, src, comm, use_streams):
-        if use_streams:
-            comm.wait_stream(torch.cuda.current_stream(src.device))
-            with torch.cuda.stream(comm):
-                dist.all_gather(outs, src, group=self.group)
-        else:
-            dist.all_gather(outs, src, group=self.group)

@@ -4,7 +4,7 @@ Same constructor arguments, same registered buffer names / shapes / dtypes (B, s
 bias persistent; workspace, reduce_buffer non-persistent) so a QQQ checkpoint's state-dict loads
 unchanged, same pack() arguments, same forward() semantics.  Differences, all deliberate:
   * no CUDA-only constructor guards (qlinear_marlin.py:56-63 reject ROCm);
-  * pack() is vectorised (qqq_amd/pack.py) instead of python loops, and runs on any device;
+  * pack() uses the native packer (qqq_amd/pack.py -> qqq_pack_int4) instead of python loops, on any device;
   * forward() uses one fused HIP kernel for dynamic_quant instead of ~8 torch launches.
 """
 from __future__ import annotations
@@ -62,10 +62,14 @@ class QuantLinear(nn.Module):
             self.bias = None
 
     def _apply(self, fn):
-        # keep scale dtypes pinned across .half()/.to() (qlinear_marlin.py:141-145)
+        # keep scale dtypes pinned across .half()/.to() (qlinear_marlin.py:141-145); the bias too: the fused
+        # epilogue reads it as fp16 bits, and the reference's own `prepare_for_inference` does model.to(bf16/fp32)
+        # (its `D + self.bias` merely promotes; here the add stays fp16 + fp16 -> fp16, the reference's default)
         super()._apply(fn)
         self.s_group = self.s_group.to(torch.half)
         self.s_channel = self.s_channel.to(torch.float32)
+        if self.bias is not None:
+            self.bias = self.bias.to(torch.half)
         return self
 
     def post_init(self):
@@ -101,7 +105,10 @@ class QuantLinear(nn.Module):
             if self.bias is not None:
                 self.bias[:] = linear.bias.data.to(self.bias.device).to(torch.half)
             else:
-                self.bias = linear.bias.clone().to(torch.half)
+                # a layer built with bias=False that is packed from a biased linear: the reference assigns a plain
+                # attribute (qlinear_marlin.py:259-262) that .to(device) does not move; register it as a buffer
+                del self.bias
+                self.register_buffer("bias", linear.bias.data.clone().to(device=self.B.device, dtype=torch.half))
 
     def dynamic_quant(self, x: torch.Tensor):
         """Per-token int8 quantisation (qlinear_marlin.py:265-268), one fused HIP kernel."""

@@ -17,15 +17,35 @@ def L():
     return _lib.lib()
 
 
-def test_exports_every_declared_symbol(L):
-    hdr = open(os.path.join(ROOT, "include", "qqq_amd.h")).read()
+def _declared(header):
+    hdr = open(os.path.join(ROOT, "include", header)).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    names = set(re.findall(r"\b(qqq_[a-z0-9_]+)\s*\(", hdr))
-    assert {"qqq_w4a8_gemm", "qqq_w4a8_gemm_ex", "qqq_dynamic_quant", "qqq_add_bias", "qqq_amd_abi_version",
-            "qqq_amd_last_error", "qqq_probe_mfma", "qqq_probe_glds", "qqq_bench_gemm"} <= names
+    hdr = re.sub(r"typedef[^;]*\(\*[^;]*;", "", hdr, flags=re.S)  # function-pointer typedefs are not exports
+    return set(re.findall(r"\b(qqq_[a-z0-9_]+)\s*\(", hdr))
+
+
+def test_exports_every_declared_symbol(L):
+    names = _declared("qqq_amd.h")
+    assert {"qqq_w4a8_gemm", "qqq_w4a8_gemm_ex", "qqq_w4a8_plan", "qqq_dynamic_quant", "qqq_quantlinear_forward",
+            "qqq_pack_int4", "qqq_unpack_int4", "qqq_amd_abi_version", "qqq_amd_last_error"} == names
     for n in names:
         assert hasattr(L, n), n
-    assert L.qqq_amd_abi_version() == 1
+    assert L.qqq_amd_abi_version() == 2
+    # the operator library is the operator only: measurement loops and hardware probes live in the dev library
+    for n in ("qqq_bench_gemm", "qqq_probe_mfma", "qqq_probe_glds", "qqq_probe_fill", "qqq_add_bias", "qqq_dev_bench_gemm"):
+        assert not hasattr(L, n), n
+
+
+def test_dev_library_exports_every_declared_symbol():
+    from qqq_amd import _dev, build
+
+    build.build_dev()
+    D = _dev.lib()
+    names = _declared("qqq_amd_dev.h")
+    assert {"qqq_dev_bench_gemm", "qqq_dev_probe_mfma", "qqq_dev_probe_glds", "qqq_dev_probe_dequant",
+            "qqq_dev_probe_fill", "qqq_dev_last_error"} == names
+    for n in names:
+        assert hasattr(D, n), n
 
 
 def _call(L, m, n, k, groupsize=-1, thread_k=-1, thread_n=-1):
@@ -46,6 +66,30 @@ def test_reference_shape_validation_codes(L):
     assert _call(L, 0, 256, 256, groupsize=64) == 0
     # valid shape, null pointers: our own argument check, still no launch
     assert _call(L, 16, 256, 256) == 17
+
+
+def test_misaligned_pointers_are_rejected_before_any_launch(L):
+    """include/qqq_amd.h documents QQQ_ERR_ARG for misaligned pointers: the kernels use 16-byte vector / LDS-DMA
+    accesses on A, B, C, D, s3, bias and 8-byte loads on s2.  Checked on the host, so no GPU is needed."""
+    import numpy as np
+
+    buf = np.zeros(1 << 16, np.uint8)
+    base = (buf.ctypes.data + 63) & ~63
+    ok = [base + 4096 * i for i in range(8)]  # A B C D s1 s2 s3 ws
+
+    def call(ptrs, groupsize=-1, bias=None):
+        A, B, C, D, s1, s2, s3, ws = ptrs
+        return L.qqq_w4a8_gemm_ex(A, B, C, D, s1, s2, s3, 16, 256, 256, ws, groupsize, 0, None, -1, -1, -1, 16, None, None, bias)
+
+    for idx, off in ((0, 8), (1, 4), (2, 8), (3, 2), (5, 4), (4, 2), (7, 1)):
+        bad = list(ok)
+        bad[idx] += off
+        assert call(bad) == 17, idx
+        assert b"misaligned" in L.qqq_amd_last_error()
+    bad = list(ok)
+    bad[6] += 2
+    assert call(bad, groupsize=128) == 17  # s3 only matters in per-group mode
+    assert call(ok, bias=base + 2) == 17
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -28,3 +28,24 @@ def test_bench_two_ranks_one_gpu_gloo(dev):
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0
+
+
+def test_bench_two_ranks_rccl_when_two_gpus():
+    """The same path over RCCL (torch "nccl" backend) when the box has >= 2 GPUs: so that the driver's 8-GPU run is not
+    the first RCCL execution of the in-place all_gather_into_tensor pipeline.  Skips on 1-GPU boxes."""
+    import torch
+
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("QQQ_BENCH_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--no-cpu", "--no-fp16", "--check"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "identical to local full GEMMs" in p.stderr

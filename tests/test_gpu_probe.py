@@ -13,14 +13,14 @@ pytestmark = pytest.mark.gpu
 
 
 def _run_mfma(kind, a, b, dev):
-    from qqq_amd import _lib
+    from qqq_amd import _dev as _lib
 
     L = _lib.lib()
     nreg = 4 if kind == 16 else 16
     ta = torch.from_numpy(a).to(dev)
     tb = torch.from_numpy(b).to(dev)
     out = torch.zeros((64, nreg), dtype=torch.int32, device=dev)
-    rc = L.qqq_probe_mfma(kind, ctypes.c_void_p(ta.data_ptr()), ctypes.c_void_p(tb.data_ptr()),
+    rc = L.qqq_dev_probe_mfma(kind, ctypes.c_void_p(ta.data_ptr()), ctypes.c_void_p(tb.data_ptr()),
                           ctypes.c_void_p(out.data_ptr()), 0, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == 0, _lib.last_error()
     torch.cuda.synchronize()
@@ -40,7 +40,7 @@ def test_mfma_lane_maps(kind, dev):
 
 
 def test_global_load_lds_is_lane_linear(dev):
-    from qqq_amd import _lib
+    from qqq_amd import _dev as _lib
 
     L = _lib.lib()
     rng = np.random.default_rng(7)
@@ -49,7 +49,7 @@ def test_global_load_lds_is_lane_linear(dev):
     ts = torch.from_numpy(src.view(np.int32)).to(dev)
     tp = torch.from_numpy(perm).to(dev)
     out = torch.zeros((64, 4), dtype=torch.int32, device=dev)
-    rc = L.qqq_probe_glds(ctypes.c_void_p(ts.data_ptr()), ctypes.c_void_p(tp.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+    rc = L.qqq_dev_probe_glds(ctypes.c_void_p(ts.data_ptr()), ctypes.c_void_p(tp.data_ptr()), ctypes.c_void_p(out.data_ptr()),
                           0, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == 0, _lib.last_error()
     torch.cuda.synchronize()

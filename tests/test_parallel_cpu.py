@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from qqq_amd.parallel import ShardedGemm, chunk_bounds, shard_rows
+from qqq_amd.parallel import ShardedGemm, pick_chunks, row_spans, shard_rows, take_rows
 
 
 def test_shard_rows_partition():
@@ -21,7 +21,28 @@ def test_shard_rows_partition():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(P - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
-    assert chunk_bounds(5, 2) == [(0, 2), (2, 5)]
+
+
+def test_row_spans_cover_every_row_once():
+    """chunk-cyclic ownership: super-block c is one contiguous slab in which rank p's piece sits at offset p*w"""
+    for M in (0, 1, 5, 37, 64, 4096, 4097, 32768):
+        for P in (1, 2, 3, 8):
+            for chunks in (1, 2, 3, 4):
+                owner = -np.ones(M, np.int64)
+                w = -(-M // (P * chunks)) if M else 0
+                for r in range(P):
+                    sp = row_spans(M, P, r, chunks)
+                    assert len(sp) == chunks
+                    for c, (s, e) in enumerate(sp):
+                        assert 0 <= s <= e <= M and e - s <= w
+                        if e > s:
+                            assert s == (c * P + r) * w
+                            assert (owner[s:e] == -1).all()
+                            owner[s:e] = r
+                assert (owner >= 0).all()
+    assert pick_chunks(4096, 8192, 8) == 1 and pick_chunks(4096, 8192, 2) == 2 and pick_chunks(32768, 4096, 2) == 4
+    t = torch.arange(10).reshape(10, 1)
+    assert take_rows(t, [(0, 2), (6, 8)]).flatten().tolist() == [0, 1, 6, 7]
 
 
 def _free_port():
@@ -56,16 +77,20 @@ def _worker(rank, world, port, M, chunks, q):
             d = C.qqq_gemm(a_rows.numpy(), B, s1_rows.numpy(), s2, None)
             d_out.copy_(torch.from_numpy(d.copy()))
 
-        r0, r1 = shard_rows(M, world, rank)
         sg = ShardedGemm(gemm_fn, chunks=chunks)
-        D = sg(torch.from_numpy(A[r0:r1].copy()), torch.from_numpy(s1[r0:r1].copy()), M, N)
+        spans = sg.spans(M, N)
+        D = sg(take_rows(torch.from_numpy(A), spans), take_rows(torch.from_numpy(s1), spans), M, N)
         ok = np.array_equal(D.numpy().view(np.uint16), full.view(np.uint16))
+        # caller-owned output, called twice (scratch slab reuse)
+        D2 = torch.full((M, N), float("nan"), dtype=torch.float16)
+        sg(take_rows(torch.from_numpy(A), spans), take_rows(torch.from_numpy(s1), spans), M, N, D2)
+        ok = ok and np.array_equal(D2.numpy().view(np.uint16), full.view(np.uint16))
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("M,chunks", [(64, 2), (37, 3), (1, 2)])
+@pytest.mark.parametrize("M,chunks", [(64, 2), (37, 3), (1, 2), (130, None), (5, 4)])
 def test_sharded_gemm_all_gather_gloo(M, chunks):
     world = 2
     ctx = mp.get_context("spawn")

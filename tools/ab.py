@@ -6,14 +6,13 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench as Bn
-from qqq_amd import _lib
+from qqq_amd import _dev, _lib
+
+DEV = _dev.lib()
 
 def load(path):
+    """an operator-library build (possibly a tuning variant); timed through the dev library's event loop"""
     L = ctypes.CDLL(path)
-    vp, ci = ctypes.c_void_p, ctypes.c_int
-    L.qqq_bench_gemm.argtypes = [vp, ctypes.POINTER(vp), ci, vp, vp, vp, vp, vp, ci, ci, ci, vp, ci, ci, vp, ci,
-                                 ctypes.POINTER(_lib.QQQTune), ci, ctypes.POINTER(ctypes.c_float)]
-    L.qqq_bench_gemm.restype = ci
     L.qqq_amd_last_error.restype = ctypes.c_char_p
     return L
 
@@ -42,7 +41,7 @@ for M in Ms:
             tn = _lib.QQQTune()
             for k, v in tune.items(): setattr(tn, k, int(v))
         st = torch.cuda.current_stream(dev).cuda_stream
-        rc = L.qqq_bench_gemm(A.data_ptr(), arr, len(layer.Bs), layer.C.data_ptr(), D.data_ptr(), s1.data_ptr(), layer.s2.data_ptr(),
+        rc = DEV.qqq_dev_bench_gemm(_dev.gemm_ex_ptr(L), A.data_ptr(), arr, len(layer.Bs), layer.C.data_ptr(), D.data_ptr(), s1.data_ptr(), layer.s2.data_ptr(),
                               layer.s3.data_ptr() if layer.s3.numel() else None, M, layer.N, layer.K, layer.ws.data_ptr(),
                               layer.groupsize, 0, ctypes.c_void_p(st), 16, ctypes.byref(tn) if tn is not None else None, n, out)
         assert rc == 0, (rc, L.qqq_amd_last_error())

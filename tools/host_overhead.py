@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Host-side cost of one qqq_gemm call (eager, M=1 decode: the kernel takes ~17 us): torch custom-op path vs the direct
-ctypes path vs the native back-to-back loop (qqq_bench_gemm)."""
+ctypes path vs the native back-to-back loop (qqq_dev_bench_gemm)."""
 import os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -6,9 +6,9 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench as Bn
-from qqq_amd import _lib
+from qqq_amd import _dev
 dev = torch.device("cuda:0")
-L = _lib.lib()
+L = _dev.lib()
 M = 4096
 layer = Bn.Layer(dev, grouped=False, nbuf=4)
 arr = (ctypes.c_void_p * len(layer.Bs))(*[b.data_ptr() for b in layer.Bs])
@@ -24,7 +24,7 @@ cases = {
 def run(A, n=6):
     out = (ctypes.c_float * n)()
     st = torch.cuda.current_stream(dev).cuda_stream
-    rc = L.qqq_bench_gemm(A.data_ptr(), arr, len(layer.Bs), layer.C.data_ptr(), D.data_ptr(), s1.data_ptr(), layer.s2.data_ptr(), None,
+    rc = L.qqq_dev_bench_gemm(_dev.gemm_ex_ptr(), A.data_ptr(), arr, len(layer.Bs), layer.C.data_ptr(), D.data_ptr(), s1.data_ptr(), layer.s2.data_ptr(), None,
                           M, layer.N, layer.K, layer.ws.data_ptr(), -1, 0, ctypes.c_void_p(st), 16, None, n, out)
     assert rc == 0
     return np.array(out[:]) * 1e3

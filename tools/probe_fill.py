@@ -1,19 +1,19 @@
 #!/usr/bin/env python3
-"""Per-CU read bandwidth of the MI355X as seen by one workgroup per CU (qqq_probe_fill): L2-resident window
+"""Per-CU read bandwidth of the MI355X as seen by one workgroup per CU (qqq_dev_probe_fill): L2-resident window
 shared by all workgroups (L2 -> L1 fill) and disjoint HBM windows, for 1 / 64 / 256 workgroups."""
 import ctypes, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from qqq_amd import _lib
-L = _lib.lib()
+from qqq_amd import _dev
+L = _dev.lib()
 dev = torch.device("cuda:0")
 buf = torch.randint(0, 2**31 - 1, ((512 << 20) // 4,), dtype=torch.int32, device=dev)  # 512 MB
 sink = torch.zeros(4, dtype=torch.int32, device=dev)
 st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 def run(stride, per_wg, nwg, reps, unroll):
     ms = ctypes.c_float()
-    rc = L.qqq_probe_fill(buf.data_ptr(), stride, per_wg, nwg, reps, unroll, sink.data_ptr(), 0, st, ctypes.byref(ms))
+    rc = L.qqq_dev_probe_fill(buf.data_ptr(), stride, per_wg, nwg, reps, unroll, sink.data_ptr(), 0, st, ctypes.byref(ms))
     assert rc == 0
     tot = per_wg * reps * nwg
     return tot / (ms.value * 1e-3) / 1e9, ms.value * 1e3
