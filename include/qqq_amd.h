@@ -57,19 +57,21 @@ int qqq_w4a8_gemm(const void* A, const void* B, void* C, void* D, const void* s1
 typedef struct qqq_tune {
   int kernel;  /* 0 auto, 1 = "stream" (weights straight to VGPRs, 16x16x64 MFMA, small m),
                   2 = "tiled" (LDS-staged 32x32x32 MFMA tiles, large m),
-                  3 = "column" (decode: 32 columns x all of K per workgroup, no split-K)                */
+                  3 = "column" (decode: 32 columns x all of K per workgroup, no split-K),
+                  4 = "panel" (8 < m <= 128: all tokens of an m-block x bm columns x a K slice per workgroup,
+                      weights straight to VGPRs, activations shared through LDS, in-launch split-K)          */
   int ksplit;  /* 0 auto, else number of K slices (partials go through C)                   */
-  int waves;   /* stream: waves per workgroup (4, 8 or 16); 0 auto                           */
+  int waves;   /* stream: waves per workgroup (4, 8 or 16); panel (bm = 128): 4 or 8 (two k-groups); 0 auto */
   int fused;   /* split-K finish; 0 auto.  stream: 1 = last-arriving workgroup reduces in-launch (tickets in
                   workspace, release fence), 3 = same with write-through slab stores (no release fence),
                   2 = separate reduce launch.  tiled: 1 = in-launch (K slices of a tile meet in tile-sized int32
                   slots of C, tickets in workspace), 2 = ksplit [m,n] slabs in C + separate reduce launch      */
-  int bm;      /* tiled: rows per workgroup tile (64, 128, 256); 0 auto                      */
+  int bm;      /* tiled: rows per workgroup tile (64, 128, 256); panel: COLUMNS per workgroup (128, 256); 0 auto */
   int glds;    /* tiled: 1 = direct global->LDS loads, 2 = register staged; 0 auto          */
   int pf;      /* stream: prefetch depth in 4 KiB steps per wave (3, 5, 7); column: 1 KiB steps per wave
                   (2..12); 0 auto                                                                  */
   int stages;  /* tiled + LDS-DMA: ring depth 2..4 (0 auto)                                      */
-  int mt;      /* stream: 16-token tiles per workgroup (1..4); column: 1..2; 0 auto                  */
+  int mt;      /* stream: 16-token tiles per workgroup (1..4); column: 1..2; panel: 1, 2, 4, 8; 0 auto  */
   int pw;      /* tiled: weight strips per XCD panel of the tile order (4, 8, 16, 32); 0 auto          */
   int nslots;  /* out (qqq_w4a8_plan only): tile-sized slots of C used by the tiled in-launch split-K  */
   int reserved[1];

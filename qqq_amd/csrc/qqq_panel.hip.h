@@ -1,0 +1,352 @@
+// qqq_panel.hip.h -- "panel" kernel (8 < m <= 128: weights HBM -> VGPR per wave, activations shared through LDS,
+// in-launch split-K).  Part of the single translation unit qqq_w4a8.hip (see its header comment for the design).
+#ifndef QQQ_AMD_QQQ_PANEL_HIP_H_
+#define QQQ_AMD_QQQ_PANEL_HIP_H_
+
+// ------------------------------------------------------------------------------------------
+// "panel" kernel: one workgroup = ALL 16*MT tokens of an m-block x BN = 32*WN weight columns x one K slice.
+//
+//  * The waves of a workgroup split the COLUMNS (wave wn owns the 32 columns of half-group (ng, half), exactly the
+//    column kernel's set: chunks c = 4*half + c' of a 64-column group = 256 contiguous bytes of every 16-k row of
+//    B), so every weight byte is loaded by exactly one wave, straight from HBM into VGPRs (used once: no LDS,
+//    no barrier on the weight path), PFS stages ahead.  The packed words are re-distributed between lanes with the
+//    column kernel's DPP 4x4 transpose; v_mfma_i32_16x16x64_i8, MFMA row i = 4*c' + jt.
+//  * The activations (16*MT tokens x 128 k per stage) are the operand every wave needs: they are staged ONCE per
+//    workgroup in a double-buffered LDS image (16-byte chunks XOR-swizzled by the row: every ds_read_b128 is
+//    conflict free), so the L1 traffic of a workgroup is weights + activations once -- not activations once per
+//    wave as in the stream / column kernels, which is what bounds those above m = 16.  They travel global -> VGPR
+//    -> ds_write (XL stages ahead), NOT by LDS-DMA: measured on this part, global_load_lds moves ~34 B/clk/CU while
+//    plain 16-byte loads reach ~64 B/clk/CU (profiles/r01_probe_fill.txt), and at m = 128 a stage needs 24 KB of
+//    operands per 576 matrix-pipe cycles -- the LDS-DMA variant of this kernel was bound by exactly that
+//    (profiles/r02_panel_dma_variant.txt).  A welcome side effect: every load is visible to hipcc, which therefore
+//    places exact counted s_waitcnt vmcnt(N) itself (loads return in order; the steady-state loop is branch-free).
+//  * KG = 2: two k-groups of WN waves; group kg takes the 64-k half kg of every 128-k stage (so one LDS stage
+//    feeds both) and the two partial tiles meet in LDS at the end.  BN = 128 with 8 waves: 4 K slices fill 256 CUs
+//    at N = 8192, which keeps the split-K partial-sum traffic at 3 x M x N x 4 B.
+//  * split-K in-launch: arrival-order tickets as in the tiled kernel, but every depositor owns a slot (slot index =
+//    arrival index), so nobody waits except the last arrival, which has by construction only already-arrived
+//    workgroups to wait for.  Deposits are lane-linear full-line write-through stores.
+// grid = (ceil(N / BN), ksplit, ceil(M / (16*MT)));  block = 64 * WN * KG.
+// ------------------------------------------------------------------------------------------
+
+template <int MT, bool GROUPED, int WN, int KG, int PFS, int XL>
+__global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
+    const int8_t* __restrict__ A, const unsigned char* __restrict__ B, int32_t* __restrict__ C,
+    _Float16* __restrict__ D, const float* __restrict__ s1, const float* __restrict__ s2,
+    const _Float16* __restrict__ s3, int32_t* __restrict__ acc_out, int* __restrict__ tickets,
+    const _Float16* __restrict__ bias, const int M, const int N, const int K, const int ksplit) {
+  constexpr int NW = WN * KG;            // waves
+  constexpr int NT = NW * 64;            // threads
+  constexpr int BN = 32 * WN;            // columns per workgroup
+  constexpr int ROWS = 16 * MT;          // tokens per workgroup
+  constexpr int XB = ROWS * 128;         // bytes of one activation stage
+  constexpr int XCH = XB / 16;           // ... in 16-byte chunks
+  constexpr int XPT = (XCH + NT - 1) / NT;  // chunks per thread
+  constexpr int SPW = 2 / KG;            // 64-k steps (= weight loads) per wave and stage
+  static_assert(PFS % XL == 0 && XL >= 2, "ring periods");
+  constexpr int NBUF = (SPW == 1) ? 2 : 3;  // LDS stage buffers (see `stage`)
+  constexpr int EP_STRIDE = BN + 4;      // ints per row of the epilogue image (bank skew)
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int xch;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave % WN;  // column set
+  const int kg = wave / WN;  // k-group
+  const int strip = blockIdx.x, sp = blockIdx.y, mblk = blockIdx.z;
+  const int mbase = mblk * ROWS;
+  const int ngroups = N >> 6;
+  int ng = strip * (WN / 2) + (wn >> 1);
+  if (ng >= ngroups) ng = ngroups - 1;  // N % BN != 0: surplus waves of the last strip compute on clamped columns, store nothing
+  const int half = wn & 1;
+  const size_t rowbytes = (size_t)N * 8;
+
+  // ---- K slice in 128-k stages (a trailing 64-k half stage when K % 128 == 64) ----
+  const int KS = K >> 6;            // 64-k steps
+  const int NST = (KS + 1) >> 1;    // stages
+  const int st_begin = (int)(((long long)NST * sp) / ksplit);
+  const int st_end = (int)(((long long)NST * (sp + 1)) / ksplit);
+  const int nst = st_end - st_begin;
+  const bool k_tail = (KS & 1) != 0;  // the last stage of the problem holds one 64-k step only
+
+  // ---- per-lane sources ----
+  const int h = lane >> 4, cq = (lane >> 2) & 3, q4 = lane & 3;  // q4: kq as a load lane, jt as an MFMA lane
+  const unsigned char* wptr = B + (size_t)h * rowbytes + (size_t)ng * 512 + (4 * half + cq) * 64 + q4 * 16;
+  const _Float16* sptr = GROUPED ? (s3 + (size_t)ng * 64 + (4 * half + cq) * 8 + 2 * q4) : nullptr;
+  // activation staging: chunk ci = tid + q*NT of the stage image = (row ci >> 3, 16-byte piece ci & 7)
+  const unsigned char* xsrc[XPT];
+  unsigned xdst[XPT];
+  bool xup[XPT];  // piece lies in the upper 64 k of the stage
+#pragma unroll
+  for (int q = 0; q < XPT; ++q) {
+    const int ci = tid + q * NT;
+    const int row = (ci >> 3) % ROWS, pos = ci & 7;
+    int grow = mbase + row;
+    if (grow >= M) grow = M - 1;
+    xsrc[q] = reinterpret_cast<const unsigned char*>(A) + (size_t)grow * K + pos * 16;
+    xdst[q] = (unsigned)(row * 128 + ((pos ^ ((row >> 1) & 7)) << 4));
+    xup[q] = pos >= 4;
+  }
+  const bool xact = (XCH % NT == 0) || tid < XCH % NT;  // wave-uniform: XCH % NT is a multiple of 64 whenever it is not 0
+  static_assert(XCH % 64 == 0, "activation stage");
+
+  // Stage indices past the slice are redirected to its last stage (loaded, never used): the loop stays branch-free.
+  auto load_x = [&](const int st_rel, v4u (&r)[XPT]) {
+    const int st = st_begin + (st_rel < nst ? st_rel : nst - 1);
+    const bool half_only = k_tail && st == NST - 1;
+#pragma unroll
+    for (int q = 0; q < XPT; ++q)
+      if (q + 1 < XPT || xact) {
+        // the upper 64 k of a trailing half stage lie outside the row: fetch the lower half again (never used)
+        const unsigned char* p = xsrc[q] + (size_t)st * 128 - ((half_only && xup[q]) ? 64 : 0);
+        r[q] = *reinterpret_cast<const v4u*>(p);
+      }
+  };
+  auto store_x = [&](const int buf, const v4u (&r)[XPT]) {
+#pragma unroll
+    for (int q = 0; q < XPT; ++q)
+      if (q + 1 < XPT || xact) *reinterpret_cast<v4u*>(smem + buf * XB + xdst[q]) = r[q];
+  };
+  auto load_w = [&](const int st_rel, const int t, v4u& dst) {
+    const int st = st_begin + (st_rel < nst ? st_rel : nst - 1);
+    int s = 2 * st + (KG == 2 ? kg : t);
+    if (s >= KS) s = KS - 1;
+    dst = *reinterpret_cast<const v4u*>(wptr + (size_t)(4 * s) * rowbytes);
+  };
+  auto load_sc = [&](const int st_rel, h2& dst) {
+    const int st = st_begin + (st_rel < nst ? st_rel : nst - 1);
+    dst = *reinterpret_cast<const h2*>(sptr + (size_t)st * N);
+  };
+
+  v4i acc[MT][2];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) acc[mt][0] = acc[mt][1] = (v4i){0, 0, 0, 0};
+
+  v4u wr[PFS * SPW];
+  v4u xr[XL][XPT];
+  h2 scr[GROUPED ? PFS : 1];
+  const bool odd = lane & 1, hi = lane & 2;
+  const unsigned xrd = (unsigned)((lane & 15) * 128);  // + mt*2048; chunk = (4*t + h) ^ ((row >> 1) & 7), row = 16*mt + j
+  const int xsw = ((lane & 15) >> 1) & 7;              // (row >> 1) & 7 for row = 16*mt + j
+
+  // MFMA operands of one 64-k step of this wave: weights (two column halves b) and the tokens' activations
+  struct Operands {
+    v4i a0, a1;
+    v4i x[MT];
+  };
+  auto read_x = [&](const int stage_abs_rel, const int tk, Operands& o) {  // LDS buffer of a stage = stage % NBUF
+    const unsigned char* st = smem + (stage_abs_rel % NBUF) * XB;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+      o.x[mt] = *reinterpret_cast<const v4i*>(st + xrd + mt * 2048 + (((4 * tk + h) ^ xsw) << 4));
+  };
+  auto unpack_w = [&](const v4u& w, const h2 sc, const bool valid, Operands& o) {
+    // 4x4 transpose over (register e, quad lane q): out[e](lane q) = in[q](lane e)   (as in the column kernel)
+    unsigned z[4], y[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const unsigned t = (unsigned)__builtin_amdgcn_mov_dpp((int)w[e ^ 1], 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+      z[e] = (odd == (bool)(e & 1)) ? w[e] : t;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const unsigned t = (unsigned)__builtin_amdgcn_mov_dpp((int)z[e ^ 2], 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
+      y[e] = (hi == (bool)(e & 2)) ? z[e] : t;
+    }
+    h2 sb0 = {(_Float16)0, (_Float16)0}, sb1 = sb0;
+    if constexpr (GROUPED) {
+      sb0 = (h2){sc[0], sc[0]};
+      sb1 = (h2){sc[1], sc[1]};
+    }
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) {
+      int w0, w1;
+      unpack_pair<GROUPED>(y[kq], sb0, sb1, w0, w1);
+      o.a0[kq] = valid ? w0 : 0;  // a step past the end of K (trailing half stage) contributes nothing
+      o.a1[kq] = valid ? w1 : 0;
+    }
+  };
+
+  // One stage of the software pipeline.  While the matrix pipe works on step (i, t) -- operands `cur`, prepared one
+  // step earlier -- the wave reads the next step's activations from LDS, unpacks the next step's weights (already in
+  // the register ring) and refills that ring slot from HBM; sched_group_barrier spreads that work between the MFMAs.
+  // LDS buffers: stage j lives in buffer j % NBUF; stage i+2 is written at the top of stage i (its buffer was last
+  // read during stage i-1, or i-2 with two buffers: KG == 2 reads every buffer in one stage only), and becomes visible
+  // with the barrier that ends stage i -- one stage before the first (prefetch) read.
+  Operands cur, nxt;
+  auto stage = [&](const int i, const int u) {  // u = i % PFS as a compile-time value at every call site
+    store_x((i + 2) % NBUF, xr[(u + 2) % XL]);
+    load_x(i + 2 + XL, xr[(u + 2) % XL]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < SPW; ++t) {
+      // the step after (i, t): (i, t+1) or (i+1, 0)
+      const bool same = (t + 1 < SPW);
+      const int ni = same ? i : i + 1, nu = same ? u : (u + 1) % PFS, nt = same ? t + 1 : 0;
+      const int ntk = (KG == 2) ? kg : nt;
+      read_x(ni, ntk, nxt);
+      unpack_w(wr[nu * SPW + nt], scr[GROUPED ? nu : 0], 2 * (st_begin + ni) + ntk < KS, nxt);
+      load_w(ni + PFS, nt, wr[nu * SPW + nt]);
+      if constexpr (GROUPED)
+        if (nt == SPW - 1) load_sc(ni + PFS, scr[nu]);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        acc[mt][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(cur.a0, cur.x[mt], acc[mt][0], 0, 0, 0);
+        acc[mt][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(cur.a1, cur.x[mt], acc[mt][1], 0, 0, 0);
+      }
+      // issue order inside this region: 1 MFMA, then its share of the VALU / LDS-read / VMEM work
+      constexpr int NVALU = GROUPED ? 88 : 40;  // DPP moves + selects + unpack of one step (upper estimate)
+      constexpr int VPM = (NVALU + 2 * MT - 1) / (2 * MT);
+#pragma unroll
+      for (int q = 0; q < 2 * MT; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                // 1 MFMA
+        if (q % 2 == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 LDS read
+        __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);              // VALU
+        if (q == 2 * MT - 1) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);  // VMEM reads (ring refills)
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      cur = nxt;
+    }
+    __syncthreads();  // stage i+2 is in LDS for everybody
+  };
+
+  if (nst > 0) {
+    // ---- prologue: stages 0 and 1 straight into LDS, the rings filled in steady-state order ----
+    load_x(0, xr[0]);
+    load_x(1, xr[1]);
+    store_x(0, xr[0]);
+    store_x(1, xr[1]);
+#pragma unroll
+    for (int j = 2; j < 2 + XL; ++j) load_x(j, xr[j % XL]);
+#pragma unroll
+    for (int j = 0; j < PFS; ++j) {
+#pragma unroll
+      for (int t = 0; t < SPW; ++t) load_w(j, t, wr[j * SPW + t]);
+      if constexpr (GROUPED) load_sc(j, scr[j]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    {  // operands of the first step; its ring slot is refilled like any other
+      const int tk0 = (KG == 2) ? kg : 0;
+      read_x(0, tk0, cur);
+      unpack_w(wr[0], scr[0], 2 * st_begin + tk0 < KS, cur);
+      load_w(PFS, 0, wr[0]);
+      if constexpr (GROUPED)
+        if (SPW == 1) load_sc(PFS, scr[0]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- steady state: PFS stages per iteration (ring slots are compile-time registers), branch-free ----
+    int i0 = 0;
+    for (; i0 + PFS <= nst; i0 += PFS) {
+#pragma unroll
+      for (int u = 0; u < PFS; ++u) stage(i0 + u, u);
+    }
+    // ---- ragged tail (< PFS stages) ----
+#pragma unroll
+    for (int u = 0; u < PFS - 1; ++u)
+      if (i0 + u < nst) stage(i0 + u, u);
+  }
+  __syncthreads();
+
+  // ---- k-groups meet in LDS (KG == 2): group 1 deposits lane-linear, group 0 adds ----
+  if constexpr (KG == 2) {
+    v4i* red = reinterpret_cast<v4i*>(smem);
+    if (kg == 1) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) red[((wn * MT + mt) * 2 + b) * 64 + lane] = acc[mt][b];
+    }
+    __syncthreads();
+    if (kg == 0) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[mt][b] += red[((wn * MT + mt) * 2 + b) * 64 + lane];
+    }
+    __syncthreads();
+  }
+
+  // ---- in-launch split-K: slot = arrival index; the last arrival folds every slot and runs the epilogue ----
+  const int tile = mblk * gridDim.x + strip;
+  if (ksplit > 1) {
+    int* tk = tickets + 2 * (size_t)tile;  // [0] arrivals, [1] completed deposits; both zero again on exit
+    if (tid == 0) xch = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int t = xch;
+    const size_t slot_ints = (size_t)ROWS * BN;
+    const size_t tile_ints = slot_ints * (size_t)(ksplit - 1);
+    if (t < ksplit - 1) {
+      if (kg == 0) {
+        const unsigned char* sb = reinterpret_cast<const unsigned char*>(C + (size_t)tile * tile_ints + (size_t)t * slot_ints +
+                                                                         (size_t)wn * (MT * 2 * 256));
+        const unsigned voff = lane * 16;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const unsigned char* p = sb + (mt * 2 + b) * 1024;
+            asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1" ::"v"(voff), "v"(acc[mt][b]), "s"(p) : "memory");
+          }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __syncthreads();  // every wave's part of the deposit has reached memory
+      if (tid == 0) __hip_atomic_fetch_add(tk + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    if (tid == 0)  // everybody waited for has arrived already (is depositing): short, and bounded as a matter of principle
+      for (int spin = 0; spin < (1 << 24) && __hip_atomic_load(tk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ksplit - 1; ++spin)
+        __builtin_amdgcn_s_sleep(2);
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (kg == 0) {
+      for (int s_ = 0; s_ < ksplit - 1; ++s_) {
+        const v4i* p = reinterpret_cast<const v4i*>(C + (size_t)tile * tile_ints + (size_t)s_ * slot_ints +
+                                                    (size_t)wn * (MT * 2 * 256));
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) acc[mt][b] += p[(mt * 2 + b) * 64 + lane];
+      }
+    }
+    if (tid < 2) __hip_atomic_store(tk + tid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // workspace zero on return
+  }
+
+  // ---- epilogue: int32 tile -> LDS (row-major, skewed rows) -> 8 consecutive n per thread -> 16-byte stores ----
+  // D lane ln of the MFMA holds token j = ln & 15, rows 4*(ln >> 4) + r -> c' = ln >> 4, jt = r:
+  //   column inside the strip  nl = 64*(wn >> 1) + 16*jt + 8*b + 4*half + c'
+  int* ep = reinterpret_cast<int*>(smem);
+  if (kg == 0) {
+    const int j = lane & 15, cp = lane >> 4;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          ep[(16 * mt + j) * EP_STRIDE + 64 * (wn >> 1) + 16 * r + 8 * b + 4 * half + cp] = acc[mt][b][r];
+  }
+  __syncthreads();
+  for (int it = tid; it < ROWS * (BN / 8); it += NT) {
+    const int row = it / (BN / 8), c8 = it % (BN / 8);
+    const int m = mbase + row, n = strip * BN + c8 * 8;
+    if (m < M && n < N) {
+      const v4i lo = *reinterpret_cast<const v4i*>(ep + row * EP_STRIDE + c8 * 8);
+      const v4i hi4 = *reinterpret_cast<const v4i*>(ep + row * EP_STRIDE + c8 * 8 + 4);
+      const float a_s = s1[m];
+      const h4 o0 = epilogue_vals4(lo[0], lo[1], lo[2], lo[3], n, a_s, s2);
+      const h4 o1 = epilogue_vals4(hi4[0], hi4[1], hi4[2], hi4[3], n + 4, a_s, s2);
+      h8 o = {o0[0], o0[1], o0[2], o0[3], o1[0], o1[1], o1[2], o1[3]};
+      if (bias) o = o + *reinterpret_cast<const h8*>(bias + n);  // fp16 add after the fp16 round
+      *reinterpret_cast<h8*>(D + (size_t)m * N + n) = o;
+      if (acc_out) {
+        *reinterpret_cast<v4i*>(acc_out + (size_t)m * N + n) = lo;
+        *reinterpret_cast<v4i*>(acc_out + (size_t)m * N + n + 4) = hi4;
+      }
+    }
+  }
+}
+
+#endif  // QQQ_AMD_QQQ_PANEL_HIP_H_

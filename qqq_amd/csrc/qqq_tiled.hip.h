@@ -379,15 +379,6 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * (2 / NB) * 64) void 
           for (int jj = 0; jj < JW; ++jj) f.wq[kq][jj] = w[kq][jj];
         unpack_frag(f, o);
       };
-      auto mfma_x = [&](const Ops& o, const v4i (&x)[MTW]) {
-#pragma unroll
-        for (int jj = 0; jj < JW; ++jj)
-#pragma unroll
-          for (int mt = 0; mt < MTW; ++mt)
-#pragma unroll
-            for (int bi = 0; bi < NB; ++bi)
-              acc[mt][jj][bi] = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.a[jj][bi], x[mt], acc[mt][jj][bi], 0, 0, 0);
-      };
       if (nkb > 0) {
         issue_loads(kb_begin, 0);
         if (nkb > 1) issue_loads(kb_begin + 1, 1);

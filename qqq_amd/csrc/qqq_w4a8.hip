@@ -44,6 +44,7 @@
 #include "qqq_common.hip.h"
 #include "qqq_stream.hip.h"
 #include "qqq_column.hip.h"
+#include "qqq_panel.hip.h"
 #include "qqq_tiled.hip.h"
 #include "qqq_small.hip.h"
 
@@ -194,6 +195,63 @@ static hipError_t launch_column(const LaunchArgs& a, bool grouped, int mt, int p
   return grouped ? launch_column_g<true>(a, mt, pf, ksplit) : launch_column_g<false>(a, mt, pf, ksplit);
 }
 
+template <int MT, bool GROUPED, int WN, int KG, int PFS, int XL>
+static hipError_t launch_panel_t(const LaunchArgs& a, int ksplit) {
+  constexpr int ROWS = 16 * MT, BN = 32 * WN;
+  constexpr int XBUF = (KG == 2 ? 2 : 3) * ROWS * 128;
+  constexpr int EP = ROWS * (BN + 4) * 4;
+  constexpr int RED = (KG == 2) ? WN * MT * 2048 : 0;
+  constexpr int LDS = XBUF > EP ? (XBUF > RED ? XBUF : RED) : (EP > RED ? EP : RED);
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  static bool attr_set[64] = {};  // per instantiation, per device
+  auto kern = qqq_panel_kernel<MT, GROUPED, WN, KG, PFS, XL>;
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  if (cur < 0 || cur >= 64 || !attr_set[cur]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return e;
+    if (cur >= 0 && cur < 64) attr_set[cur] = true;
+  }
+  dim3 grid((a.N + BN - 1) / BN, ksplit, (a.M + ROWS - 1) / ROWS);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WN * KG), LDS, a.stream, a.A, a.B, a.C, a.D, a.s1, a.s2, a.s3, a.acc_out,
+                     a.tickets, a.bias, a.M, a.N, a.K, ksplit);
+  return hipGetLastError();
+}
+
+template <int MT, bool GROUPED, int PFS, int XL>
+static hipError_t launch_panel_shape(const LaunchArgs& a, int bn, int waves, int ksplit) {
+  if (bn == 256) return launch_panel_t<MT, GROUPED, 8, 1, PFS, XL>(a, ksplit);
+  if (waves == 4) return launch_panel_t<MT, GROUPED, 4, 1, PFS, XL>(a, ksplit);
+  return launch_panel_t<MT, GROUPED, 4, 2, PFS, XL>(a, ksplit);
+}
+
+template <int MT, bool GROUPED>
+static hipError_t launch_panel_pf(const LaunchArgs& a, int bn, int waves, int pfs, int xl, int ksplit) {
+  // XL (activation lead) = PFS (weight lead) unless asked otherwise: loads return in order, so a shorter activation
+  // lead would force the weight loads issued before it to land early and cut their effective lead to XL + 1
+  if (pfs <= 2) return launch_panel_shape<MT, GROUPED, 2, 2>(a, bn, waves, ksplit);
+  if constexpr (MT <= 4) {
+    if (pfs >= 8) return launch_panel_shape<MT, GROUPED, 8, 8>(a, bn, waves, ksplit);
+  }
+  if (pfs >= 6 || pfs == 3) return launch_panel_shape<MT, GROUPED, 3, 3>(a, bn, waves, ksplit);
+  if (xl == 2) return launch_panel_shape<MT, GROUPED, 4, 2>(a, bn, waves, ksplit);
+  return launch_panel_shape<MT, GROUPED, 4, 4>(a, bn, waves, ksplit);
+}
+
+template <bool GROUPED>
+static hipError_t launch_panel_g(const LaunchArgs& a, int mt, int bn, int waves, int pfs, int xl, int ksplit) {
+  switch (mt) {
+    case 1: return launch_panel_pf<1, GROUPED>(a, bn, waves, pfs, xl, ksplit);
+    case 2: return launch_panel_pf<2, GROUPED>(a, bn, waves, pfs, xl, ksplit);
+    case 4: return launch_panel_pf<4, GROUPED>(a, bn, waves, pfs, xl, ksplit);
+    default: return launch_panel_pf<8, GROUPED>(a, bn, waves, pfs, xl, ksplit);
+  }
+}
+
+static hipError_t launch_panel(const LaunchArgs& a, bool grouped, int mt, int bn, int waves, int pfs, int xl, int ksplit) {
+  return grouped ? launch_panel_g<true>(a, mt, bn, waves, pfs, xl, ksplit) : launch_panel_g<false>(a, mt, bn, waves, pfs, xl, ksplit);
+}
+
 template <int BM, int MTW, int JW, int NB, bool GROUPED, int NS>
 static hipError_t launch_tiled_t(const LaunchArgs& a, int ksplit, int nslots, int pw) {
   constexpr int WAVES = (BM / (32 * MTW)) * (4 / JW) * (2 / NB);
@@ -271,10 +329,98 @@ static hipError_t launch_tiled(const LaunchArgs& a, bool grouped, int bm, int st
 
 static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// ---- cost models (microseconds) used by the automatic dispatch; constants fitted to profiles/r02_dispatch_check*.txt ----
+// tiled: rounds(tiles x ksplit over 256 CUs) x tile_time(rows, K / ksplit, rate(shape)) + split-K cost,
+// per-shape rates (TOPS at large m) measured on MI355X.  Bigger tiles are more efficient per MFMA but quantise worse
+// over the CUs; split-K fills idle CUs at the price of int32 partial-sum traffic.  Wave shapes per mode: per-channel
+// keeps 64x128 wave tiles (least LDS traffic); per-group uses the column-owner shapes (258 / 130): every weight
+// re-quantised once per workgroup.
+static double tiled_estimate(int M, int N, int K, bool grouped, bool have_scratch, long long cap_rows, long long cap_tickets,
+                             bool slabs_only, int* bm_out, int* ks_out) {
+  const long long strips = (N + 255) / 256;
+  const long long cap_ints = cap_rows * (long long)N;
+  auto slot_count = [&](int rows, int ks) -> int {
+    if (!have_scratch || ks < 2 || slabs_only) return 0;
+    const long long tl = (long long)((M + rows - 1) / rows) * strips;
+    long long S = cap_ints / (tl * rows * 256);
+    if (S > ks - 1) S = ks - 1;
+    while (S > 0 && tl * (1 + S) > cap_tickets) --S;
+    return (int)S;
+  };
+  // {several workgroups co-resident per CU, a single one} -- small tiles lose efficiency when alone on a CU
+  const double rate256 = grouped ? 1800.0 : 2300.0;
+  const double rate128[2] = {grouped ? 1360.0 : 2050.0, grouped ? 1320.0 : 1650.0};
+  const double rate64[2] = {grouped ? 800.0 : 1560.0, grouped ? 650.0 : 1170.0};
+  double best = 1e30;
+  auto consider = [&](int rows, const double* rates, int code) {
+    const long long tl = (long long)((M + rows - 1) / rows) * strips;
+    const int ks_max = (tl < 192 && have_scratch) ? clampi((int)((256 + tl - 1) / tl), 1, (K / 128) / 4 > 0 ? (K / 128) / 4 : 1) : 1;
+    for (int ks = 1; ks <= ks_max; ++ks) {
+      const int S = slot_count(rows, ks);
+      if (ks > 1 && S == 0 && (long long)ks * M > cap_rows) break;
+      const double rate = (rows == 256) ? rates[0] : rates[(tl * ks <= 256) ? 1 : 0];
+      const double tile_us = (double)rows * ((double)K / ks) * 131072.0 / (rate * 1e6) + 6.0;  // + prologue/epilogue
+      double us = (double)((tl * ks + 255) / 256) * tile_us;
+      if (ks > 1 && S > 0)  // every deposit is written once and read once (~4.2 TB/s chip-wide) + serial hops
+        us += 3.0 + 2.0 * (ks - 1) * (double)tl * rows * 1024.0 / 4.2e6 + 3.0 * (double)((ks - 1 + S - 1) / S);
+      else if (ks > 1) us += 5.0 + (double)ks * M * N * 8.0 / 3.0e6;  // slabs written + read at ~3 TB/s, + launch
+      if (us < best) {
+        best = us;
+        *bm_out = code;
+        *ks_out = ks;
+      }
+    }
+  };
+  consider(256, &rate256, grouped ? 258 : 256);
+  consider(128, rate128, grouped ? 130 : 131);
+  consider(64, rate64, 64);
+  return best;
+}
+
+// stream: every 64-token m-block streams the whole weight matrix (the first from HBM, the others mostly from L2 /
+// Infinity Cache), plus launch, LDS reduce and the separate split-K reduce launch
+static double stream_estimate(int M, int N, int K, bool grouped) {
+  double per_block = (double)N * K / 2.0 / 5.0e6;  // the weight matrix at ~5 TB/s
+  if (per_block < 2.5) per_block = 2.5;
+  const int mblocks = (M + 63) / 64;
+  // measured: 1 / 2 / 3 / 4 m-blocks take 1.15 / 1.95 / 3.0 / 3.3 weight passes, plus ~2 us of fixed work per m-block
+  const double passes = (mblocks == 1) ? 1.15 : (mblocks == 2) ? 1.95 : (mblocks == 3) ? 3.0 : 3.3 + 0.8 * (mblocks - 4);
+  const double us = 9.0 + per_block * passes + 2.0 * mblocks;
+  return grouped ? us * 1.15 : us;
+}
+
+// panel: 128-token m-blocks x bn-column strips x K slices; one workgroup per CU and round (mt = 8); measured ~0.47 us
+// per 128-k stage (bn = 128, per-channel), twice that for bn = 256, x1.45 per-group; ~9 us of launch / pipeline fill /
+// epilogue and 7..11 us for the in-launch split-K hand-off (deposit, ticket, fold by the last arrival)
+static double panel_estimate(int M, int N, int K, bool grouped, bool have_scratch, long long cap_rows, long long cap_tickets,
+                             int* bn_out, int* ks_out) {
+  const int mt = (M <= 16) ? 1 : (M <= 32) ? 2 : (M <= 64) ? 4 : 8;
+  const int rows = 16 * mt;
+  const long long mblocks = (M + rows - 1) / rows;
+  const int NST = (K / 64 + 1) / 2;
+  double best = 1e30;
+  for (int bn = 128; bn <= 256; bn *= 2) {
+    const long long tl = mblocks * ((N + bn - 1) / bn);
+    const double t_stage = (0.13 + 0.042 * mt) * (bn == 256 ? 1.7 : 1.0) * (grouped ? 1.45 : 1.0);
+    for (int ks = 1; ks <= 4; ++ks) {
+      if (ks > 1 && (!have_scratch || 2 * tl > cap_tickets || mblocks * rows * (ks - 1) > cap_rows || ks > NST / 4)) break;
+      static const double tail[5] = {0.0, 0.0, 7.0, 9.0, 11.0};
+      const double wg_us = 8.7 + tail[ks] + ((double)NST / ks) * t_stage;
+      const double us = (double)((tl * ks + 255) / 256) * wg_us;
+      if (us < best) {
+        best = us;
+        *bn_out = bn;
+        *ks_out = ks;
+      }
+    }
+  }
+  return best;
+}
+
 // The dispatch decision of one call, as plain data (pure host logic: also exported as qqq_w4a8_plan so
 // that it can be inspected and tested without a GPU).
 struct Plan {
-  int kernel;  // 1 stream, 2 tiled, 3 column
+  int kernel;  // 1 stream, 2 tiled, 3 column, 4 panel
   int ksplit;
   int fused;   // stream: 1 / 3 in-launch, 2 separate reduce.  tiled: 1 in-launch slots, 2 slabs + reduce
   int mt, waves, pf;      // stream
@@ -301,11 +447,56 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
                         (M <= 8 || ((long long)M * K <= (grouped ? 524288 : 262144) && N / 32 <= 512));
     if (column) kernel = 3;
     else kernel = (M <= 128 || (K % 128) != 0) ? 1 : 2;
+    // Above the decode regime the family is picked by the three cost models.  The panel kernel is also the MFMA path
+    // with LDS-shared activations for K % 128 == 64 at any m (the tiled kernel needs 128-k blocks).
+    if (column_ok && !column && M > 32) {
+      const long long cap_tk = have_ws ? (long long)(N / 128) * (max_par > 0 ? max_par : 0) : 0;
+      int pbn = 128, pks = 1, tbm = 0, tks = 1;
+      const double e_panel = ((long long)(M + 127) / 128 <= 65535) ? panel_estimate(M, N, K, grouped, have_scratch && have_ws, cap_rows, cap_tk, &pbn, &pks) : 1e30;
+      const double e_stream = (M <= 256) ? stream_estimate(M, N, K, grouped) : 1e30;
+      const double e_tiled = ((K % 128) == 0 && M > 64) ? tiled_estimate(M, N, K, grouped, have_scratch, cap_rows, cap_tk, false, &tbm, &tks) : 1e30;
+      if (e_panel <= e_stream && e_panel <= e_tiled) {
+        kernel = 4;
+        if (t.bm == 0) t.bm = pbn;
+        if (t.ksplit <= 0) t.ksplit = pks;
+      } else {
+        kernel = (e_stream <= e_tiled) ? 1 : 2;
+      }
+    }
   }
-  if (kernel == 3 && !column_ok) kernel = 1;
+  if ((kernel == 3 || kernel == 4) && !column_ok) kernel = 1;
   if (kernel == 2 && (K % 128) != 0) kernel = 1;
   pl.kernel = kernel;
   int ksplit = 1;
+
+  if (kernel == 4) {
+    // panel: all tokens of an m-block (16*mt <= 128) x bn columns x a K slice per workgroup; in-launch split-K with one
+    // slot of C per depositing slice and two ticket words per (m-block, strip) tile
+    int mt = (t.mt == 1 || t.mt == 2 || t.mt == 4 || t.mt == 8) ? t.mt : (M <= 16 ? 1 : M <= 32 ? 2 : M <= 64 ? 4 : 8);
+    const int bn = (t.bm == 256) ? 256 : 128;
+    const int waves = (bn == 256) ? 8 : (t.waves == 4 ? 4 : 8);
+    const int rows = 16 * mt;
+    const long long mblocks = (M + rows - 1) / rows, strips = (N + bn - 1) / bn;
+    const int NST = (K / 64 + 1) / 2;
+    ksplit = t.ksplit;
+    if (ksplit <= 0) ksplit = clampi((int)(256 / (strips * mblocks)), 1, 4);  // never more than one round of workgroups
+    ksplit = clampi(ksplit, 1, NST / 4 > 0 ? NST / 4 : 1);
+    if (!have_scratch || workspace == nullptr) ksplit = 1;
+    if (ksplit > 1) {
+      const long long cap_tk = (long long)(N / 128) * (max_par > 0 ? max_par : 0);
+      if (2 * mblocks * strips > cap_tk) ksplit = 1;
+      while (ksplit > 1 && mblocks * rows * (ksplit - 1) > cap_rows) --ksplit;
+    }
+    pl.mt = mt;
+    pl.bm = bn;
+    pl.waves = waves;
+    pl.pf = (t.pf == 2 || t.pf == 3 || t.pf == 8) ? t.pf : (t.pf == 0 && bn == 256 ? 3 : 4);  // weight prefetch depth in stages
+    if (pl.pf == 8 && mt > 4) pl.pf = 4;
+    pl.stages = (pl.pf == 4 && t.stages == 2) ? 2 : pl.pf;  // activation prefetch depth in stages
+    pl.ksplit = ksplit;
+    pl.fused = 1;
+    return pl;
+  }
 
   if (kernel == 3) {
     const int mt = (t.mt >= 1 && t.mt <= 2) ? t.mt : (M <= 16 ? 1 : 2);
@@ -374,40 +565,8 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
   };
   int bm = t.bm;
   if (bm != 64 && bm != 128 && bm != 256 && bm != 258 && bm != 259 && bm != 130 && bm != 131) {
-    // Pick the tile height (and its K split) by a small cost model in microseconds:
-    //   rounds(tiles x ksplit over 256 CUs) x tile_time(rows, K / ksplit, rate(shape)) + split-K cost,
-    // per-shape rates (TOPS at large m) measured on MI355X (profiles/).  Bigger tiles are more efficient per
-    // MFMA but quantise worse over the CUs; split-K fills idle CUs at the price of int32 partial-sum traffic.
-    // Wave shapes per mode: per-channel keeps 64x128 wave tiles (least LDS traffic); per-group uses the
-    // column-owner shapes (258 / 130): every weight re-quantised once per workgroup.
-    // {several workgroups co-resident per CU, a single one} -- small tiles lose efficiency when alone on a CU
-    const double rate256 = grouped ? 1800.0 : 2300.0;
-    const double rate128[2] = {grouped ? 1360.0 : 2050.0, grouped ? 1320.0 : 1650.0};
-    const double rate64[2] = {grouped ? 800.0 : 1560.0, grouped ? 650.0 : 1170.0};
     int best_ks = 1;
-    double best = 1e30;
-    auto consider = [&](int rows, const double* rates, int code) {
-      const long long tl = (long long)((M + rows - 1) / rows) * strips;
-      const int ks_max = (tl < 192 && have_scratch) ? clampi((int)((256 + tl - 1) / tl), 1, (K / 128) / 4 > 0 ? (K / 128) / 4 : 1) : 1;
-      for (int ks = 1; ks <= ks_max; ++ks) {
-        const int S = slot_count(rows, ks);
-        if (ks > 1 && S == 0 && (long long)ks * M > cap_rows) break;
-        const double rate = (rows == 256) ? rates[0] : rates[(tl * ks <= 256) ? 1 : 0];
-        const double tile_us = (double)rows * ((double)K / ks) * 131072.0 / (rate * 1e6) + 6.0;  // + prologue/epilogue
-        double us = (double)((tl * ks + 255) / 256) * tile_us;
-        if (ks > 1 && S > 0)  // every deposit is written once and read once (~4.2 TB/s chip-wide) + serial hops
-          us += 3.0 + 2.0 * (ks - 1) * (double)tl * rows * 1024.0 / 4.2e6 + 3.0 * (double)((ks - 1 + S - 1) / S);
-        else if (ks > 1) us += 5.0 + (double)ks * M * N * 8.0 / 3.0e6;  // slabs written + read at ~3 TB/s, + launch
-        if (us < best) {
-          best = us;
-          bm = code;
-          best_ks = ks;
-        }
-      }
-    };
-    consider(256, &rate256, grouped ? 258 : 256);
-    consider(128, rate128, grouped ? 130 : 131);
-    consider(64, rate64, 64);
+    (void)tiled_estimate(M, N, K, grouped, have_scratch, cap_rows, cap_tickets, t.fused == 2, &bm, &best_ks);
     if (t.ksplit <= 0) t.ksplit = best_ks;
   }
   // glds: 2 = register-staged, 1 = LDS-DMA ring with `stages` buffers; auto: the DMA ring pays at the
@@ -514,11 +673,15 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
   DeviceGuard guard(dev);
   hipError_t e = hipSuccess;
   bool reduce_launch;
-  if ((pl.kernel == 1 || pl.kernel == 3) && (M + 16 * pl.mt - 1) / (16 * pl.mt) > 65535) {
+  if ((pl.kernel == 1 || pl.kernel == 3 || pl.kernel == 4) && (M + 16 * pl.mt - 1) / (16 * pl.mt) > 65535) {
     snprintf(g_err, sizeof(g_err), "m=%d exceeds the grid of the small-m kernels (forced by tune)", M);
     return QQQ_ERR_ARG;
   }
-  if (pl.kernel == 3) {
+  if (pl.kernel == 4) {
+    e = launch_panel(a, grouped, pl.mt, pl.bm, pl.waves, pl.pf, pl.stages, pl.ksplit);
+    if (e != hipSuccess) return fail_hip(e, "qqq_panel_kernel launch");
+    reduce_launch = false;
+  } else if (pl.kernel == 3) {
     e = launch_column(a, grouped, pl.mt, pl.pf, pl.ksplit);
     if (e != hipSuccess) return fail_hip(e, "qqq_column_kernel launch");
     reduce_launch = pl.ksplit > 1;

@@ -62,14 +62,18 @@ class QuantLinear(nn.Module):
             self.bias = None
 
     def _apply(self, fn):
-        # keep scale dtypes pinned across .half()/.to() (qlinear_marlin.py:141-145); the bias too: the fused
-        # epilogue reads it as fp16 bits, and the reference's own `prepare_for_inference` does model.to(bf16/fp32)
-        # (its `D + self.bias` merely promotes; here the add stays fp16 + fp16 -> fp16, the reference's default)
-        super()._apply(fn)
-        self.s_group = self.s_group.to(torch.half)
-        self.s_channel = self.s_channel.to(torch.float32)
+        # Keep scale dtypes pinned across .half()/.to() (qlinear_marlin.py:141-145) -- and the bias: the fused epilogue
+        # reads it as fp16 bits, and the reference's own `prepare_for_inference` does model.to(bf16/fp32).  Unlike the
+        # reference's pin (cast there and back: fp32 -> bf16 -> fp32 rounds the scales to 8 bits), the stored VALUES are
+        # preserved: the pinned tensors only follow device moves.
+        keep = {"s_group": self.s_group, "s_channel": self.s_channel}
         if self.bias is not None:
-            self.bias = self.bias.to(torch.half)
+            keep["bias"] = self.bias
+        super()._apply(fn)
+        for name, old in keep.items():
+            cur = getattr(self, name)
+            if cur.dtype != old.dtype:  # a dtype cast: take the original values to wherever the module now lives
+                setattr(self, name, old.to(device=cur.device))
         return self
 
     def post_init(self):

@@ -67,6 +67,16 @@ def variants(M, K, N):
         v += [dict(kernel=3), dict(kernel=3, mt=1, pf=4), dict(kernel=3, mt=2, pf=4), dict(kernel=3, mt=1, pf=12, ksplit=2)]
         if K // 64 >= 3:
             v += [dict(kernel=3, mt=2, pf=8, ksplit=3), dict(kernel=3, mt=1, pf=2), dict(kernel=3, mt=1, pf=6)]
+    if N % 64 == 0:  # panel kernel: all tokens of an m-block x 128 / 256 columns x a K slice, in-launch split-K
+        nst = (K // 64 + 1) // 2
+        for mt in (1, 2, 4, 8):
+            v.append(dict(kernel=4, mt=mt, ksplit=1))
+        v += [dict(kernel=4), dict(kernel=4, bm=256), dict(kernel=4, waves=4), dict(kernel=4, pf=2), dict(kernel=4, bm=256, pf=2, mt=2),
+              dict(kernel=4, pf=8, mt=1), dict(kernel=4, pf=3), dict(kernel=4, pf=4, stages=2, mt=4)]
+        if nst >= 2:
+            v += [dict(kernel=4, ksplit=2), dict(kernel=4, bm=256, ksplit=2, mt=4), dict(kernel=4, waves=4, ksplit=2, pf=2)]
+        if nst >= 3:
+            v += [dict(kernel=4, ksplit=3, mt=1), dict(kernel=4, bm=256, ksplit=3)]
     if K % 128 == 0:
         for bm in (64, 128, 256):
             v.append(dict(kernel=2, bm=bm, glds=2, ksplit=1))

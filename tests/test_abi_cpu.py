@@ -111,13 +111,22 @@ def test_dispatch_plan_respects_scratch_contract(L):
             for max_par in (1, 4, 16):
                 for m in (1, 7, 16, 64, 128, 129, 200, 256, 300, 512, 640, 1000, 1024, 1025, 2048, 4096, 32768):
                     p = _lib.plan(m, n, k, 128 if grouped else -1, max_par)
-                    assert p["kernel"] in (1, 2, 3) and p["ksplit"] >= 1
+                    assert p["kernel"] in (1, 2, 3, 4) and p["ksplit"] >= 1
                     cap_rows, cap_tk = max_par * 64, (n // 128) * max_par
+                    if p["kernel"] == 4:  # panel: one slot of C per depositing slice, two ticket words per tile
+                        rows, bn = 16 * p["mt"], p["bm"]
+                        mblocks, strips = -(-m // rows), -(-n // bn)
+                        assert n % 64 == 0 and k % 64 == 0 and bn in (128, 256) and p["mt"] in (1, 2, 4, 8)
+                        if p["ksplit"] > 1:
+                            assert mblocks * rows * (p["ksplit"] - 1) <= cap_rows and 2 * mblocks * strips <= cap_tk
+                            assert p["ksplit"] <= ((k // 64 + 1) // 2)
+                        assert _lib.plan(m, n, k, 128 if grouped else -1, max_par, have_scratch=False)["ksplit"] == 1
+                        continue
                     if p["kernel"] == 3:
                         assert m <= 16 and n % 64 == 0 and k % 64 == 0 and p["ksplit"] == 1
                         continue
                     if p["kernel"] == 1:
-                        assert m <= 128 or k % 128
+                        assert m <= 256 or k % 128 or n % 64  # the stream family is only chosen for a few m-blocks
                         if p["ksplit"] > 1:
                             assert p["ksplit"] * m <= cap_rows and p["fused"] == 2
                         continue

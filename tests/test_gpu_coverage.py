@@ -245,7 +245,7 @@ def test_per_group_gemm_with_scales_in_the_wrap_region(dev):
     assert np.array_equal(eacc, R.gemm_int32(A, R.weight_operand(B, s3, True)))
     h = GemmHarness(B, s2, s3, dev)
     for tune in (None, dict(kernel=1), dict(kernel=3, mt=2), dict(kernel=2, bm=64), dict(kernel=2, bm=130, glds=1, stages=3),
-                 dict(kernel=2, bm=258, glds=1, stages=3), dict(kernel=2, bm=256, glds=1, stages=6)):
+                 dict(kernel=2, bm=258, glds=1, stages=3), dict(kernel=2, bm=256, glds=1, stages=6), dict(kernel=4), dict(kernel=4, bm=256, ksplit=2)):
         D, acc = h.run(A, s1, tune)
         assert np.array_equal(acc, eacc), tune
         assert ulp_distance(D, eD) == 0, tune

@@ -118,7 +118,8 @@ def test_random_shapes_against_oracle(dev):
             s2 = (rng.random((1, N), dtype=np.float32) * 2e-4 + 1e-5)
             eD, eacc = C.qqq_gemm(A, B, s1, s2, s3 if grouped else None, return_acc=True)
             h = GemmHarness(B, s2, s3, dev)
-            tunes = [None, dict(kernel=1), dict(kernel=1, ksplit=2, fused=1), dict(kernel=3), dict(kernel=3, mt=2, ksplit=2)]
+            tunes = [None, dict(kernel=1), dict(kernel=1, ksplit=2, fused=1), dict(kernel=3), dict(kernel=3, mt=2, ksplit=2),
+                     dict(kernel=4), dict(kernel=4, bm=256, ksplit=2), dict(kernel=4, waves=4, mt=2, pf=2), dict(kernel=4, mt=8, ksplit=3)]
             if K % 128 == 0:
                 tunes += [dict(kernel=2), dict(kernel=2, bm=64, glds=1, stages=3), dict(kernel=2, bm=130, glds=1, stages=5),
                           dict(kernel=2, bm=258, glds=1, stages=3, ksplit=2)]
@@ -219,9 +220,16 @@ def test_baseline_sizes_against_oracle(grouped, dev):
     # property: the decode (column) kernel and the stream kernel agree bit-for-bit at full size, any m <= 16
     A, s1, D, acc = ref_rows[16]
     for m in (1, 5, 16):
-        for tune in (dict(kernel=3), dict(kernel=3, pf=8, ksplit=2), dict(kernel=1)):
+        for tune in (dict(kernel=3), dict(kernel=3, pf=8, ksplit=2), dict(kernel=1), dict(kernel=4), dict(kernel=4, bm=256, ksplit=8)):
             Dm, accm = h.run(A[:m].numpy(), s1[:m].numpy(), tune)
             assert np.array_equal(accm, acc[:m]) and np.array_equal(Dm.view(np.uint16), D[:m].view(np.uint16)), (m, tune)
+    # property: the panel kernel (every shape) agrees with the automatic dispatch at full size for m = 16 .. 128
+    for m_src, ms in ((128, (128, 100, 64, 33)), (16, (16, 9))):
+        A, s1, D, acc = ref_rows[m_src]
+        for m in ms:
+            for tune in (dict(kernel=4), dict(kernel=4, bm=256), dict(kernel=4, waves=4), dict(kernel=4, ksplit=1, mt=2), dict(kernel=4, pf=2, ksplit=5)):
+                Dm, accm = h.run(A[:m].numpy(), s1[:m].numpy(), tune)
+                assert np.array_equal(accm, acc[:m]) and np.array_equal(Dm.view(np.uint16), D[:m].view(np.uint16)), (m, tune)
     # property: token order does not matter (rows independent) -- permute the M=128 batch
     A, s1, D, acc = ref_rows[128]
     perm = np.random.default_rng(3).permutation(128)
