@@ -230,15 +230,57 @@ def cpu_baseline(sample_rows=64, budget_s=12.0):
     return out
 
 
-def measured_traffic(key):
-    """HBM/fabric bytes per launch of the roofline kernels, from the committed rocprofv3 PMC passes
-    (profiles/hbm_traffic.json: FETCH_SIZE / WRITE_SIZE collected in separate --pmc runs and corrected as
-    MI355X_MICROARCH.md prescribes).  None when the file has no entry."""
+def committed_traffic(key):
+    """bytes per launch from the committed rocprofv3 PMC passes (profiles/hbm_traffic.json, tools/pmc_traffic.sh)"""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
         return d[key]["bytes"]
     except Exception:
         return None
+
+
+def live_traffic(timeout_s=240):
+    """HBM/fabric bytes per launch of the two roofline kernels, measured NOW with rocprofv3 exactly as
+    MI355X_MICROARCH.md's HBM section prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes (with
+    --kernel-trace only), read bytes = 2 x FETCH_SIZE KiB (gfx950 correction), write bytes = WRITE_SIZE KiB.
+    Each pass re-runs the same launches (tools/prof_calls.py: M=1 and M=4096 on the BASELINE layer) in a child process.
+    Returns ({kernel-key: bytes}, note); on any failure ({}, reason) and the caller falls back to the committed pass."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {}, "rocprofv3 not found"
+    vals = {}
+    tmp = tempfile.mkdtemp(prefix="qqq_pmc_", dir="/tmp")
+    try:
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, c)
+            cmd = [exe, "--pmc", c, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "t", "--",
+                   sys.executable, os.path.join(ROOT, "tools", "prof_calls.py"), "--ms", "1,4096", "--iters", "3"]
+            p = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if p.returncode != 0 or not files:
+                return {}, f"rocprofv3 --pmc {c} failed (rc={p.returncode})"
+            for r in csv.DictReader(open(files[0])):
+                if r["Counter_Name"] != c:
+                    continue
+                name = r["Kernel_Name"]
+                key = "tiled_m4096" if "qqq_tiled_kernel" in name else "column_m1" if "qqq_column_kernel" in name else None
+                if key:
+                    vals.setdefault(key, {}).setdefault(c, []).append(float(r["Counter_Value"]))
+        res = {}
+        for key, v in vals.items():
+            if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+                res[key] = int(2 * 1024 * np.mean(v["FETCH_SIZE"]) + 1024 * np.mean(v["WRITE_SIZE"]))
+        return res, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) run by bench.py after the timed region"
+    except Exception as e:  # pragma: no cover
+        return {}, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def cpu_model_name():
@@ -259,6 +301,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-fp16", action="store_true", help="skip the torch fp16 GPU GEMM comparison")
     ap.add_argument("--detail-iters", type=int, default=30)
+    ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 PMC traffic passes; quote the committed ones")
     ap.add_argument("--check", action="store_true",
                     help="after the timed region verify the gathered outputs of the sharded points against a local full GEMM")
     args = ap.parse_args()
@@ -424,11 +467,20 @@ def main():
             cold = layer.time_calls(A, s1, Dfull[M], it, rotate=True) * 1e3
             warm = layer.time_calls(A, s1, Dfull[M], it, rotate=False) * 1e3
             us = float(np.mean(cold))
+            from qqq_amd import _lib as _L
+
+            pln = _L.plan(M, N_FULL, K_FULL, -1, MAX_PAR)
             entry = {
                 "us": us, "us_median": float(np.median(cold)), "us_min": float(np.min(cold)), "us_warm_l3": float(np.mean(warm)),
                 "tops": algorithmic_ops(M, N_FULL, K_FULL) / us / 1e6,
                 "gbs": algorithmic_bytes(M, N_FULL, K_FULL) / us / 1e3,
+                "kernel": {1: "stream", 2: "tiled", 3: "column", 4: "panel"}[pln["kernel"]], "ksplit": pln["ksplit"],
             }
+            # the roof that binds this point: HBM below the ridge (~629 op/B), MFMA above
+            hbm_us = algorithmic_bytes(M, N_FULL, K_FULL) / PEAK_HBM_GBS / 1e3
+            mfma_us = algorithmic_ops(M, N_FULL, K_FULL) / PEAK_MFMA_TOPS / 1e6
+            entry["roof"] = "hbm" if hbm_us >= mfma_us else "mfma"
+            entry["roof_frac"] = max(hbm_us, mfma_us) / us
             if not args.no_fp16:
                 f = fp16_gemm_us(dev, M)
                 entry["fp16_gemm_us"] = f
@@ -440,20 +492,30 @@ def main():
                 entry["speedup_vs_fp16"] = f / us
             per_m[str(M)] = entry
         result["per_m"] = per_m
+        live, traffic_note = ({}, "skipped (--no-pmc)") if args.no_pmc else live_traffic()
         a = per_m["4096"]
         result["roofline"] = {
             "kernel": "qqq_tiled_kernel (M=4096)", "bound": "mfma", "achieved": a["tops"], "peak": PEAK_MFMA_TOPS,
-            "unit": "TOPS", "frac": a["tops"] / PEAK_MFMA_TOPS, "traffic": measured_traffic("qqq_tiled_kernel_M4096"),
-            "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/hbm_traffic.json)",
+            "unit": "TOPS", "frac": a["tops"] / PEAK_MFMA_TOPS,
+            "traffic": live.get("tiled_m4096", committed_traffic("qqq_tiled_kernel_M4096")),
+            "traffic_unit": "bytes/launch, L2<->fabric (HBM + Infinity Cache)",
+            "traffic_source": traffic_note if "tiled_m4096" in live else f"profiles/hbm_traffic.json (committed PMC pass; live pass: {traffic_note})",
             "algorithmic_bytes": algorithmic_bytes(4096, N_FULL, K_FULL), "avg_launch_us": a["us"],
+            "frac_of_ubench_ceiling": a["tops"] / 4404.0,
+            "note": "peak = 256 CU x 2.4 GHz x 8192 int8 op/clk; 4404 TOPS is the v_mfma_i32_32x32x32_i8 micro-benchmark ceiling; "
+                    "under this kernel the chip clocks ~1.9 GHz (power), profiles/r02_pmc_tiled_m4096.txt",
         }
         h = per_m["1"]
         result["roofline_hbm"] = {
             "kernel": "qqq_column_kernel (M=1, decode)", "bound": "hbm", "achieved": h["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
-            "frac": h["gbs"] / PEAK_HBM_GBS, "traffic": measured_traffic("qqq_column_kernel_M1"),
-            "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/hbm_traffic.json)",
+            "frac": h["gbs"] / PEAK_HBM_GBS,
+            "traffic": live.get("column_m1", committed_traffic("qqq_column_kernel_M1")),
+            "traffic_unit": "bytes/launch, L2<->fabric (HBM + Infinity Cache)",
+            "traffic_source": traffic_note if "column_m1" in live else f"profiles/hbm_traffic.json (committed PMC pass; live pass: {traffic_note})",
             "algorithmic_bytes": algorithmic_bytes(1, N_FULL, K_FULL), "avg_launch_us": h["us"],
-            "note": "one launch per call (no split-K); the figure is the whole call incl. launch latency, cold Infinity Cache",
+            "frac_of_measured_read_ceiling": h["gbs"] / 6290.0,
+            "note": "one launch per call (no split-K); the figure is the whole call incl. launch latency, cold Infinity Cache; "
+                    "6.29 TB/s is the streaming-read ceiling measured on this part (MI355X_MICROARCH.md)",
         }
         # per-group (BASELINE configs[2]) detail
         try:

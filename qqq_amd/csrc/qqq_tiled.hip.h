@@ -45,7 +45,8 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * (2 / NB) * 64) void 
   // NS == 6: LDS-DMA ring of 3 stages, ONE barrier per 128-k block placed two k-steps before the stage
   //          switch, fragment pipeline (W reads 2 steps ahead, unpack 1 step ahead) running across it
   constexpr bool PINGPONG = (NS == 5);
-  constexpr bool CONTPIPE = (NS == 6);
+  constexpr bool CONTPIPE = (NS == 6 || NS == 7);
+  constexpr bool ILV = (NS == 7);  // NS == 7: as 6, with the LDS fragment reads and the DMA issue spread between the MFMAs too
   constexpr int NSTAGE = (PINGPONG || CONTPIPE) ? 3 : NS;
   constexpr int SC_BYTES = (GLDS && GROUPED) ? WM * WN * 512 : 0;  // per-wave slot of group scales
   constexpr int STAGE = W_BYTES + X_BYTES + SC_BYTES;
@@ -400,7 +401,7 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * (2 / NB) * 64) void 
             wait_younger(0);  // this wave's DMA of stage i+1 (the only one in flight) has landed
             __syncthreads();  // ... and everybody else's
           }
-          {
+          if constexpr (!ILV) {
             // DMA issue of a stage spread over the 3 k-steps behind the barrier (2 of the wave's 6 instructions
             // each): a burst of all 8 waves x 6 KB right behind the barrier overruns the address pipe (~30
             // cycles per 1 KB instruction, measured with s_memtime stamps), and an in-order wave stuck in VMEM issue
@@ -411,12 +412,17 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * (2 / NB) * 64) void 
             if (part < SPREAD && stg < nkb && stg >= 2) issue_loads(kb_begin + stg, stg % 3, part, SPREAD);
           }
           __builtin_amdgcn_sched_barrier(0);
-          // fragment reads: W two steps ahead, X one step ahead
-          read_w((t + 2 < 4) ? st : stn, (t + 2) & 3, wraw[t & 1]);
-          read_x((t + 1 < 4) ? st : stn, (t + 1) & 3, xfr[(t + 1) & 1]);
-          if constexpr (GROUPED)
+          if constexpr (!ILV) {
+            // fragment reads: W two steps ahead, X one step ahead
+            read_w((t + 2 < 4) ? st : stn, (t + 2) & 3, wraw[t & 1]);
+            read_x((t + 1 < 4) ? st : stn, (t + 1) & 3, xfr[(t + 1) & 1]);
+            if constexpr (GROUPED)
+              if (t == 3) sc_cur = *reinterpret_cast<const hsc*>(stn + scrd);  // scales of the block being unpacked
+            __builtin_amdgcn_sched_barrier(0);
+          } else if constexpr (GROUPED) {
             if (t == 3) sc_cur = *reinterpret_cast<const hsc*>(stn + scrd);  // scales of the block being unpacked
-          __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
           // hand-interleaved issue order: one MFMA of step u, then the unpack of one packed word of step
           // u+1 (hipcc otherwise issues the 8 MFMAs back to back and leaves the VALU work uncovered)
           constexpr int NM = MTW * JW * NB;  // MFMAs per step
@@ -427,6 +433,24 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * (2 / NB) * 64) void 
               const int jj = q / (MTW * NB), mt = (q / NB) % MTW, bi = q % NB;
               acc[mt][jj][bi] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ops2[t & 1].a[jj][bi], xfr[t & 1][mt],
                                                                       acc[mt][jj][bi], 0, 0, 0);
+            }
+            if constexpr (ILV) {
+              // one LDS fragment read (W two steps ahead: 4 pieces, then X one step ahead: MTW pieces) or one DMA
+              // instruction behind every MFMA instead of a burst in front of the step
+              static_assert(!ILV || (JW == 2 && 4 + MTW + 2 <= MTW * JW * NB), "interleave slots");
+              if (q < 4) {
+                const unsigned char* p = ((t + 2 < 4) ? st : stn) + wrd[q] + ((t + 2) & 3) * 4096;
+                const uint2 v = *reinterpret_cast<const uint2*>(p);
+                wraw[t & 1][q][0] = v.x;
+                wraw[t & 1][q][1] = v.y;
+              } else if (q < 4 + MTW) {
+                xfr[(t + 1) & 1][q - 4] =
+                    *reinterpret_cast<const v4i*>(((t + 1 < 4) ? st : stn) + xrd[(t + 1) & 3] + (q - 4) * (32 * 128));
+              } else if (q < 4 + MTW + 2) {
+                const int part = (t + 2) & 3;  // t=2 -> 0, t=3 -> 1, t=0 -> 2: a third of the stage per k-step
+                const int stg = (t >= 2) ? i + 2 : i + 1;
+                if (part < 3 && stg < nkb && stg >= 2) issue_loads(kb_begin + stg, stg % 3, 2 * part + (q - 4 - MTW), 6);
+              }
             }
             if (q < NWD) {
               const int kq = q & 3, jj = q >> 2;

@@ -257,7 +257,7 @@ static hipError_t launch_tiled_t(const LaunchArgs& a, int ksplit, int nslots, in
   constexpr int WAVES = (BM / (32 * MTW)) * (4 / JW) * (2 / NB);
   constexpr int NT = WAVES * 64;
   constexpr int STAGE = 8 * 2048 + BM * 128 + ((NS > 0 && GROUPED) ? WAVES * 512 : 0);
-  constexpr int RING = ((NS == 5 || NS == 6) ? 3 : (NS > 0 ? NS : 2)) * STAGE;
+  constexpr int RING = ((NS == 5 || NS == 6 || NS == 7) ? 3 : (NS > 0 ? NS : 2)) * STAGE;
   constexpr int LDS = RING > BM * 512 ? RING : BM * 512;  // the epilogue stages the fp16 tile (BM x 512 B)
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static bool attr_set[64] = {};  // per instantiation, per device
@@ -318,6 +318,7 @@ static hipError_t launch_tiled_bm(const LaunchArgs& a, int bm, int stages, int k
       if (stages == 2) return launch_tiled_t<256, 2, 2, 2, GROUPED, 2>(a, ksplit, nslots, pw);
       if (stages == 5) return launch_tiled_t<256, 2, 2, 2, GROUPED, 5>(a, ksplit, nslots, pw);
       if (stages == 6) return launch_tiled_t<256, 2, 2, 2, GROUPED, 6>(a, ksplit, nslots, pw);
+      if (stages == 7) return launch_tiled_t<256, 2, 2, 2, GROUPED, 7>(a, ksplit, nslots, pw);
       return launch_tiled_t<256, 2, 2, 2, GROUPED, 3>(a, ksplit, nslots, pw);
   }
 }
@@ -573,8 +574,8 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
   // 8-wave 256-row tile, register staging is faster for the 4-wave tiles (measured)
   int stages;
   if (t.glds == 2) stages = 0;
-  else if (t.glds == 1) stages = ((t.stages >= 2 && t.stages <= 4) || (t.stages == 5 && bm != 64 && bm != 128) || (t.stages == 6 && bm == 256)) ? t.stages : (bm >= 256 ? 3 : 4);
-  else stages = (bm == 256) ? 6 : (bm == 258) ? 2 : (bm == 130) ? 4 : 0;  // measured best per shape (profiles/r01_tune_sweep_*.txt)
+  else if (t.glds == 1) stages = ((t.stages >= 2 && t.stages <= 4) || (t.stages == 5 && bm != 64 && bm != 128) || ((t.stages == 6 || t.stages == 7) && bm == 256)) ? t.stages : (bm >= 256 ? 3 : 4);
+  else stages = (bm == 256) ? 7 : (bm == 258) ? 2 : (bm == 130) ? 4 : 0;  // measured best per shape (profiles/r01_tune_sweep_*.txt, r02_tiled_ns7.txt)
   if (bm >= 256 && stages == 4) stages = 3;
   const int bm_rows = (bm >= 256) ? 256 : (bm >= 128 ? 128 : bm);
   const long long tiles = (long long)((M + bm_rows - 1) / bm_rows) * strips;

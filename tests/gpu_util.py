@@ -80,7 +80,7 @@ def variants(M, K, N):
     if K % 128 == 0:
         for bm in (64, 128, 256):
             v.append(dict(kernel=2, bm=bm, glds=2, ksplit=1))
-            for stages in (2, 3, 4) + ((5, 6) if bm == 256 else ()):
+            for stages in (2, 3, 4) + ((5, 6, 7) if bm == 256 else ()):
                 v.append(dict(kernel=2, bm=bm, glds=1, stages=stages, ksplit=1))
         for bm in (258, 259, 130, 131):  # other wave shapes of the 256- and 128-row tiles
             for stages in (2, 3, 5):
@@ -89,6 +89,7 @@ def variants(M, K, N):
             v.append(dict(kernel=2, bm=258, glds=1, stages=5, ksplit=2))
             v.append(dict(kernel=2, bm=256, glds=1, stages=5, ksplit=2))
             v.append(dict(kernel=2, bm=256, glds=1, stages=6, ksplit=2))
+            v.append(dict(kernel=2, bm=256, glds=1, stages=7, ksplit=2))
             v.append(dict(kernel=2, bm=128, glds=1, stages=3, ksplit=2))
             v.append(dict(kernel=2, bm=64, glds=2, ksplit=2))
             # tiled split-K: fused=1 in-launch (slots + tickets; also the default), fused=2 slabs + reduce launch
