@@ -349,7 +349,7 @@ static double tiled_estimate(int M, int N, int K, bool grouped, bool have_scratc
     return (int)S;
   };
   // {several workgroups co-resident per CU, a single one} -- small tiles lose efficiency when alone on a CU
-  const double rate256 = grouped ? 1800.0 : 2300.0;
+  const double rate256 = grouped ? 1950.0 : 2500.0;
   const double rate128[2] = {grouped ? 1360.0 : 2050.0, grouped ? 1320.0 : 1650.0};
   const double rate64[2] = {grouped ? 800.0 : 1560.0, grouped ? 650.0 : 1170.0};
   double best = 1e30;
@@ -402,7 +402,7 @@ static double panel_estimate(int M, int N, int K, bool grouped, bool have_scratc
   double best = 1e30;
   for (int bn = 128; bn <= 256; bn *= 2) {
     const long long tl = mblocks * ((N + bn - 1) / bn);
-    const double t_stage = (0.13 + 0.042 * mt) * (bn == 256 ? 1.7 : 1.0) * (grouped ? 1.45 : 1.0);
+    const double t_stage = (0.13 + 0.042 * mt) * (bn == 256 ? 1.9 : 1.0) * (grouped ? 1.45 : 1.0);
     for (int ks = 1; ks <= 4; ++ks) {
       if (ks > 1 && (!have_scratch || 2 * tl > cap_tickets || mblocks * rows * (ks - 1) > cap_rows || ks > NST / 4)) break;
       static const double tail[5] = {0.0, 0.0, 7.0, 9.0, 11.0};
