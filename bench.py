@@ -269,7 +269,10 @@ def live_traffic(timeout_s=240):
                 if r["Counter_Name"] != c:
                     continue
                 name = r["Kernel_Name"]
-                key = "tiled_m4096" if "qqq_tiled_kernel" in name else "column_m1" if "qqq_column_kernel" in name else None
+                # the child runs M=1 (decode: column / stream kernel, <= 512 workgroups) and M=4096 (tiled / panel)
+                big = any(k in name for k in ("qqq_tiled_kernel", "qqq_panel_kernel"))
+                small = any(k in name for k in ("qqq_column_kernel", "qqq_stream_kernel"))
+                key = "tiled_m4096" if big else "column_m1" if small else None
                 if key:
                     vals.setdefault(key, {}).setdefault(c, []).append(float(r["Counter_Value"]))
         res = {}
