@@ -442,10 +442,12 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
   int kernel = t.kernel;
   const bool column_ok = (N % 64) == 0 && (K % 64) == 0;
   if (kernel == 0) {
-    // measured (profiles/r01_tune_decode.txt): every column workgroup re-reads the m x K activations, so beyond
-    // m = 8 it only wins while that stays small; very wide layers at m > 8 are better off with strips
-    const bool column = column_ok && M <= 16 && N / 32 >= 64 &&
-                        (M <= 8 || ((long long)M * K <= (grouped ? 524288 : 262144) && N / 32 <= 512));
+    // measured (profiles/r01_tune_decode.txt, r02_decode_sweep.txt): every column workgroup re-reads the m x K
+    // activations (per-lane 16-byte loads of 16 rows), so beyond m = 8 it only wins while m*K stays small -- but then
+    // up to 32 tokens (two 16-token tiles per wave), where it saves the stream kernel's reduce launch
+    const long long mk = (long long)M * K;
+    const bool column = column_ok && N / 32 >= 64 &&
+                        (M <= 8 || (M <= 32 && N / 32 <= 512 && mk <= (grouped ? (M <= 16 ? 360000 : 140000) : 200000)));
     if (column) kernel = 3;
     else kernel = (M <= 128 || (K % 128) != 0) ? 1 : 2;
     // Above the decode regime the family is picked by the three cost models.  The panel kernel is also the MFMA path

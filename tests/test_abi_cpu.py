@@ -123,7 +123,7 @@ def test_dispatch_plan_respects_scratch_contract(L):
                         assert _lib.plan(m, n, k, 128 if grouped else -1, max_par, have_scratch=False)["ksplit"] == 1
                         continue
                     if p["kernel"] == 3:
-                        assert m <= 16 and n % 64 == 0 and k % 64 == 0 and p["ksplit"] == 1
+                        assert m <= 32 and n % 64 == 0 and k % 64 == 0 and p["ksplit"] == 1
                         continue
                     if p["kernel"] == 1:
                         assert m <= 256 or k % 128 or n % 64  # the stream family is only chosen for a few m-blocks
