@@ -27,7 +27,14 @@ def _ptr(t: Optional[torch.Tensor]):
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream_for(t: torch.Tensor):
+    # the raw hipStream_t of t's device; the private fast path saves ~1.5 us of Stream-object construction per call
+    if _raw_stream is not None:
+        idx = t.device.index
+        return _raw_stream(idx if idx is not None else torch.cuda.current_device())
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
@@ -233,11 +240,13 @@ def quantlinear_forward(x: torch.Tensor, B, C, s2, s3, workspace, bias=None, max
         raise RuntimeError("quantlinear_forward: expected a contiguous 2-D fp16 tensor on the GPU (there is no CPU path)")
     m, k = x.shape
     n = C.size(1)
-    if B.numel() != (k // 16) * (n * 2) or B.device != x.device:
+    dev = x.device
+    if B.size(0) * 16 != k or B.device != dev:
         raise RuntimeError("quantlinear_forward: B must be the packed [k/16, 2n] weight on x's device")
     groupsize = -1 if s3.numel() == 0 else k // s3.size(0)
-    # the cheap subset of _check_common: everything the kernels would read as raw bits
-    dev = x.device
+    # everything the kernels would read as raw bits
+    if B.numel() != (k // 16) * (n * 2):
+        raise RuntimeError("quantlinear_forward: B must be the packed [k/16, 2n] weight on x's device")
     if (B.dtype != torch.int32 or C.dtype != torch.int32 or workspace.dtype != torch.int32 or s2.dtype != torch.float32
             or C.device != dev or s2.device != dev or workspace.device != dev
             or not (B.is_contiguous() and C.is_contiguous() and s2.is_contiguous() and workspace.is_contiguous())):

@@ -121,11 +121,14 @@ class QuantLinear(nn.Module):
     def forward(self, A):
         # reference: dynamic_quant (:265-268) -> mul (:28-45) -> `D + self.bias` (:287); here one binding call that
         # launches the fused quantiser and the GEMM with the bias in its epilogue (fp16 add after the fp16 round)
-        out_shape = A.shape[:-1] + (self.outfeatures,)
-        A = A.reshape(-1, A.shape[-1]).half().contiguous()
-        D = ops.quantlinear_forward(A, self.B, self.reduce_buffer, self.s_channel, self.s_group, self.workspace,
+        if A.dim() == 2 and A.dtype == torch.half and A.is_contiguous():
+            x, out_shape = A, None  # the common serving case: nothing to reshape or cast
+        else:
+            out_shape = A.shape[:-1] + (self.outfeatures,)
+            x = A.reshape(-1, A.shape[-1]).half().contiguous()
+        D = ops.quantlinear_forward(x, self.B, self.reduce_buffer, self.s_channel, self.s_group, self.workspace,
                                     self.bias, max_par=self.max_par)
-        return D.reshape(out_shape)
+        return D if out_shape is None else D.reshape(out_shape)
 
 
 def fuse_quant_linears(layers) -> QuantLinear:

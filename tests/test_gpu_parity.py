@@ -333,3 +333,72 @@ def test_inlaunch_splitk_stress_two_streams(dev):
         assert torch.equal(D.view(torch.int16), want[(li, M)].view(torch.int16)), (li, M)
     for h in layers:
         assert int(h.ws.abs().sum().item()) == 0
+
+
+def test_panel_inlaunch_splitk_stress_two_streams(dev):
+    """The panel kernel's ticket / slot hand-off under load: two layers (own scratch each) hammered from two streams, varying m
+    (one to three m-blocks), K splits and shapes; every result must equal the unsplit stream kernel's bit for bit, the
+    workspaces must end all-zero, and the poisoned reduce buffer must never leak into an output."""
+    from qqq_amd import pack as P
+
+    g = torch.Generator(device="cpu").manual_seed(123)
+    N, K = 2048, 4096 + 64  # K % 128 == 64: the trailing half stage is exercised as well
+    layers = []
+    for i in range(2):
+        codes = torch.randint(-7, 8, (K, N), generator=g, dtype=torch.int8)
+        B = P.pack_codes(codes.to(dev), False)
+        s2 = (torch.rand((1, N), generator=g) * 2e-4 + 1e-5).to(torch.float32)
+        layers.append(GemmHarness(B, s2, None, dev))
+    Ms = [33, 64, 100, 128, 200, 256, 300]
+    toks, want = {}, {}
+    for M in Ms:
+        A = torch.randint(-128, 128, (M, K), generator=g, dtype=torch.int8).to(dev)
+        s1 = (torch.rand((M, 1), generator=g) * 0.05 + 0.001).to(torch.float32).to(dev)
+        toks[M] = (A, s1)
+        for li, h in enumerate(layers):
+            D = torch.empty((M, N), dtype=torch.float16, device=dev)
+            ops.qqq_gemm_ex(A, h.B, h.C, D, s1, h.s2, h.s3, h.ws, -1, -1, -1, 16, tune=dict(kernel=1, ksplit=1))
+            want[(li, M)] = D
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    outs = []
+    for it in range(150):
+        for li, h in enumerate(layers):
+            M = Ms[(it + 2 * li) % len(Ms)]
+            A, s1 = toks[M]
+            tune = [dict(kernel=4), dict(kernel=4, ksplit=2 + it % 3), dict(kernel=4, bm=256, ksplit=2 + it % 2, pf=3),
+                    dict(kernel=4, waves=4, ksplit=4, pf=2), dict(kernel=4, mt=4, ksplit=3)][it % 5]
+            D = torch.empty((M, N), dtype=torch.float16, device=dev)
+            with torch.cuda.stream(streams[li]):
+                ops.qqq_gemm_ex(A, h.B, h.C, D, s1, h.s2, h.s3, h.ws, -1, -1, -1, 16, tune=tune)
+            outs.append((li, M, D))
+    torch.cuda.synchronize()
+    for li, M, D in outs:
+        assert torch.equal(D.view(torch.int16), want[(li, M)].view(torch.int16)), (li, M)
+    for h in layers:
+        assert int(h.ws.abs().sum().item()) == 0
+
+
+def test_k_tail_large_m_through_auto_dispatch(dev):
+    """K % 128 == 64 with many tokens (round 1 sent these to the stream kernel, one weight pass per 64 tokens): the
+    automatic dispatch must take the panel kernel and match the oracle on sampled rows."""
+    from oracle import c_oracle as C
+    from oracle import qqq_ref as R
+    from qqq_amd import _lib
+
+    rng = np.random.default_rng(8)
+    for (M, N, K, grouped) in ((1000, 1024, 1344, False), (3000, 768, 2112 + 64, False), (700, 512, 1280, True)):
+        codes = rng.integers(0, 16, size=(K, N), dtype=np.int8) if grouped else rng.integers(-8, 8, size=(K, N), dtype=np.int8)
+        s3 = (rng.random((K // 128, N), dtype=np.float32) * 15 + 0.5).astype(np.float16) if grouped else np.zeros((0,), np.float16)
+        B = R.pack_codes(codes, grouped)
+        A = rng.integers(-128, 128, size=(M, K), dtype=np.int8)
+        s1 = (rng.random((M, 1), dtype=np.float32) * 0.05 + 0.001)
+        s2 = (rng.random((1, N), dtype=np.float32) * 2e-4 + 1e-5)
+        if K % 128:
+            assert _lib.plan(M, N, K, 128 if grouped else -1, 16)["kernel"] == 4
+        h = GemmHarness(B, s2, s3, dev)
+        D, acc = h.run(A, s1, None)
+        rows = np.unique(np.r_[0, M - 1, rng.integers(0, M, 60)])
+        eD, eacc = C.qqq_gemm(A[rows], B, s1[rows], s2, s3 if grouped else None, return_acc=True)
+        assert np.array_equal(acc[rows], eacc), (M, N, K)
+        assert ulp_distance(D[rows], eD) == 0
