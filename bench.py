@@ -303,7 +303,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-fp16", action="store_true", help="skip the torch fp16 GPU GEMM comparison")
-    ap.add_argument("--detail-iters", type=int, default=30)
+    ap.add_argument("--detail-iters", type=int, default=100)
     ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 PMC traffic passes; quote the committed ones")
     ap.add_argument("--check", action="store_true",
                     help="after the timed region verify the gathered outputs of the sharded points against a local full GEMM")

@@ -1,5 +1,5 @@
-// qqq_panel.hip.h -- "panel" kernel (8 < m <= 128: weights HBM -> VGPR per wave, activations shared through LDS,
-// in-launch split-K).  Part of the single translation unit qqq_w4a8.hip (see its header comment for the design).
+// qqq_panel.hip.h -- "panel" kernel (about 64 .. 1024 tokens, in 128-token m-blocks: weights HBM -> VGPR per wave,
+// activations shared through LDS, in-launch split-K).  Part of the single translation unit qqq_w4a8.hip (see its header comment for the design).
 #ifndef QQQ_AMD_QQQ_PANEL_HIP_H_
 #define QQQ_AMD_QQQ_PANEL_HIP_H_
 
@@ -12,8 +12,8 @@
 //    no barrier on the weight path), PFS stages ahead.  The packed words are re-distributed between lanes with the
 //    column kernel's DPP 4x4 transpose; v_mfma_i32_16x16x64_i8, MFMA row i = 4*c' + jt.
 //  * The activations (16*MT tokens x 128 k per stage) are the operand every wave needs: they are staged ONCE per
-//    workgroup in a double-buffered LDS image (16-byte chunks XOR-swizzled by the row: every ds_read_b128 is
-//    conflict free), so the L1 traffic of a workgroup is weights + activations once -- not activations once per
+//    workgroup in a double- / triple-buffered LDS image (16-byte chunks XOR-swizzled by the row: every ds_read_b128
+//    is conflict free), so the L1 traffic of a workgroup is weights + activations once -- not activations once per
 //    wave as in the stream / column kernels, which is what bounds those above m = 16.  They travel global -> VGPR
 //    -> ds_write (XL stages ahead), NOT by LDS-DMA: measured on this part, global_load_lds moves ~34 B/clk/CU while
 //    plain 16-byte loads reach ~64 B/clk/CU (profiles/r01_probe_fill.txt), and at m = 128 a stage needs 24 KB of

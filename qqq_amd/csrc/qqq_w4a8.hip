@@ -20,18 +20,21 @@
 //    int32 partial-sum stores.  The integer dot products do not care about the k order inside
 //    an operand as long as both operands use the same order ("k-slot freedom"), and the
 //    packed order [kq][r] IS natural k order, so the activation operand is 16 contiguous bytes.
-//  * "column" kernel (decode, m <= 16): HBM-bound.  32 weight columns x all of K per workgroup, so a wide layer
+//  * "column" kernel (decode: m <= 8, up to 32 tokens while m*K is small): HBM-bound.  32 weight columns x all of K per workgroup, so a wide layer
 //    fills the chip without split-K (one launch per call); packed words re-distributed between lanes with DPP.
-//  * "stream" kernel (m <= 128): HBM-bound.  v_mfma_i32_16x16x64_i8; a lane (i = 8*g + c, h)
+//  * "stream" kernel (a few tens of tokens; small layers up to ~256): HBM-bound.  v_mfma_i32_16x16x64_i8; a lane (i = 8*g + c, h)
 //    loads its 64 weight bytes of k-tile 4*s + h straight from HBM into VGPRs (no LDS: the
 //    weights are used once), a wave eats 128 columns x 64 k = 4 KiB per step, waves of a
 //    workgroup split K and reduce through LDS, workgroups split K through int32 slabs in the
 //    reduce buffer C (int32 addition is associative: bit-exact for every split).
-//  * "tiled" kernel (m > 128): MFMA-bound.  v_mfma_i32_32x32x32_i8; BMx256 tiles, BK = 128,
+//  * "panel" kernel (about 64 .. 1024 tokens): all tokens of a 128-token m-block x 128 / 256 columns x a K slice per
+//    workgroup; the waves split the columns (weights HBM -> VGPR, once per workgroup), the activations are shared
+//    through LDS, software-pipelined 16x16x64 MFMAs, in-launch split-K with one slot of C per depositing slice.
+//  * "tiled" kernel (large m): MFMA-bound.  v_mfma_i32_32x32x32_i8; BMx256 tiles, BK = 128,
 //    activations and RAW packed weights staged in LDS by LDS-DMA (XOR-swizzled 16-byte chunks so that
 //    every fragment read is bank-conflict free), continuous fragment pipeline, XCD-aware tile order,
 //    in-launch split-K through tile-sized slots of C.
-//  Host side: make_plan() picks family / tile / split from a small measured cost model; the C-ABI entry points
+//  Host side: make_plan() picks family / tile / split from small measured cost models (one per family); the C-ABI entry points
 //  are at the end of the file.
 //
 // The accumulators are the reference's: per-channel weights enter as 16*w4 (high nibble of each
