@@ -271,7 +271,7 @@ def test_bias_survives_model_wide_dtype_casts(dev):
 
     with pytest.raises(RuntimeError, match="bias must be a contiguous fp16"):
         ops.quantlinear_forward(x, ql.B, ql.reduce_buffer, ql.s_channel, ql.s_group, ql.workspace, ql.bias.float())
-    with pytest.raises(RuntimeError, match="s2 needs n="):
+    with pytest.raises(RuntimeError, match="s2"):  # eager check or, on the dispatcher path, the custom op's own
         ops.quantlinear_forward(x, ql.B, ql.reduce_buffer, ql.s_channel[:, :128].contiguous(), ql.s_group, ql.workspace, None)
 
 
