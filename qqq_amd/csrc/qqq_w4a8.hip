@@ -407,7 +407,7 @@ static double panel_estimate(int M, int N, int K, bool grouped, bool have_scratc
     const long long tl = mblocks * ((N + bn - 1) / bn);
     const double t_stage = (0.13 + 0.042 * mt) * (bn == 256 ? 1.9 : 1.0) * (grouped ? 1.45 : 1.0);
     for (int ks = 1; ks <= 4; ++ks) {
-      if (ks > 1 && (!have_scratch || 2 * tl > cap_tickets || mblocks * rows * (ks - 1) > cap_rows || ks > NST / 4)) break;
+      if (ks > 1 && (!have_scratch || 2 * tl > cap_tickets || tl * rows * bn * (ks - 1) > cap_rows * (long long)N || ks > NST / 4)) break;  // slots: tiles x (ks-1) x rows x bn ints inside C
       static const double tail[5] = {0.0, 0.0, 7.0, 9.0, 11.0};
       const double wg_us = 8.7 + tail[ks] + ((double)NST / ks) * t_stage;
       const double us = (double)((tl * ks + 255) / 256) * wg_us;
@@ -491,7 +491,9 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
     if (ksplit > 1) {
       const long long cap_tk = (long long)(N / 128) * (max_par > 0 ? max_par : 0);
       if (2 * mblocks * strips > cap_tk) ksplit = 1;
-      while (ksplit > 1 && mblocks * rows * (ksplit - 1) > cap_rows) --ksplit;
+      // one slot of rows x bn ints per tile and depositing slice, all inside the max_par*64 x n ints of C (bn-wide strips
+      // may overhang n)
+      while (ksplit > 1 && mblocks * strips * rows * bn * (ksplit - 1) > cap_rows * (long long)N) --ksplit;
     }
     pl.mt = mt;
     pl.bm = bn;

@@ -118,7 +118,7 @@ def test_dispatch_plan_respects_scratch_contract(L):
                         mblocks, strips = -(-m // rows), -(-n // bn)
                         assert n % 64 == 0 and k % 64 == 0 and bn in (128, 256) and p["mt"] in (1, 2, 4, 8)
                         if p["ksplit"] > 1:
-                            assert mblocks * rows * (p["ksplit"] - 1) <= cap_rows and 2 * mblocks * strips <= cap_tk
+                            assert mblocks * strips * rows * bn * (p["ksplit"] - 1) <= cap_rows * n and 2 * mblocks * strips <= cap_tk
                             assert p["ksplit"] <= ((k // 64 + 1) // 2)
                         assert _lib.plan(m, n, k, 128 if grouped else -1, max_par, have_scratch=False)["ksplit"] == 1
                         continue

@@ -402,3 +402,37 @@ def test_k_tail_large_m_through_auto_dispatch(dev):
         eD, eacc = C.qqq_gemm(A[rows], B, s1[rows], s2, s3 if grouped else None, return_acc=True)
         assert np.array_equal(acc[rows], eacc), (M, N, K)
         assert ulp_distance(D[rows], eD) == 0
+
+
+def test_split_k_scratch_stays_inside_the_reduce_buffer(dev):
+    """Every split-K family keeps its partial sums inside the caller's `C` (max_par*64 x n int32) and its tickets inside
+    `workspace` (n/128*max_par ints) -- also when the column strips overhang n (n % 256 != 0) and max_par is small.
+    Both buffers are followed by sentinel words that must survive."""
+    from oracle import c_oracle as C
+    from oracle import qqq_ref as R
+
+    rng = np.random.default_rng(31)
+    for (M, N, K) in ((128, 320, 2048), (256, 192, 1536), (100, 1088, 1024)):
+        codes = rng.integers(-8, 8, size=(K, N), dtype=np.int8)
+        B = torch.from_numpy(R.pack_codes(codes, False)).to(dev)
+        A = rng.integers(-128, 128, size=(M, K), dtype=np.int8)
+        s1 = (rng.random((M, 1), dtype=np.float32) * 0.05 + 0.001)
+        s2 = (rng.random((1, N), dtype=np.float32) * 2e-4 + 1e-5)
+        eD = C.qqq_gemm(A, R.pack_codes(codes, False), s1, s2, None)
+        tA, ts1, ts2 = torch.from_numpy(A).to(dev), torch.from_numpy(s1).to(dev), torch.from_numpy(s2).to(dev)
+        s3 = torch.empty(0, dtype=torch.float16, device=dev)
+        for max_par in (1, 2, 3, 16):
+            nC, nW = max_par * 64 * N, max(N // 128, 1) * max_par
+            Cbig = torch.full((nC + 4096,), 0x5A5A5A5A, dtype=torch.int32, device=dev)
+            Wbig = torch.zeros(nW + 256, dtype=torch.int32, device=dev)
+            Wbig[nW:] = 0x5A5A5A5A
+            Cbuf, ws = Cbig[:nC].view(max_par * 64, N), Wbig[:nW]
+            for tune in (None, dict(kernel=4, ksplit=2), dict(kernel=4, ksplit=4, bm=256), dict(kernel=4, ksplit=3, mt=4),
+                         dict(kernel=2, bm=64, ksplit=3), dict(kernel=2, bm=131, ksplit=2), dict(kernel=1, ksplit=2),
+                         dict(kernel=3, mt=2, ksplit=2)):
+                D = torch.full((M, N), float("nan"), dtype=torch.float16, device=dev)
+                ops.qqq_gemm_ex(tA, B, Cbuf, D, ts1, ts2, s3, ws, -1, -1, -1, max_par, tune=tune)
+                torch.cuda.synchronize()
+                assert ulp_distance(D.cpu().numpy(), eD) == 0, (M, N, K, max_par, tune)
+                assert bool((Cbig[nC:] == 0x5A5A5A5A).all()) and bool((Wbig[nW:] == 0x5A5A5A5A).all()), (M, N, K, max_par, tune)
+                assert int(ws.abs().sum().item()) == 0
