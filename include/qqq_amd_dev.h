@@ -45,6 +45,12 @@ int qqq_dev_probe_dequant(const void* q, const void* s0, const void* s1, void* o
  * Writes the duration of one launch in milliseconds to ms_out (host memory). */
 int qqq_dev_probe_fill(const void* src, size_t wg_stride, size_t bytes_per_wg, int nwg, int reps, int unroll, void* sink,
                        int dev, void* stream, float* ms_out);
+/* Sustained matrix-pipe rate probe (tools/mfma_ceiling.py): `nwg` workgroups of 8 waves, each wave `iters` k-steps of
+ * 8 x v_mfma_i32_32x32x32_i8 (the tiled kernel's 4 x 2 fragment grid) on operands from `ops` (>= nwg * 64 KiB of
+ * random bytes or zeros).  mode 0: register operands only; 1: + LDS fragment reads at the tiled kernel's volume;
+ * 2: + the per-channel int4 unpack.  Times ONE launch (after a warm-up launch); ms_out in host memory. */
+int qqq_dev_probe_mfma_rate(int mode, const void* ops, int nwg, int iters, void* sink, int dev, void* stream,
+                            float* ms_out);
 const char* qqq_dev_last_error(void);
 
 #ifdef __cplusplus

@@ -30,6 +30,8 @@ def lib():
     L.qqq_dev_probe_dequant.restype = ci
     L.qqq_dev_probe_fill.argtypes = [vp, ctypes.c_size_t, ctypes.c_size_t, ci, ci, ci, vp, ci, vp, ctypes.POINTER(ctypes.c_float)]
     L.qqq_dev_probe_fill.restype = ci
+    L.qqq_dev_probe_mfma_rate.argtypes = [ci, vp, ci, ci, vp, ci, vp, ctypes.POINTER(ctypes.c_float)]
+    L.qqq_dev_probe_mfma_rate.restype = ci
     L.qqq_dev_bench_gemm.argtypes = [vp, vp, ctypes.POINTER(vp), ci, vp, vp, vp, vp, vp, ci, ci, ci, vp, ci, ci, vp, ci,
                                      ctypes.POINTER(_lib.QQQTune), ci, ctypes.POINTER(ctypes.c_float)]
     L.qqq_dev_bench_gemm.restype = ci

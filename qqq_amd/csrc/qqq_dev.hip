@@ -8,6 +8,8 @@
 #include "qqq_common.hip.h"
 #include "../../include/qqq_amd_dev.h"
 
+typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+
 static thread_local char g_dev_err[256] = "";
 
 static int dev_fail(hipError_t e, const char* what) {
@@ -87,6 +89,70 @@ __global__ __launch_bounds__(256) void qqq_probe_dequant_kernel(const unsigned* 
   out[2 * i + 1] = (unsigned)w1;
 }
 
+// Sustained matrix-pipe rate under the power limit (tools/mfma_ceiling.py): 8 waves per workgroup, each running the
+// tiled kernel's k-step shape -- 8 x v_mfma_i32_32x32x32_i8 on a 4 (weights) x 2 (tokens) fragment grid -- `iters`
+// times on operands taken from `ops` (random bytes or zeros: the cycle count is the same, the clock is not).
+//   MODE 0: operands stay in registers (two sets, alternated)         -> what the matrix pipe alone sustains
+//   MODE 1: + the k-step's LDS fragment reads at the kernel's volume (4 KiB per wave and k-step), used as operands
+//   MODE 2: + the per-channel unpack (shift / and / and per packed word) on the weight words read from LDS
+template <int MODE>
+__global__ __launch_bounds__(512) void qqq_probe_mfma_rate_kernel(const v4i* __restrict__ ops, const int iters,
+                                                                 int* __restrict__ sink) {
+  __shared__ __attribute__((aligned(16))) unsigned char img[16 * 4096];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const v4i* p = ops + ((size_t)blockIdx.x * 512 + tid) * 12;
+  v4i a[2][4], b[2][2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[s][i] = p[s * 6 + i];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) b[s][i] = p[s * 6 + 4 + i];
+  }
+  for (int i = tid; i < 16 * 256; i += 512) reinterpret_cast<v4i*>(img)[i] = ops[(size_t)blockIdx.x * 4096 + i];
+  __syncthreads();
+  v16i acc[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0;
+  for (int it = 0; it < iters; ++it) {
+    const unsigned char* st = img + (it & 15) * 4096;
+    if constexpr (MODE == 0) {  // two k-steps per trip, one per operand set: no selects, no copies in the loop
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0][q & 3], b[0][q >> 2], acc[q], 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[1][q & 3], b[1][q >> 2], acc[q], 0, 0, 0);
+      ++it;
+    } else if constexpr (MODE == 1) {
+      const v4i x0 = *reinterpret_cast<const v4i*>(st + lane * 16), x1 = *reinterpret_cast<const v4i*>(st + 1024 + lane * 16);
+      const v4i w0 = *reinterpret_cast<const v4i*>(st + 2048 + lane * 16), w1 = *reinterpret_cast<const v4i*>(st + 3072 + lane * 16);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int i = q & 3;
+        acc[q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(i == 0 ? w0 : i == 1 ? w1 : a[0][i], (q >> 2) ? x1 : x0, acc[q], 0, 0, 0);
+      }
+    } else {
+      const v4i x0 = *reinterpret_cast<const v4i*>(st + lane * 16), x1 = *reinterpret_cast<const v4i*>(st + 1024 + lane * 16);
+      v4i w[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const v2u pk = *reinterpret_cast<const v2u*>(st + 2048 + i * 512 + lane * 8);
+        w[i] = (v4i){(int)((pk[0] << 4) & 0xF0F0F0F0u), (int)(pk[0] & 0xF0F0F0F0u), (int)((pk[1] << 4) & 0xF0F0F0F0u),
+                     (int)(pk[1] & 0xF0F0F0F0u)};
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w[q & 3], (q >> 2) ? x1 : x0, acc[q], 0, 0, 0);
+    }
+  }
+  int f = 0;
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) f ^= acc[q][r];
+  if (f == 0x13579bdf) sink[0] = f;  // keeps the chains alive
+}
+
 extern "C" int qqq_dev_probe_mfma(int kind, const void* a, const void* b, void* out, int dev, void* stream) {
   DevGuard guard(dev);
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -147,6 +213,31 @@ extern "C" int qqq_dev_probe_fill(const void* src, size_t wg_stride, size_t byte
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   if (e != hipSuccess) return dev_fail(e, "qqq_dev_probe_fill");
+  return QQQ_OK;
+}
+
+extern "C" int qqq_dev_probe_mfma_rate(int mode, const void* ops, int nwg, int iters, void* sink, int dev, void* stream,
+                                       float* ms_out) {
+  DevGuard guard(dev);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return dev_fail(hipGetLastError(), "event");
+  auto launch = [&]() {
+    const v4i* o = static_cast<const v4i*>(ops);
+    int* sk = static_cast<int*>(sink);
+    if (mode == 0) hipLaunchKernelGGL(qqq_probe_mfma_rate_kernel<0>, dim3(nwg), dim3(512), 0, st, o, iters, sk);
+    else if (mode == 1) hipLaunchKernelGGL(qqq_probe_mfma_rate_kernel<1>, dim3(nwg), dim3(512), 0, st, o, iters, sk);
+    else hipLaunchKernelGGL(qqq_probe_mfma_rate_kernel<2>, dim3(nwg), dim3(512), 0, st, o, iters, sk);
+  };
+  launch();  // warm-up (and clock settling)
+  (void)hipEventRecord(e0, st);
+  launch();
+  (void)hipEventRecord(e1, st);
+  hipError_t e = hipStreamSynchronize(st);
+  if (e == hipSuccess) e = hipEventElapsedTime(ms_out, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (e != hipSuccess) return dev_fail(e, "qqq_dev_probe_mfma_rate");
   return QQQ_OK;
 }
 
