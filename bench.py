@@ -230,6 +230,29 @@ def cpu_baseline(sample_rows=64, budget_s=12.0):
     return out
 
 
+def sustained_matrix_rate(dev, reps=3, iters=20000, nwg=256):
+    """What the matrix pipe sustains on THIS part under its power limit, on random int8 operands, in the tiled kernel's
+    k-step shape (dev library probe, tools/mfma_ceiling.py): rung 0 = MFMAs on register operands only, rung 2 = + the
+    k-step's LDS fragment reads + the int4 unpack.  Context for `roofline.frac` (profiles/r02_mfma_power_ceiling.txt)."""
+    from qqq_amd import _dev
+
+    L = _dev.lib()
+    g = torch.Generator(device=dev).manual_seed(3)
+    buf = torch.randint(-128, 128, (nwg * (65536 + 512 * 12 * 16),), generator=g, dtype=torch.int8, device=dev)
+    sink = torch.zeros(4, dtype=torch.int32, device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    out = {}
+    for mode, key in ((0, "mfma_only_tops"), (2, "mfma_lds_unpack_tops")):
+        v = []
+        for _ in range(reps):
+            ms = ctypes.c_float()
+            if L.qqq_dev_probe_mfma_rate(mode, buf.data_ptr(), nwg, iters, sink.data_ptr(), dev.index or 0, st, ctypes.byref(ms)) != 0:
+                return {"error": _dev.last_error()}
+            v.append(ms.value)
+        out[key] = nwg * 8 * iters * 8 * 65536.0 / float(np.median(v)) / 1e9
+    return out
+
+
 def committed_traffic(key):
     """bytes per launch from the committed rocprofv3 PMC passes (profiles/hbm_traffic.json, tools/pmc_traffic.sh)"""
     try:
@@ -497,6 +520,7 @@ def main():
         result["per_m"] = per_m
         live, traffic_note = ({}, "skipped (--no-pmc)") if args.no_pmc else live_traffic()
         a = per_m["4096"]
+        sus = sustained_matrix_rate(dev)
         result["roofline"] = {
             "kernel": "qqq_tiled_kernel (M=4096)", "bound": "mfma", "achieved": a["tops"], "peak": PEAK_MFMA_TOPS,
             "unit": "TOPS", "frac": a["tops"] / PEAK_MFMA_TOPS,
@@ -505,8 +529,13 @@ def main():
             "traffic_source": traffic_note if "tiled_m4096" in live else f"profiles/hbm_traffic.json (committed PMC pass; live pass: {traffic_note})",
             "algorithmic_bytes": algorithmic_bytes(4096, N_FULL, K_FULL), "avg_launch_us": a["us"],
             "frac_of_ubench_ceiling": a["tops"] / 4404.0,
+            "sustained_on_random_int8": sus,
+            "frac_of_sustained_mfma_only": (a["tops"] / sus["mfma_only_tops"]) if "mfma_only_tops" in sus else None,
+            "frac_of_sustained_kstep_shape": (a["tops"] / sus["mfma_lds_unpack_tops"]) if "mfma_lds_unpack_tops" in sus else None,
             "note": "peak = 256 CU x 2.4 GHz x 8192 int8 op/clk; 4404 TOPS is the v_mfma_i32_32x32x32_i8 micro-benchmark ceiling; "
-                    "under this kernel the chip clocks ~1.9 GHz (power), profiles/r02_pmc_tiled_m4096.txt",
+                    "under this kernel the chip clocks ~1.9 GHz (power), profiles/r02_pmc_tiled_m4096.txt; "
+                    "sustained_on_random_int8 = this part's matrix pipe measured in this run on random operands, MFMAs only and "
+                    "with the k-step's LDS reads + int4 unpack (profiles/r02_mfma_power_ceiling.txt)",
         }
         h = per_m["1"]
         result["roofline_hbm"] = {

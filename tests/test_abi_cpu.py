@@ -43,7 +43,7 @@ def test_dev_library_exports_every_declared_symbol():
     D = _dev.lib()
     names = _declared("qqq_amd_dev.h")
     assert {"qqq_dev_bench_gemm", "qqq_dev_probe_mfma", "qqq_dev_probe_glds", "qqq_dev_probe_dequant",
-            "qqq_dev_probe_fill", "qqq_dev_last_error"} == names
+            "qqq_dev_probe_fill", "qqq_dev_probe_mfma_rate", "qqq_dev_last_error"} == names
     for n in names:
         assert hasattr(D, n), n
 
