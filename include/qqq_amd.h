@@ -72,7 +72,8 @@ typedef struct qqq_tune {
                   (2..12); 0 auto                                                                  */
   int stages;  /* tiled + LDS-DMA: ring depth 2..4 (0 auto)                                      */
   int mt;      /* stream: 16-token tiles per workgroup (1..4); column: 1..2; panel: 1, 2, 4, 8; 0 auto  */
-  int pw;      /* tiled: weight strips per XCD panel of the tile order (4, 8, 16, 32); 0 auto          */
+  int pw;      /* tiled: weight strips per XCD panel of the tile order (4, 8, 16, 32); panel (bm = 256, mt = 8):
+                  32-column sets per wave (1, or 2 = 4 waves x 64 columns x 2 k-groups); 0 auto            */
   int nslots;  /* out (qqq_w4a8_plan only): tile-sized slots of C used by the tiled in-launch split-K  */
   int reserved[1];
 } qqq_tune_t;

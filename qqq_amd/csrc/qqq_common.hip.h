@@ -99,6 +99,32 @@ __device__ __forceinline__ void glds16(const void* gsrc, const unsigned lds_dst)
       : "memory");
 }
 
+// 4x4 transpose over (register e, lane q of a quad): y[e](lane q) = w[q](lane e) -- what turns the 16-byte pieces a
+// lane loads from the packed layout (4 words jt = 0..3 of one (k-tile, chunk, kq)) into the MFMA lane's 4 words
+// kq = 0..3 of its jt.  Two butterfly stages, each ONE VOP2 v_cndmask_b32 per register with a DPP quad_perm on the
+// not-taken operand (8 VALU; written as plain C++ -- __builtin_amdgcn_mov_dpp + select -- hipcc emits v_mov_dpp +
+// VOP3 v_cndmask, 16 VALU, because its lane-parity conditions live in SGPR pairs, not VCC).  The lane masks are
+// constants: even lanes 0x5555.., lanes with bit 1 clear 0x3333...  The two s_mov in front of the first DPP read also
+// cover the 2 wait states a DPP source needs behind a VALU write; the second stage reads z's written >= 2 slots earlier.
+__device__ __forceinline__ void quad_transpose4(const v4u w, unsigned (&y)[4]) {
+  unsigned z0, z1, z2, z3;
+  asm("s_mov_b32 vcc_lo, 0x55555555\n\ts_mov_b32 vcc_hi, 0x55555555\n\t"
+      "v_cndmask_b32_dpp %4, %9, %8, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"    // z0 = even ? w0 : w1'
+      "v_cndmask_b32_dpp %6, %11, %10, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"  // z2 = even ? w2 : w3'
+      "s_mov_b32 vcc_lo, 0xaaaaaaaa\n\ts_mov_b32 vcc_hi, 0xaaaaaaaa\n\t"
+      "v_cndmask_b32_dpp %5, %8, %9, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"    // z1 = odd ? w1 : w0'
+      "v_cndmask_b32_dpp %7, %10, %11, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"  // z3 = odd ? w3 : w2'
+      "s_mov_b32 vcc_lo, 0x33333333\n\ts_mov_b32 vcc_hi, 0x33333333\n\t"
+      "v_cndmask_b32_dpp %0, %6, %4, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"    // y0 = lo ? z0 : z2''
+      "v_cndmask_b32_dpp %1, %7, %5, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"    // y1 = lo ? z1 : z3''
+      "s_mov_b32 vcc_lo, 0xcccccccc\n\ts_mov_b32 vcc_hi, 0xcccccccc\n\t"
+      "v_cndmask_b32_dpp %2, %4, %6, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"    // y2 = hi ? z2 : z0''
+      "v_cndmask_b32_dpp %3, %5, %7, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"          // y3 = hi ? z3 : z1''
+      : "=&v"(y[0]), "=&v"(y[1]), "=&v"(y[2]), "=&v"(y[3]), "=&v"(z0), "=&v"(z1), "=&v"(z2), "=&v"(z3)
+      : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3])
+      : "vcc");
+}
+
 template <bool GROUPED>
 __device__ __forceinline__ void unpack_pair(const unsigned q, const h2 s_b0, const h2 s_b1,
                                             int& w_b0, int& w_b1) {

@@ -26,10 +26,14 @@
 //  * split-K in-launch: arrival-order tickets as in the tiled kernel, but every depositor owns a slot (slot index =
 //    arrival index), so nobody waits except the last arrival, which has by construction only already-arrived
 //    workgroups to wait for.  Deposits are lane-linear full-line write-through stores.
-// grid = (ceil(N / BN), ksplit, ceil(M / (16*MT)));  block = 64 * WN * KG.
+//  * HW = 2: a wave owns BOTH halves of its 64-column group (two weight loads, 4*MT MFMAs per 64-k step): every
+//    activation fragment read from LDS then feeds 4 MFMAs instead of 2.  With HW = 1 a 128-token workgroup reads
+//    8 waves x 16 KB of fragments per stage = 1024 LDS clocks against 1024 matrix-pipe clocks per SIMD -- the LDS
+//    read port is a co-limit; HW = 2 halves it.
+// grid = (ceil(N / BN), ksplit, ceil(M / (16*MT)));  block = 64 * WN * KG;  BN = 32 * WN * HW.
 // ------------------------------------------------------------------------------------------
 
-template <int MT, bool GROUPED, int WN, int KG, int PFS, int XL>
+template <int MT, bool GROUPED, int WN, int KG, int PFS, int XL, int HW>
 __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
     const int8_t* __restrict__ A, const unsigned char* __restrict__ B, int32_t* __restrict__ C,
     _Float16* __restrict__ D, const float* __restrict__ s1, const float* __restrict__ s2,
@@ -37,7 +41,8 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
     const _Float16* __restrict__ bias, const int M, const int N, const int K, const int ksplit) {
   constexpr int NW = WN * KG;            // waves
   constexpr int NT = NW * 64;            // threads
-  constexpr int BN = 32 * WN;            // columns per workgroup
+  constexpr int BN = 32 * WN * HW;       // columns per workgroup
+  static_assert(HW == 1 || HW == 2, "32-column sets per wave");
   constexpr int ROWS = 16 * MT;          // tokens per workgroup
   constexpr int XB = ROWS * 128;         // bytes of one activation stage
   constexpr int XCH = XB / 16;           // ... in 16-byte chunks
@@ -58,9 +63,10 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
   const int strip = blockIdx.x, sp = blockIdx.y, mblk = blockIdx.z;
   const int mbase = mblk * ROWS;
   const int ngroups = N >> 6;
-  int ng = strip * (WN / 2) + (wn >> 1);
+  const int gl = (wn * HW) >> 1;  // 64-column group of this wave inside the strip
+  int ng = strip * (BN / 64) + gl;
   if (ng >= ngroups) ng = ngroups - 1;  // N % BN != 0: surplus waves of the last strip compute on clamped columns, store nothing
-  const int half = wn & 1;
+  const int half = (HW == 2) ? 0 : (wn & 1);  // first (HW == 2: both) half of the group
   const size_t rowbytes = (size_t)N * 8;
 
   // ---- K slice in 128-k stages (a trailing 64-k half stage when K % 128 == 64) ----
@@ -109,63 +115,63 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
     for (int q = 0; q < XPT; ++q)
       if (q + 1 < XPT || xact) *reinterpret_cast<v4u*>(smem + buf * XB + xdst[q]) = r[q];
   };
-  auto load_w = [&](const int st_rel, const int t, v4u& dst) {
+  auto load_w = [&](const int st_rel, const int t, v4u (&dst)[HW]) {
     const int st = st_begin + (st_rel < nst ? st_rel : nst - 1);
     int s = 2 * st + (KG == 2 ? kg : t);
     if (s >= KS) s = KS - 1;
-    dst = *reinterpret_cast<const v4u*>(wptr + (size_t)(4 * s) * rowbytes);
-  };
-  auto load_sc = [&](const int st_rel, h2& dst) {
-    const int st = st_begin + (st_rel < nst ? st_rel : nst - 1);
-    dst = *reinterpret_cast<const h2*>(sptr + (size_t)st * N);
-  };
-
-  v4i acc[MT][2];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) acc[mt][0] = acc[mt][1] = (v4i){0, 0, 0, 0};
+    for (int hf = 0; hf < HW; ++hf) dst[hf] = *reinterpret_cast<const v4u*>(wptr + (size_t)(4 * s) * rowbytes + 256 * hf);
+  };
+  auto load_sc = [&](const int st_rel, h2 (&dst)[HW]) {
+    const int st = st_begin + (st_rel < nst ? st_rel : nst - 1);
+#pragma unroll
+    for (int hf = 0; hf < HW; ++hf) dst[hf] = *reinterpret_cast<const h2*>(sptr + (size_t)st * N + 32 * hf);
+  };
 
-  v4u wr[PFS * SPW];
+  v4i acc[MT][2 * HW];  // [mt][2*hf + b]
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int q = 0; q < 2 * HW; ++q) acc[mt][q] = (v4i){0, 0, 0, 0};
+
+  v4u wr[PFS * SPW][HW];
   v4u xr[XL][XPT];
-  h2 scr[GROUPED ? PFS : 1];
-  const bool odd = lane & 1, hi = lane & 2;
+  h2 scr[GROUPED ? PFS : 1][HW];
   const unsigned xrd = (unsigned)((lane & 15) * 128);  // + mt*2048; chunk = (4*t + h) ^ ((row >> 1) & 7), row = 16*mt + j
   const int xsw = ((lane & 15) >> 1) & 7;              // (row >> 1) & 7 for row = 16*mt + j
 
   // MFMA operands of one 64-k step of this wave: weights (two column halves b) and the tokens' activations
   struct Operands {
-    v4i a0, a1;
-    v4i x[MT];
+    v4i a[2 * HW];  // [2*hf + b]
   };
-  auto read_x = [&](const int stage_abs_rel, const int tk, Operands& o) {  // LDS buffer of a stage = stage % NBUF
+  v4i x[MT];  // activation fragments of the current step; x[mt] is re-read for the next step right behind its last MFMA
+  auto read_x = [&](const int stage_abs_rel, const int tk, const int mt) {  // LDS buffer of a stage = stage % NBUF
     const unsigned char* st = smem + (stage_abs_rel % NBUF) * XB;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-      o.x[mt] = *reinterpret_cast<const v4i*>(st + xrd + mt * 2048 + (((4 * tk + h) ^ xsw) << 4));
+    x[mt] = *reinterpret_cast<const v4i*>(st + xrd + mt * 2048 + (((4 * tk + h) ^ xsw) << 4));
   };
-  auto unpack_w = [&](const v4u& w, const h2 sc, const bool valid, Operands& o) {
-    // 4x4 transpose over (register e, quad lane q): out[e](lane q) = in[q](lane e)   (as in the column kernel)
-    unsigned z[4], y[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const unsigned t = (unsigned)__builtin_amdgcn_mov_dpp((int)w[e ^ 1], 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
-      z[e] = (odd == (bool)(e & 1)) ? w[e] : t;
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const unsigned t = (unsigned)__builtin_amdgcn_mov_dpp((int)z[e ^ 2], 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
-      y[e] = (hi == (bool)(e & 2)) ? z[e] : t;
-    }
-    h2 sb0 = {(_Float16)0, (_Float16)0}, sb1 = sb0;
+  auto unpack_w = [&](const v4u& w, const h2 sc, const bool valid, const int hf, Operands& o) {
+    unsigned y[4];
+    quad_transpose4(w, y);  // y[kq] = word kq of this lane's jt
+    // a step past the end of K (trailing half stage) contributes nothing: `valid` is wave-uniform, so it costs a scalar
+    // select on the nibble mask (per-channel) or on the group scale (scale 0 re-quantises every nibble to 0)
     if constexpr (GROUPED) {
-      sb0 = (h2){sc[0], sc[0]};
-      sb1 = (h2){sc[1], sc[1]};
-    }
+      const h2 zero = {(_Float16)0, (_Float16)0};
+      const h2 sv = valid ? sc : zero;
+      const h2 sb0 = {sv[0], sv[0]}, sb1 = {sv[1], sv[1]};
 #pragma unroll
-    for (int kq = 0; kq < 4; ++kq) {
-      int w0, w1;
-      unpack_pair<GROUPED>(y[kq], sb0, sb1, w0, w1);
-      o.a0[kq] = valid ? w0 : 0;  // a step past the end of K (trailing half stage) contributes nothing
-      o.a1[kq] = valid ? w1 : 0;
+      for (int kq = 0; kq < 4; ++kq) {
+        int w0, w1;
+        unpack_pair<true>(y[kq], sb0, sb1, w0, w1);
+        o.a[2 * hf][kq] = w0;
+        o.a[2 * hf + 1][kq] = w1;
+      }
+    } else {
+      const unsigned nm = valid ? QQQ_NIB_MASK : 0u;
+#pragma unroll
+      for (int kq = 0; kq < 4; ++kq) {
+        o.a[2 * hf][kq] = (int)(y[kq] & nm);             // odd nibbles  -> 16*w4 of column n      (b = 0)
+        o.a[2 * hf + 1][kq] = (int)((y[kq] << 4) & nm);  // even nibbles -> 16*w4 of column n + 8  (b = 1)
+      }
     }
   };
 
@@ -175,36 +181,82 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
   // LDS buffers: stage j lives in buffer j % NBUF; stage i+2 is written at the top of stage i (its buffer was last
   // read during stage i-1, or i-2 with two buffers: KG == 2 reads every buffer in one stage only), and becomes visible
   // with the barrier that ends stage i -- one stage before the first (prefetch) read.
+  // HW == 2 (64 columns per wave, KG == 2) runs the weight operands half a step ahead instead of a whole one, in place
+  // (128 accumulators leave no room for two operand sets): while the MFMAs of column half 0 issue, the wave unpacks THIS
+  // step's half 1; while those of half 1 issue, the NEXT step's half 0 -- and refills the ring slot just emptied.
   Operands cur, nxt;
   auto stage = [&](const int i, const int u) {  // u = i % PFS as a compile-time value at every call site
     store_x((i + 2) % NBUF, xr[(u + 2) % XL]);
     load_x(i + 2 + XL, xr[(u + 2) % XL]);
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (HW == 2) {
+      static_assert(HW == 1 || SPW == 1, "64 columns per wave: two k-groups");
+      const int un = (u + 1) % PFS;
+      constexpr int NV = GROUPED ? 68 : 14;  // compiler-visible VALU of one 32-column unpack (the transpose is an asm block)
+      constexpr int VPM = (NV + 2 * MT - 1) / (2 * MT);
+      // ---- column half 0 of step i ----
+      unpack_w(wr[u][1], scr[GROUPED ? u : 0][1], 2 * (st_begin + i) + kg < KS, 1, cur);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        acc[mt][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(cur.a[0], x[mt], acc[mt][0], 0, 0, 0);
+        acc[mt][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(cur.a[1], x[mt], acc[mt][1], 0, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < 2 * MT; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);  // VALU
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- column half 1 of step i ----
+      unpack_w(wr[un][0], scr[GROUPED ? un : 0][0], 2 * (st_begin + i + 1) + kg < KS, 0, cur);
+      load_w(i + PFS, 0, wr[u]);
+      if constexpr (GROUPED) load_sc(i + PFS, scr[u]);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        acc[mt][2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(cur.a[2], x[mt], acc[mt][2], 0, 0, 0);
+        acc[mt][3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(cur.a[3], x[mt], acc[mt][3], 0, 0, 0);
+        read_x(i + 1, kg, mt);  // the next step's fragment, in place
+      }
+#pragma unroll
+      for (int q = 0; q < 2 * MT; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                     // 1 MFMA
+        if (q % 2 == 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // 1 LDS read (behind its fragment's last use)
+        __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);                   // VALU
+        if (q == 2 * MT - 1) __builtin_amdgcn_sched_group_barrier(0x020, GROUPED ? 4 : 2, 0);  // VMEM reads (ring refills)
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();  // stage i+2 is in LDS for everybody
+      return;
+    }
 #pragma unroll
     for (int t = 0; t < SPW; ++t) {
       // the step after (i, t): (i, t+1) or (i+1, 0)
       const bool same = (t + 1 < SPW);
       const int ni = same ? i : i + 1, nu = same ? u : (u + 1) % PFS, nt = same ? t + 1 : 0;
       const int ntk = (KG == 2) ? kg : nt;
-      read_x(ni, ntk, nxt);
-      unpack_w(wr[nu * SPW + nt], scr[GROUPED ? nu : 0], 2 * (st_begin + ni) + ntk < KS, nxt);
+#pragma unroll
+      for (int hf = 0; hf < HW; ++hf)
+        unpack_w(wr[nu * SPW + nt][hf], scr[GROUPED ? nu : 0][hf], 2 * (st_begin + ni) + ntk < KS, hf, nxt);
       load_w(ni + PFS, nt, wr[nu * SPW + nt]);
       if constexpr (GROUPED)
         if (nt == SPW - 1) load_sc(ni + PFS, scr[nu]);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        acc[mt][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(cur.a0, cur.x[mt], acc[mt][0], 0, 0, 0);
-        acc[mt][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(cur.a1, cur.x[mt], acc[mt][1], 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 2 * HW; ++q)
+          acc[mt][q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(cur.a[q], x[mt], acc[mt][q], 0, 0, 0);
+        read_x(ni, ntk, mt);  // the next step's fragment, in place
       }
       // issue order inside this region: 1 MFMA, then its share of the VALU / LDS-read / VMEM work
-      constexpr int NVALU = GROUPED ? 88 : 40;  // DPP moves + selects + unpack of one step (upper estimate)
-      constexpr int VPM = (NVALU + 2 * MT - 1) / (2 * MT);
+      constexpr int NVALU = (GROUPED ? 68 : 14) * HW;  // compiler-visible VALU of one step's unpack (the transpose is an asm block)
+      constexpr int NMF = 2 * HW * MT;
+      constexpr int VPM = (NVALU + NMF - 1) / NMF;
 #pragma unroll
-      for (int q = 0; q < 2 * MT; ++q) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                // 1 MFMA
-        if (q % 2 == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 LDS read
-        __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);              // VALU
-        if (q == 2 * MT - 1) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);  // VMEM reads (ring refills)
+      for (int q = 0; q < NMF; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                           // 1 MFMA
+        if (q % (2 * HW) == 2 * HW - 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 LDS read (behind its fragment's last use)
+        __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);                         // VALU
+        if (q == NMF - 1) __builtin_amdgcn_sched_group_barrier(0x020, 2 * HW, 0);    // VMEM reads (ring refills)
       }
       __builtin_amdgcn_sched_barrier(0);
       cur = nxt;
@@ -230,13 +282,22 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
     __syncthreads();
     {  // operands of the first step; its ring slot is refilled like any other
       const int tk0 = (KG == 2) ? kg : 0;
-      read_x(0, tk0, cur);
-      unpack_w(wr[0], scr[0], 2 * st_begin + tk0 < KS, cur);
-      load_w(PFS, 0, wr[0]);
-      if constexpr (GROUPED)
-        if (SPW == 1) load_sc(PFS, scr[0]);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) read_x(0, tk0, mt);
+      if constexpr (HW == 2) {
+        unpack_w(wr[0][0], scr[0][0], 2 * st_begin + tk0 < KS, 0, cur);  // half 1 and the refill: inside stage 0
+      } else {
+        unpack_w(wr[0][0], scr[0][0], 2 * st_begin + tk0 < KS, 0, cur);
+        load_w(PFS, 0, wr[0]);
+        if constexpr (GROUPED)
+          if (SPW == 1) load_sc(PFS, scr[0]);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
+    // Two LDS buffers: stage 0 re-fills buffer 0 (with stage 2) at its very top, and the fragment reads just above are
+    // the only reads of a buffer that no stage-end barrier separates from its next write -- a wave delayed behind the
+    // barrier (two workgroups sharing a CU) would otherwise read stage 2 rows for its first step.
+    if constexpr (NBUF == 2) __syncthreads();
     // ---- steady state: PFS stages per iteration (ring slots are compile-time registers), branch-free ----
     int i0 = 0;
     for (; i0 + PFS <= nst; i0 += PFS) {
@@ -250,26 +311,69 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
   }
   __syncthreads();
 
-  // ---- k-groups meet in LDS (KG == 2): group 1 deposits lane-linear, group 0 adds ----
-  if constexpr (KG == 2) {
-    v4i* red = reinterpret_cast<v4i*>(smem);
-    if (kg == 1) {
+  // ---- k-groups meet in LDS (KG == 2).  With MT >= 2 the tile is then FINISHED BY BOTH groups: group kg keeps the
+  // m-tiles [kg*MT/2, +MT/2) -- it deposits the other half in LDS, adds the partner's deposit to its own half -- so
+  // the split-K hand-off and the epilogue below are spread over all waves (and 64, not 128, live accumulators per
+  // wave with HW == 2).  MT == 1: group 1 deposits, group 0 finishes alone.
+  constexpr bool SPLIT = (KG == 2) && (MT >= 2);
+  constexpr int MTO = SPLIT ? MT / 2 : MT;  // m-tiles this wave finishes
+  constexpr int NQ = 2 * HW;
+  v4i fin[MTO][NQ];
+  const int mb = SPLIT ? kg * MTO : 0;      // first of them
+  const bool finisher = SPLIT || kg == 0;
+  if constexpr (SPLIT) {
+    v4i* red = reinterpret_cast<v4i*>(smem);  // [kg][wn][MTO][NQ][64 lanes]
+    v4i* mine = red + (size_t)((kg * WN + wn) * MTO) * NQ * 64;
+    const v4i* theirs = red + (size_t)(((kg ^ 1) * WN + wn) * MTO) * NQ * 64;
+    if (kg == 0) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+      for (int j = 0; j < MTO; ++j)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) red[((wn * MT + mt) * 2 + b) * 64 + lane] = acc[mt][b];
+        for (int q = 0; q < NQ; ++q) mine[(j * NQ + q) * 64 + lane] = acc[MTO + j][q];
+    } else {
+#pragma unroll
+      for (int j = 0; j < MTO; ++j)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) mine[(j * NQ + q) * 64 + lane] = acc[j][q];
     }
     __syncthreads();
     if (kg == 0) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+      for (int j = 0; j < MTO; ++j)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) acc[mt][b] += red[((wn * MT + mt) * 2 + b) * 64 + lane];
+        for (int q = 0; q < NQ; ++q) fin[j][q] = acc[j][q] + theirs[(j * NQ + q) * 64 + lane];
+    } else {
+#pragma unroll
+      for (int j = 0; j < MTO; ++j)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) fin[j][q] = acc[MTO + j][q] + theirs[(j * NQ + q) * 64 + lane];
     }
     __syncthreads();
+  } else {
+    if constexpr (KG == 2) {
+      v4i* red = reinterpret_cast<v4i*>(smem);
+      if (kg == 1) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) red[((wn * MT + mt) * NQ + q) * 64 + lane] = acc[mt][q];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) fin[mt][q] = acc[mt][q] + ((kg == 0) ? red[((wn * MT + mt) * NQ + q) * 64 + lane] : (v4i){0, 0, 0, 0});
+      __syncthreads();
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) fin[mt][q] = acc[mt][q];
+    }
   }
 
   // ---- in-launch split-K: slot = arrival index; the last arrival folds every slot and runs the epilogue ----
+  // slot image: wave wn's m-tile mt, operand q at ((wn*MT + mt)*NQ + q) KiB, lane-linear inside
   const int tile = mblk * gridDim.x + strip;
   if (ksplit > 1) {
     int* tk = tickets + 2 * (size_t)tile;  // [0] arrivals, [1] completed deposits; both zero again on exit
@@ -278,17 +382,20 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
     const int t = xch;
     const size_t slot_ints = (size_t)ROWS * BN;
     const size_t tile_ints = slot_ints * (size_t)(ksplit - 1);
+    const size_t wave_ints = ((size_t)wn * MT + mb) * NQ * 256;
     if (t < ksplit - 1) {
-      if (kg == 0) {
-        const unsigned char* sb = reinterpret_cast<const unsigned char*>(C + (size_t)tile * tile_ints + (size_t)t * slot_ints +
-                                                                         (size_t)wn * (MT * 2 * 256));
+      if (finisher) {
+        const unsigned char* sb = reinterpret_cast<const unsigned char*>(C + (size_t)tile * tile_ints + (size_t)t * slot_ints + wave_ints);
         const unsigned voff = lane * 16;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int j = 0; j < MTO; ++j)
 #pragma unroll
-          for (int b = 0; b < 2; ++b) {
-            const unsigned char* p = sb + (mt * 2 + b) * 1024;
-            asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1" ::"v"(voff), "v"(acc[mt][b]), "s"(p) : "memory");
+          for (int q = 0; q < NQ; ++q) {
+            const unsigned char* p = sb + (j * NQ + q) * 1024;
+            // (s_nop 1 inside the string: hipcc does not know this is a 16-byte store whose data registers are read late, and
+            //  would let its next VALU instruction overwrite them -- garbage in the slot under load; s_nop 4 in front: the
+            //  scalar base may come straight from a v_readfirstlane, 5 wait states ahead of a VMEM read)
+            asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc0 sc1\n\ts_nop 1" ::"v"(voff), "v"(fin[j][q]), "s"(p) : "memory");
           }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
@@ -301,14 +408,13 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
         __builtin_amdgcn_s_sleep(2);
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    if (kg == 0) {
+    if (finisher) {
       for (int s_ = 0; s_ < ksplit - 1; ++s_) {
-        const v4i* p = reinterpret_cast<const v4i*>(C + (size_t)tile * tile_ints + (size_t)s_ * slot_ints +
-                                                    (size_t)wn * (MT * 2 * 256));
+        const v4i* p = reinterpret_cast<const v4i*>(C + (size_t)tile * tile_ints + (size_t)s_ * slot_ints + wave_ints);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int j = 0; j < MTO; ++j)
 #pragma unroll
-          for (int b = 0; b < 2; ++b) acc[mt][b] += p[(mt * 2 + b) * 64 + lane];
+          for (int q = 0; q < NQ; ++q) fin[j][q] += p[(j * NQ + q) * 64 + lane];
       }
     }
     if (tid < 2) __hip_atomic_store(tk + tid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // workspace zero on return
@@ -316,17 +422,17 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
 
   // ---- epilogue: int32 tile -> LDS (row-major, skewed rows) -> 8 consecutive n per thread -> 16-byte stores ----
   // D lane ln of the MFMA holds token j = ln & 15, rows 4*(ln >> 4) + r -> c' = ln >> 4, jt = r:
-  //   column inside the strip  nl = 64*(wn >> 1) + 16*jt + 8*b + 4*half + c'
+  //   column inside the strip  nl = 64*gl + 16*jt + 8*b + 4*(half + hf) + c'
   int* ep = reinterpret_cast<int*>(smem);
-  if (kg == 0) {
+  if (finisher) {
     const int j = lane & 15, cp = lane >> 4;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int jm = 0; jm < MTO; ++jm)
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
+      for (int q = 0; q < NQ; ++q)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          ep[(16 * mt + j) * EP_STRIDE + 64 * (wn >> 1) + 16 * r + 8 * b + 4 * half + cp] = acc[mt][b][r];
+          ep[(16 * (mb + jm) + j) * EP_STRIDE + 64 * gl + 16 * r + 8 * (q & 1) + 4 * (half + (q >> 1)) + cp] = fin[jm][q][r];
   }
   __syncthreads();
   for (int it = tid; it < ROWS * (BN / 8); it += NT) {

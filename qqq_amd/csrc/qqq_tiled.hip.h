@@ -625,7 +625,9 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * (2 / NB) * 64) void 
               const v4i v = {acc[mt][jj][bi][4 * gq + 0], acc[mt][jj][bi][4 * gq + 1], acc[mt][jj][bi][4 * gq + 2],
                              acc[mt][jj][bi][4 * gq + 3]};
               const unsigned char* sb = sbase + (((mt * JW + jj) * NB + bi) * 4 + gq) * 1024;
-              asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1" ::"v"(voff), "v"(v), "s"(sb) : "memory");
+              // s_nop 1 behind: a 16-byte store reads its data registers late and hipcc would let its next VALU overwrite them;
+              // s_nop 4 in front: the scalar base may come straight from a v_readfirstlane (5 wait states before a VMEM read)
+              asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc0 sc1\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sb) : "memory");
             }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();  // every wave's part of the deposit has reached memory

@@ -198,16 +198,16 @@ static hipError_t launch_column(const LaunchArgs& a, bool grouped, int mt, int p
   return grouped ? launch_column_g<true>(a, mt, pf, ksplit) : launch_column_g<false>(a, mt, pf, ksplit);
 }
 
-template <int MT, bool GROUPED, int WN, int KG, int PFS, int XL>
+template <int MT, bool GROUPED, int WN, int KG, int PFS, int XL, int HW = 1>
 static hipError_t launch_panel_t(const LaunchArgs& a, int ksplit) {
-  constexpr int ROWS = 16 * MT, BN = 32 * WN;
+  constexpr int ROWS = 16 * MT, BN = 32 * WN * HW;
   constexpr int XBUF = (KG == 2 ? 2 : 3) * ROWS * 128;
   constexpr int EP = ROWS * (BN + 4) * 4;
-  constexpr int RED = (KG == 2) ? WN * MT * 2048 : 0;
+  constexpr int RED = (KG == 2) ? WN * MT * HW * 2048 : 0;
   constexpr int LDS = XBUF > EP ? (XBUF > RED ? XBUF : RED) : (EP > RED ? EP : RED);
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static bool attr_set[64] = {};  // per instantiation, per device
-  auto kern = qqq_panel_kernel<MT, GROUPED, WN, KG, PFS, XL>;
+  auto kern = qqq_panel_kernel<MT, GROUPED, WN, KG, PFS, XL, HW>;
   int cur = 0;
   (void)hipGetDevice(&cur);
   if (cur < 0 || cur >= 64 || !attr_set[cur]) {
@@ -222,37 +222,40 @@ static hipError_t launch_panel_t(const LaunchArgs& a, int ksplit) {
 }
 
 template <int MT, bool GROUPED, int PFS, int XL>
-static hipError_t launch_panel_shape(const LaunchArgs& a, int bn, int waves, int ksplit) {
+static hipError_t launch_panel_shape(const LaunchArgs& a, int bn, int waves, int cw, int ksplit) {
+  if constexpr (MT == 8 && PFS >= 3 && PFS == XL) {  // 64 columns per wave (two k-groups of 4 waves)
+    if (bn == 256 && cw == 2) return launch_panel_t<MT, GROUPED, 4, 2, PFS, XL, 2>(a, ksplit);
+  }
   if (bn == 256) return launch_panel_t<MT, GROUPED, 8, 1, PFS, XL>(a, ksplit);
   if (waves == 4) return launch_panel_t<MT, GROUPED, 4, 1, PFS, XL>(a, ksplit);
   return launch_panel_t<MT, GROUPED, 4, 2, PFS, XL>(a, ksplit);
 }
 
 template <int MT, bool GROUPED>
-static hipError_t launch_panel_pf(const LaunchArgs& a, int bn, int waves, int pfs, int xl, int ksplit) {
+static hipError_t launch_panel_pf(const LaunchArgs& a, int bn, int waves, int cw, int pfs, int xl, int ksplit) {
   // XL (activation lead) = PFS (weight lead) unless asked otherwise: loads return in order, so a shorter activation
   // lead would force the weight loads issued before it to land early and cut their effective lead to XL + 1
-  if (pfs <= 2) return launch_panel_shape<MT, GROUPED, 2, 2>(a, bn, waves, ksplit);
+  if (pfs <= 2) return launch_panel_shape<MT, GROUPED, 2, 2>(a, bn, waves, cw, ksplit);
   if constexpr (MT <= 4) {
-    if (pfs >= 8) return launch_panel_shape<MT, GROUPED, 8, 8>(a, bn, waves, ksplit);
+    if (pfs >= 8) return launch_panel_shape<MT, GROUPED, 8, 8>(a, bn, waves, cw, ksplit);
   }
-  if (pfs >= 6 || pfs == 3) return launch_panel_shape<MT, GROUPED, 3, 3>(a, bn, waves, ksplit);
-  if (xl == 2) return launch_panel_shape<MT, GROUPED, 4, 2>(a, bn, waves, ksplit);
-  return launch_panel_shape<MT, GROUPED, 4, 4>(a, bn, waves, ksplit);
+  if (pfs >= 6 || pfs == 3) return launch_panel_shape<MT, GROUPED, 3, 3>(a, bn, waves, cw, ksplit);
+  if (xl == 2) return launch_panel_shape<MT, GROUPED, 4, 2>(a, bn, waves, cw, ksplit);
+  return launch_panel_shape<MT, GROUPED, 4, 4>(a, bn, waves, cw, ksplit);
 }
 
 template <bool GROUPED>
-static hipError_t launch_panel_g(const LaunchArgs& a, int mt, int bn, int waves, int pfs, int xl, int ksplit) {
+static hipError_t launch_panel_g(const LaunchArgs& a, int mt, int bn, int waves, int cw, int pfs, int xl, int ksplit) {
   switch (mt) {
-    case 1: return launch_panel_pf<1, GROUPED>(a, bn, waves, pfs, xl, ksplit);
-    case 2: return launch_panel_pf<2, GROUPED>(a, bn, waves, pfs, xl, ksplit);
-    case 4: return launch_panel_pf<4, GROUPED>(a, bn, waves, pfs, xl, ksplit);
-    default: return launch_panel_pf<8, GROUPED>(a, bn, waves, pfs, xl, ksplit);
+    case 1: return launch_panel_pf<1, GROUPED>(a, bn, waves, cw, pfs, xl, ksplit);
+    case 2: return launch_panel_pf<2, GROUPED>(a, bn, waves, cw, pfs, xl, ksplit);
+    case 4: return launch_panel_pf<4, GROUPED>(a, bn, waves, cw, pfs, xl, ksplit);
+    default: return launch_panel_pf<8, GROUPED>(a, bn, waves, cw, pfs, xl, ksplit);
   }
 }
 
-static hipError_t launch_panel(const LaunchArgs& a, bool grouped, int mt, int bn, int waves, int pfs, int xl, int ksplit) {
-  return grouped ? launch_panel_g<true>(a, mt, bn, waves, pfs, xl, ksplit) : launch_panel_g<false>(a, mt, bn, waves, pfs, xl, ksplit);
+static hipError_t launch_panel(const LaunchArgs& a, bool grouped, int mt, int bn, int waves, int cw, int pfs, int xl, int ksplit) {
+  return grouped ? launch_panel_g<true>(a, mt, bn, waves, cw, pfs, xl, ksplit) : launch_panel_g<false>(a, mt, bn, waves, cw, pfs, xl, ksplit);
 }
 
 template <int BM, int MTW, int JW, int NB, bool GROUPED, int NS>
@@ -397,7 +400,7 @@ static double stream_estimate(int M, int N, int K, bool grouped) {
 // per 128-k stage (bn = 128, per-channel), twice that for bn = 256, x1.45 per-group; ~9 us of launch / pipeline fill /
 // epilogue and 7..11 us for the in-launch split-K hand-off (deposit, ticket, fold by the last arrival)
 static double panel_estimate(int M, int N, int K, bool grouped, bool have_scratch, long long cap_rows, long long cap_tickets,
-                             int* bn_out, int* ks_out) {
+                             int* bn_out, int* ks_out, int* cw_out) {
   const int mt = (M <= 16) ? 1 : (M <= 32) ? 2 : (M <= 64) ? 4 : 8;
   const int rows = 16 * mt;
   const long long mblocks = (M + rows - 1) / rows;
@@ -405,7 +408,7 @@ static double panel_estimate(int M, int N, int K, bool grouped, bool have_scratc
   double best = 1e30;
   for (int bn = 128; bn <= 256; bn *= 2) {
     const long long tl = mblocks * ((N + bn - 1) / bn);
-    const double t_stage = (0.13 + 0.042 * mt) * (bn == 256 ? 1.9 : 1.0) * (grouped ? 1.45 : 1.0);
+    const double t_stage = ((mt == 8 && bn == 128) ? 0.506 : 0.13 + 0.042 * mt) * (bn == 256 ? 1.9 : 1.0) * (grouped ? 1.45 : 1.0);
     for (int ks = 1; ks <= 4; ++ks) {
       if (ks > 1 && (!have_scratch || 2 * tl > cap_tickets || tl * rows * bn * (ks - 1) > cap_rows * (long long)N || ks > NST / 4)) break;  // slots: tiles x (ks-1) x rows x bn ints inside C
       static const double tail[5] = {0.0, 0.0, 7.0, 9.0, 11.0};
@@ -415,6 +418,26 @@ static double panel_estimate(int M, int N, int K, bool grouped, bool have_scratc
         best = us;
         *bn_out = bn;
         *ks_out = ks;
+        *cw_out = 1;
+      }
+    }
+  }
+  // 64 columns per wave (bn = 256, 128-token m-blocks, per-channel): ~0.8 us per stage, workgroups of later rounds start
+  // as CUs free up (no per-round launch cost), a per-workgroup fixed part that weighs more on short K slices
+  // (profiles/r02_panel_cw2.txt)
+  if (!grouped && mt == 8) {
+    const long long tl = mblocks * ((N + 255) / 256);
+    for (int ks = 1; ks <= 4; ++ks) {
+      if (ks > 1 && (!have_scratch || 2 * tl > cap_tickets || tl * rows * 256 * (ks - 1) > cap_rows * (long long)N || ks > NST / 4)) break;
+      static const double tail[5] = {0.0, 0.0, 7.0, 9.0, 11.0};
+      const double nst_k = (double)NST / ks;
+      const double wg_us = 5.0 + 100.0 / nst_k + tail[ks] + nst_k * 0.805 * (ks > 1 ? 1.10 : 1.0);
+      const double us = 3.7 + (double)((tl * ks + 255) / 256) * wg_us;
+      if (us < best) {
+        best = us;
+        *bn_out = 256;
+        *ks_out = ks;
+        *cw_out = 2;
       }
     }
   }
@@ -457,12 +480,13 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
     // with LDS-shared activations for K % 128 == 64 at any m (the tiled kernel needs 128-k blocks).
     if (column_ok && !column && M > 32) {
       const long long cap_tk = have_ws ? (long long)(N / 128) * (max_par > 0 ? max_par : 0) : 0;
-      int pbn = 128, pks = 1, tbm = 0, tks = 1;
-      const double e_panel = ((long long)(M + 127) / 128 <= 65535) ? panel_estimate(M, N, K, grouped, have_scratch && have_ws, cap_rows, cap_tk, &pbn, &pks) : 1e30;
+      int pbn = 128, pks = 1, pcw = 1, tbm = 0, tks = 1;
+      const double e_panel = ((long long)(M + 127) / 128 <= 65535) ? panel_estimate(M, N, K, grouped, have_scratch && have_ws, cap_rows, cap_tk, &pbn, &pks, &pcw) : 1e30;
       const double e_stream = (M <= 256) ? stream_estimate(M, N, K, grouped) : 1e30;
       const double e_tiled = ((K % 128) == 0 && M > 64) ? tiled_estimate(M, N, K, grouped, have_scratch, cap_rows, cap_tk, false, &tbm, &tks) : 1e30;
       if (e_panel <= e_stream && e_panel <= e_tiled) {
         kernel = 4;
+        if (t.bm == 0 && t.pw == 0 && t.mt == 0 && pcw == 2) t.pw = 2;
         if (t.bm == 0) t.bm = pbn;
         if (t.ksplit <= 0) t.ksplit = pks;
       } else {
@@ -498,9 +522,12 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
     pl.mt = mt;
     pl.bm = bn;
     pl.waves = waves;
-    pl.pf = (t.pf == 2 || t.pf == 3 || t.pf == 8) ? t.pf : (t.pf == 0 && bn == 256 ? 3 : 4);  // weight prefetch depth in stages
+    const bool cw2 = (t.pw == 2 && bn == 256 && mt == 8);
+    pl.pf = (t.pf == 2 || t.pf == 3 || t.pf == 8) ? t.pf : (t.pf == 0 && bn == 256 && !cw2 ? 3 : 4);  // weight prefetch depth in stages
     if (pl.pf == 8 && mt > 4) pl.pf = 4;
     pl.stages = (pl.pf == 4 && t.stages == 2) ? 2 : pl.pf;  // activation prefetch depth in stages
+    // 32-column sets per wave: 2 = 4 waves x 64 columns x 2 k-groups for the 256-column, 128-token shape
+    pl.pw = (cw2 && pl.pf >= 3 && pl.pf <= 4 && pl.stages == pl.pf) ? 2 : 1;
     pl.ksplit = ksplit;
     pl.fused = 1;
     return pl;
@@ -686,7 +713,7 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
     return QQQ_ERR_ARG;
   }
   if (pl.kernel == 4) {
-    e = launch_panel(a, grouped, pl.mt, pl.bm, pl.waves, pl.pf, pl.stages, pl.ksplit);
+    e = launch_panel(a, grouped, pl.mt, pl.bm, pl.waves, pl.pw, pl.pf, pl.stages, pl.ksplit);
     if (e != hipSuccess) return fail_hip(e, "qqq_panel_kernel launch");
     reduce_launch = false;
   } else if (pl.kernel == 3) {
