@@ -18,7 +18,7 @@
 //     load lane L = 16*h + 4*c' + kq holds the 4 words (jt = 0..3) of piece (k-tile 4*s + h, chunk c', kq);
 //     MFMA lane l = 16*h + 4*c' + jt needs the word jt of the pieces kq = 0..3 of the same (h, c'),
 // i.e. a 4x4 transpose between the 4 registers and the 4 lanes of every quad: two butterfly stages of DPP
-// quad_perm moves.  The MFMA row of lane l is then i = 4*c' + jt (any bijection onto the 16 rows will do);
+// quad_perm selects (quad_transpose4).  The MFMA row of lane l is then i = 4*c' + jt (any bijection onto the 16 rows will do);
 // D lane l holds rows 4*(l >> 4) + r, i.e. c' = l >> 4 (of the OUTPUT lane) and jt = r.
 // Each workgroup re-reads all m x K activation bytes (from L2), which at m = 16 equals its weight bytes:
 // the kernel pays off for m <= 8 everywhere and up to m = 16 while m*K stays small (host heuristic).
@@ -73,20 +73,10 @@ __global__ __launch_bounds__(WAVES * 64) void qqq_column_kernel(
     for (int mt = 0; mt < MT; ++mt) r.x[mt] = *reinterpret_cast<const v4i*>(xptr[mt] + 64 * s);
     if constexpr (GROUPED) r.sc = *reinterpret_cast<const h2*>(sptr + (size_t)(s >> 1) * N);
   };
-  const bool odd = lane & 1, hi = lane & 2;
   auto compute_step = [&](const Step& r) {
-    // 4x4 transpose over (register e, quad lane q): out[e](lane q) = in[q](lane e)
-    unsigned z[4], y[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {  // stage 1: exchange across lane bit 0 / register bit 0
-      const unsigned t = (unsigned)__builtin_amdgcn_mov_dpp((int)r.w[e ^ 1], 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
-      z[e] = (odd == (bool)(e & 1)) ? r.w[e] : t;
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {  // stage 2: across lane bit 1 / register bit 1
-      const unsigned t = (unsigned)__builtin_amdgcn_mov_dpp((int)z[e ^ 2], 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
-      y[e] = (hi == (bool)(e & 2)) ? z[e] : t;
-    }
+    // 4x4 transpose over (register e, quad lane q): y[e](lane q) = w[q](lane e)   (qqq_common.hip.h: 8 VALU)
+    unsigned y[4];
+    quad_transpose4(r.w, y);
     h2 sb0 = {(_Float16)0, (_Float16)0}, sb1 = sb0;
     if constexpr (GROUPED) {
       sb0 = (h2){r.sc[0], r.sc[0]};

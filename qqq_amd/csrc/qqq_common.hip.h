@@ -67,9 +67,18 @@ __device__ __forceinline__ void epilogue_store4(const int v0, const int v1, cons
 // per-group int4 -> int8 re-quantisation of 4 weights (nibbles p0,p4,p1,p5 of q):
 // u -> fp16(u-8) exactly, ONE fp16 FMA (u-8)*s + 1152, low byte, ^0x80
 // (bit-identical to dequant_per_group, csrc/qqq_gemm.cu:167-210).
+// (The 0x6400 exponent pattern is handed to the compiler in a VGPR: v_and_or_b32 is VOP3, which on gfx9 takes no
+//  literal and one scalar operand -- with both constants as literals hipcc emits v_and + v_or, 4 extra VALU per packed
+//  word in a loop that is VALU-bound in the per-group mode.)
+__device__ __forceinline__ unsigned qqq_fp16_1024x2() {
+  unsigned m;
+  asm("v_mov_b32 %0, 0x64006400" : "=v"(m));  // pure: hoisted out of the loops
+  return m;
+}
 __device__ __forceinline__ unsigned dequant_group4(const unsigned q, const h2 s) {
-  const unsigned t0 = (q & 0x000f000fu) | 0x64006400u;  // {1024+p0, 1024+p4}
-  const unsigned t1 = (q & 0x00f000f0u) | 0x64006400u;  // {1024+16*p1, 1024+16*p5}
+  const unsigned magic = qqq_fp16_1024x2();
+  const unsigned t0 = (q & 0x000f000fu) | magic;  // {1024+p0, 1024+p4}
+  const unsigned t1 = (q & 0x00f000f0u) | magic;  // {1024+16*p1, 1024+16*p5}
   const h2 c_sub = {(_Float16)-1032.0f, (_Float16)-1032.0f};
   const h2 c_mul = {(_Float16)0.0625f, (_Float16)0.0625f};
   const h2 c_add = {(_Float16)-72.0f, (_Float16)-72.0f};
