@@ -521,10 +521,11 @@ def main():
         live, traffic_note = ({}, "skipped (--no-pmc)") if args.no_pmc else live_traffic()
         a = per_m["4096"]
         sus = sustained_matrix_rate(dev)
+        fam = a["kernel"]  # the family the dispatcher runs at M=4096 ("panel": 64 columns per wave, or "tiled")
         result["roofline"] = {
-            "kernel": "qqq_tiled_kernel (M=4096)", "bound": "mfma", "achieved": a["tops"], "peak": PEAK_MFMA_TOPS,
+            "kernel": f"qqq_{fam}_kernel (M=4096)", "bound": "mfma", "achieved": a["tops"], "peak": PEAK_MFMA_TOPS,
             "unit": "TOPS", "frac": a["tops"] / PEAK_MFMA_TOPS,
-            "traffic": live.get("tiled_m4096", committed_traffic("qqq_tiled_kernel_M4096")),
+            "traffic": live.get("tiled_m4096", committed_traffic(f"qqq_{fam}_kernel_M4096")),
             "traffic_unit": "bytes/launch, L2<->fabric (HBM + Infinity Cache)",
             "traffic_source": traffic_note if "tiled_m4096" in live else f"profiles/hbm_traffic.json (committed PMC pass; live pass: {traffic_note})",
             "algorithmic_bytes": algorithmic_bytes(4096, N_FULL, K_FULL), "avg_launch_us": a["us"],
@@ -533,7 +534,7 @@ def main():
             "frac_of_sustained_mfma_only": (a["tops"] / sus["mfma_only_tops"]) if "mfma_only_tops" in sus else None,
             "frac_of_sustained_kstep_shape": (a["tops"] / sus["mfma_lds_unpack_tops"]) if "mfma_lds_unpack_tops" in sus else None,
             "note": "peak = 256 CU x 2.4 GHz x 8192 int8 op/clk; 4404 TOPS is the v_mfma_i32_32x32x32_i8 micro-benchmark ceiling; "
-                    "under this kernel the chip clocks ~1.9 GHz (power), profiles/r02_pmc_tiled_m4096.txt; "
+                    "under the M=4096 kernels the chip clocks ~1.9 GHz (power), profiles/r02_pmc_*_m4096.txt; "
                     "sustained_on_random_int8 = this part's matrix pipe measured in this run on random operands, MFMAs only and "
                     "with the k-step's LDS reads + int4 unpack (profiles/r02_mfma_power_ceiling.txt)",
         }

@@ -21,6 +21,7 @@ for (name, grid), v in sorted(vals.items()):
     if "qqq_stream_kernelILi1E" in name: key = "qqq_stream_kernel_M16"
     if "qqq_column_kernelILi1E" in name: key = "qqq_column_kernel_M1"
     if "qqq_tiled_kernel" in name: key = "qqq_tiled_kernel_M4096"
+    if "qqq_panel_kernel" in name: key = "qqq_panel_kernel_M4096"
     if key and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
         out[key] = {"kernel": name, "fetch_size_kib": round(v["FETCH_SIZE"]), "write_size_kib": round(v["WRITE_SIZE"]),
                     "bytes": int(2 * v["FETCH_SIZE"] * 1024 + v["WRITE_SIZE"] * 1024)}
