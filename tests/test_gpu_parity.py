@@ -412,6 +412,92 @@ def test_panel_two_workgroups_per_cu(dev):
                     assert ulp_distance(D, eD) == 0, (grouped, M, tune, rep)
 
 
+def test_every_variant_under_load(dev):
+    """Every tuning variant, repeatedly, while a second stream keeps the chip busy with other GEMMs of mixed weight (so
+    that workgroups of different kernels share CUs and the waves of a workgroup drift apart): results must equal the
+    quiet run's bit for bit.  Idle-chip parity alone had missed two races."""
+    from oracle import qqq_ref as R
+
+    rng = np.random.default_rng(4242)
+    N, K = 2048, 2048
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    for grouped in (False, True):
+        codes = rng.integers(0 if grouped else -8, 16 if grouped else 8, size=(K, N)).astype(np.int8)
+        B = torch.from_numpy(R.pack_codes(codes, grouped)).to(dev)
+        s2 = torch.from_numpy(rng.random((1, N), dtype=np.float32) * 2e-4 + 1e-5).to(dev)
+        s3 = torch.from_numpy((rng.random((K // 128, N), dtype=np.float32) * 15 + 0.5).astype(np.float16)).to(dev) if grouped else None
+        h = GemmHarness(B, s2, s3, dev)       # the layer under test
+        bg = GemmHarness(B, s2, s3, dev)      # the background layer: own scratch
+        toks = {}
+        for M in (40, 64, 200, 520):
+            A = torch.from_numpy(rng.integers(-128, 128, size=(M, K), dtype=np.int8)).to(dev)
+            s1 = torch.from_numpy(rng.random((M, 1), dtype=np.float32) * 0.05 + 0.001).to(dev)
+            toks[M] = (A, s1)
+        bg_tunes = [dict(kernel=4, waves=4, ksplit=2, pf=2), dict(kernel=1), dict(kernel=2, bm=64, ksplit=2), dict(kernel=4, mt=4, ksplit=3), dict(kernel=3)]
+        for M in (40, 200, 520):
+            A, s1 = toks[M]
+            want = torch.empty((M, N), dtype=torch.float16, device=dev)
+            ops.qqq_gemm_ex(A, h.B, h.C, want, s1, h.s2, h.s3, h.ws, -1, -1, -1, 16, tune=dict(kernel=1, ksplit=1))
+            torch.cuda.synchronize()
+            for tune in variants(M, K, N):
+                outs = []
+                for it in range(6):
+                    with torch.cuda.stream(streams[1]):
+                        for j in range(3):
+                            Mb = (64, 40, 200)[(it + j) % 3]
+                            Ab, s1b = toks[Mb]
+                            Db = torch.empty((Mb, N), dtype=torch.float16, device=dev)
+                            ops.qqq_gemm_ex(Ab, bg.B, bg.C, Db, s1b, bg.s2, bg.s3, bg.ws, -1, -1, -1, 16, tune=bg_tunes[(it + j) % len(bg_tunes)])
+                    D = torch.empty((M, N), dtype=torch.float16, device=dev)
+                    with torch.cuda.stream(streams[0]):
+                        ops.qqq_gemm_ex(A, h.B, h.C, D, s1, h.s2, h.s3, h.ws, -1, -1, -1, 16, tune=tune or None)
+                    outs.append(D)
+                torch.cuda.synchronize()
+                for it, D in enumerate(outs):
+                    assert torch.equal(D.view(torch.int16), want.view(torch.int16)), (grouped, M, tune, it)
+            assert int(h.ws.abs().max()) == 0 and int(bg.ws.abs().max()) == 0
+
+
+def test_splitk_deposits_with_three_workgroups_per_cu(dev):
+    """The reproducer of the missing-s_nop bug (inline-asm 16-byte deposit stores whose data registers hipcc re-used before
+    the store had read them): light 4-wave panel workgroups, three to a CU, the same split-K launch hammered from two
+    streams.  Failed 25-40 % of the calls at m = 33 / 64 before the fix, on every box; idle-chip tests never did."""
+    from qqq_amd import pack as P
+
+    g = torch.Generator(device="cpu").manual_seed(123)
+    N, K = 2048, 4096
+    layers = []
+    for i in range(2):
+        codes = torch.randint(-7, 8, (K, N), generator=g, dtype=torch.int8)
+        layers.append(GemmHarness(P.pack_codes(codes.to(dev), False), (torch.rand((1, N), generator=g) * 2e-4 + 1e-5).to(torch.float32), None, dev))
+    Ms = [33, 64, 100, 128, 200, 256, 300]
+    toks, want = {}, {}
+    for M in Ms:
+        A = torch.randint(-128, 128, (M, K), generator=g, dtype=torch.int8).to(dev)
+        s1 = (torch.rand((M, 1), generator=g) * 0.05 + 0.001).to(torch.float32).to(dev)
+        toks[M] = (A, s1)
+        for li, h in enumerate(layers):
+            D = torch.empty((M, N), dtype=torch.float16, device=dev)
+            ops.qqq_gemm_ex(A, h.B, h.C, D, s1, h.s2, h.s3, h.ws, -1, -1, -1, 16, tune=dict(kernel=1, ksplit=1))
+            want[(li, M)] = D
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    for tune in (dict(kernel=4, waves=4, ksplit=4, pf=2), dict(kernel=4, waves=4, ksplit=4, pf=2, mt=2), dict(kernel=2, bm=64, ksplit=4), dict(kernel=4, mt=4, ksplit=4)):
+        for trial in range(3):
+            outs = []
+            for it in range(100):
+                for li, h in enumerate(layers):
+                    M = Ms[(it + 2 * li) % len(Ms)]
+                    A, s1 = toks[M]
+                    D = torch.empty((M, N), dtype=torch.float16, device=dev)
+                    with torch.cuda.stream(streams[li]):
+                        ops.qqq_gemm_ex(A, h.B, h.C, D, s1, h.s2, h.s3, h.ws, -1, -1, -1, 16, tune=tune)
+                    outs.append((li, M, D))
+            torch.cuda.synchronize()
+            bad = [(li, M) for li, M, D in outs if not torch.equal(D.view(torch.int16), want[(li, M)].view(torch.int16))]
+            assert not bad, (tune, trial, len(bad), bad[:4])
+
+
 def test_k_tail_large_m_through_auto_dispatch(dev):
     """K % 128 == 64 with many tokens (round 1 sent these to the stream kernel, one weight pass per 64 tokens): the
     automatic dispatch must take the panel kernel and match the oracle on sampled rows."""
