@@ -1,5 +1,5 @@
-// qqq_panel.hip.h -- "panel" kernel (about 64 .. 1024 tokens, in 128-token m-blocks: weights HBM -> VGPR per wave,
-// activations shared through LDS, in-launch split-K).  Part of the single translation unit qqq_w4a8.hip (see its header comment for the design).
+// qqq_panel.hip.h -- "panel" kernel (from about 64 tokens up, in m-blocks of up to 128 tokens: weights HBM -> VGPR per wave,
+// activations shared through LDS, in-launch split-K; with 64 columns per wave also the large-m kernel of the per-channel mode).  Part of the single translation unit qqq_w4a8.hip (see its header comment for the design).
 #ifndef QQQ_AMD_QQQ_PANEL_HIP_H_
 #define QQQ_AMD_QQQ_PANEL_HIP_H_
 
@@ -9,8 +9,9 @@
 //  * The waves of a workgroup split the COLUMNS (wave wn owns the 32 columns of half-group (ng, half), exactly the
 //    column kernel's set: chunks c = 4*half + c' of a 64-column group = 256 contiguous bytes of every 16-k row of
 //    B), so every weight byte is loaded by exactly one wave, straight from HBM into VGPRs (used once: no LDS,
-//    no barrier on the weight path), PFS stages ahead.  The packed words are re-distributed between lanes with the
-//    column kernel's DPP 4x4 transpose; v_mfma_i32_16x16x64_i8, MFMA row i = 4*c' + jt.
+//    no barrier on the weight path), PFS stages ahead.  The packed words are re-distributed between the lanes of a
+//    quad with the 8-VALU 4x4 transpose of qqq_common.hip.h (quad_transpose4); v_mfma_i32_16x16x64_i8, MFMA row
+//    i = 4*c' + jt.
 //  * The activations (16*MT tokens x 128 k per stage) are the operand every wave needs: they are staged ONCE per
 //    workgroup in a double- / triple-buffered LDS image (16-byte chunks XOR-swizzled by the row: every ds_read_b128
 //    is conflict free), so the L1 traffic of a workgroup is weights + activations once -- not activations once per
@@ -25,11 +26,12 @@
 //    at N = 8192, which keeps the split-K partial-sum traffic at 3 x M x N x 4 B.
 //  * split-K in-launch: arrival-order tickets as in the tiled kernel, but every depositor owns a slot (slot index =
 //    arrival index), so nobody waits except the last arrival, which has by construction only already-arrived
-//    workgroups to wait for.  Deposits are lane-linear full-line write-through stores.
+//    workgroups to wait for.  Deposits are lane-linear full-line write-through stores.  With two k-groups and at
+//    least two m-tiles BOTH groups finish the tile (each keeps half of the m-tiles after the meeting in LDS).
 //  * HW = 2: a wave owns BOTH halves of its 64-column group (two weight loads, 4*MT MFMAs per 64-k step): every
-//    activation fragment read from LDS then feeds 4 MFMAs instead of 2.  With HW = 1 a 128-token workgroup reads
-//    8 waves x 16 KB of fragments per stage = 1024 LDS clocks against 1024 matrix-pipe clocks per SIMD -- the LDS
-//    read port is a co-limit; HW = 2 halves it.
+//    activation fragment read from LDS feeds 4 MFMAs instead of 2 and the unpack work per MFMA halves -- the loop
+//    of this kernel is bound by VALU ISSUE (VALU and MFMA share the SIMD's issue port), not by the LDS or the
+//    matrix pipe: 3.1 VALU per 16-cycle MFMA kept that pipe at 50 %, HW = 2 with the cheap transpose runs 1.45.
 // grid = (ceil(N / BN), ksplit, ceil(M / (16*MT)));  block = 64 * WN * KG;  BN = 32 * WN * HW.
 // ------------------------------------------------------------------------------------------
 
