@@ -267,13 +267,12 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
   };
 
   if (nst > 0) {
-    // ---- prologue: stages 0 and 1 straight into LDS, the rings filled in steady-state order ----
+    // ---- prologue: stages 0 and 1 go straight into LDS.  Everything that does not need their staging registers is
+    // issued BEFORE the wait for them (loads return in order, the two are the oldest): the first weight stages'
+    // HBM latency overlaps the activations' instead of following it ----
     load_x(0, xr[0]);
     load_x(1, xr[1]);
-    store_x(0, xr[0]);
-    store_x(1, xr[1]);
-#pragma unroll
-    for (int j = 2; j < 2 + XL; ++j) load_x(j, xr[j % XL]);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < PFS; ++j) {
 #pragma unroll
@@ -281,6 +280,15 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
       if constexpr (GROUPED) load_sc(j, scr[j]);
       __builtin_amdgcn_sched_barrier(0);
     }
+#pragma unroll
+    for (int j = 2; j < 2 + XL; ++j)
+      if (j % XL >= 2) load_x(j, xr[j % XL]);
+    __builtin_amdgcn_sched_barrier(0);
+    store_x(0, xr[0]);
+    store_x(1, xr[1]);
+#pragma unroll
+    for (int j = 2; j < 2 + XL; ++j)
+      if (j % XL < 2) load_x(j, xr[j % XL]);
     __syncthreads();
     {  // operands of the first step; its ring slot is refilled like any other
       const int tk0 = (KG == 2) ? kg : 0;
