@@ -39,11 +39,11 @@ __global__ __launch_bounds__(64) void qqq_reduce_kernel(const int32_t* __restric
 // fused per-token dynamic int8 quantisation (QuantLinear.dynamic_quant, qlinear_marlin.py:265-268)
 // one workgroup per token row; the row is kept in registers between the two passes.
 // ------------------------------------------------------------------------------------------
-template <int VPT>  // 16-byte vectors (8 halfs) per thread; covers K <= 256*8*VPT
-__global__ __launch_bounds__(256) void qqq_dynamic_quant_kernel(const _Float16* __restrict__ x,
-                                                                int8_t* __restrict__ xq,
-                                                                float* __restrict__ s1, const int K) {
-  __shared__ float wmax[4];
+template <int VPT, int NT = 256>  // 16-byte vectors (8 halfs) per thread; covers K <= NT*8*VPT.  NT = 1024: few rows (decode) --
+__global__ __launch_bounds__(NT) void qqq_dynamic_quant_kernel(const _Float16* __restrict__ x,  // the row's latency chain is 4x shorter
+                                                               int8_t* __restrict__ xq,
+                                                               float* __restrict__ s1, const int K) {
+  __shared__ float wmax[NT / 64];
   const int row = blockIdx.x;
   const int tid = threadIdx.x;
   const int nvec = K >> 3;
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void qqq_dynamic_quant_kernel(const _Float16* 
   h2 amax2 = {(_Float16)0, (_Float16)0};
 #pragma unroll
   for (int i = 0; i < VPT; ++i) {
-    const int idx = tid + i * 256;
+    const int idx = tid + i * NT;
     if (idx < nvec) {
       v[i] = xr[idx];
       const u4v bits = __builtin_bit_cast(u4v, v[i]);
@@ -68,31 +68,35 @@ __global__ __launch_bounds__(256) void qqq_dynamic_quant_kernel(const _Float16* 
   for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
   if ((tid & 63) == 0) wmax[tid >> 6] = amax;
   __syncthreads();
-  amax = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+  amax = wmax[0];
+#pragma unroll
+  for (int w = 1; w < NT / 64; ++w) amax = fmaxf(amax, wmax[w]);
   // torch on GPU lowers `.div(127.0)` to a multiply by the fp32 reciprocal; result kept in fp16
   const float scale = (float)(_Float16)__fmul_rn(amax, 1.0f / 127.0f);
   if (tid == 0) s1[row] = scale;
   // x / scale must be the correctly rounded fp32 quotient before rint() (torch semantics).  An IEEE division costs
   // ~12 VALU ops per element and made this kernel compute-bound; rint(x * (1/scale)) equals rint(x / scale) unless
   // the product lies within ~1e-4 of a half-integer (|q| <= 128 and the reciprocal-multiply is good to a few ulp),
-  // so only vectors with such an element (a few per thousand) take the exact division.
+  // so only elements for which some lane of the wave is that close take the exact division.
   const float rinv = (scale > 0.f) ? __frcp_rn(scale) : 0.f;  // all-zero row: reference gives NaN -> int8 (UB); we emit 0
   int2* qr = reinterpret_cast<int2*>(xq + (size_t)row * K);
 #pragma unroll
   for (int i = 0; i < VPT; ++i) {
-    const int idx = tid + i * 256;
+    const int idx = tid + i * NT;
     if (idx < nvec) {
       float q[8];
-      bool near_tie = false;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float p = (float)v[i][e] * rinv;
+        const float xe = (float)v[i][e];
+        const float p = xe * rinv;
         q[e] = rintf(p);
-        near_tie |= fabsf(p - q[e]) > 0.4995f;
-      }
-      if (near_tie) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) q[e] = (scale > 0.f) ? rintf(__fdiv_rn((float)v[i][e], scale)) : 0.f;
+        // the exact division only where some lane of the wave needs it for THIS element (~6 % of the wave-elements;
+        // decided per 8-element vector it was ~40 % of the vectors, each paying 8 divisions)
+        const bool near_tie = fabsf(p - q[e]) > 0.4995f;
+        if (__builtin_amdgcn_ballot_w64(near_tie) != 0) {
+          const float qd = (scale > 0.f) ? rintf(__fdiv_rn(xe, scale)) : 0.f;
+          q[e] = near_tie ? qd : q[e];
+        }
       }
       unsigned lo = 0, hi = 0;
 #pragma unroll

@@ -764,7 +764,15 @@ extern "C" int qqq_dynamic_quant(const void* x, void* xq, void* s1, int m, int k
   float* sp = static_cast<float*>(s1);
   const int nvec = k / 8;
   const int vpt = (nvec + 255) / 256;
-  if (vpt <= 2)
+  if ((m <= 512 || nvec > 2048) && vpt > 2 && vpt <= 32) {  // few rows (<= 2 per CU) or very long rows: 16 waves per row
+    const int v4 = (nvec + 1023) / 1024;
+    if (v4 <= 2)
+      hipLaunchKernelGGL((qqq_dynamic_quant_kernel<2, 1024>), dim3(m), dim3(1024), 0, st, xp, qp, sp, k);
+    else if (v4 <= 4)
+      hipLaunchKernelGGL((qqq_dynamic_quant_kernel<4, 1024>), dim3(m), dim3(1024), 0, st, xp, qp, sp, k);
+    else
+      hipLaunchKernelGGL((qqq_dynamic_quant_kernel<8, 1024>), dim3(m), dim3(1024), 0, st, xp, qp, sp, k);
+  } else if (vpt <= 2)
     hipLaunchKernelGGL(qqq_dynamic_quant_kernel<2>, dim3(m), dim3(256), 0, st, xp, qp, sp, k);
   else if (vpt <= 4)
     hipLaunchKernelGGL(qqq_dynamic_quant_kernel<4>, dim3(m), dim3(256), 0, st, xp, qp, sp, k);
