@@ -58,8 +58,8 @@ typedef struct qqq_tune {
   int kernel;  /* 0 auto, 1 = "stream" (weights straight to VGPRs, 16x16x64 MFMA, small m),
                   2 = "tiled" (LDS-staged 32x32x32 MFMA tiles, large m),
                   3 = "column" (decode: 32 columns x all of K per workgroup, no split-K),
-                  4 = "panel" (8 < m <= 128: all tokens of an m-block x bm columns x a K slice per workgroup,
-                      weights straight to VGPRs, activations shared through LDS, in-launch split-K)          */
+                  4 = "panel" (m-blocks of up to 128 tokens: all tokens of an m-block x bm columns x a K slice per
+                      workgroup, weights straight to VGPRs, activations shared through LDS, in-launch split-K) */
   int ksplit;  /* 0 auto, else number of K slices (partials go through C)                   */
   int waves;   /* stream: waves per workgroup (4, 8 or 16); panel (bm = 128): 4 or 8 (two k-groups); 0 auto */
   int fused;   /* split-K finish; 0 auto.  stream: 1 = last-arriving workgroup reduces in-launch (tickets in
