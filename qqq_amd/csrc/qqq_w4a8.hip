@@ -431,7 +431,7 @@ static double panel_estimate(int M, int N, int K, bool grouped, bool have_scratc
       if (ks > 1 && (!have_scratch || 2 * tl > cap_tickets || tl * rows * 256 * (ks - 1) > cap_rows * (long long)N || ks > NST / 4)) break;
       static const double tail[5] = {0.0, 0.0, 7.0, 9.0, 11.0};
       const double nst_k = (double)NST / ks;
-      const double wg_us = 5.0 + 100.0 / nst_k + tail[ks] + nst_k * 0.805 * (ks > 1 ? 1.10 : 1.0);
+      const double wg_us = 5.0 + 100.0 / nst_k + tail[ks] + nst_k * 0.805 * (ks > 1 ? 1.04 : 1.0);
       const double us = 3.7 + (double)((tl * ks + 255) / 256) * wg_us;
       if (us < best) {
         best = us;
