@@ -77,6 +77,27 @@ def main():
             del ql, lin
             torch.cuda.empty_cache()
         out.setdefault("sum_of_7_linears", {})[mode] = {str(M): {"quantlinear_us": a, "fp16_us": b, "speedup": b / a} for M, (a, b) in tot.items()}
+        # the same block with the projections that share an input merged (what vLLM does): q/k/v -> one layer
+        # with N = 12288, gate/up -> N = 22016; the fp16 side gets the same merge (one nn.Linear each)
+        from qqq_amd import fuse_quant_linears
+        ftot = {}
+        for (name, parts, K) in (("qkv_proj", [4096, 4096, 4096], 4096), ("o_proj", [4096], 4096), ("gate_up_proj", [11008, 11008], 4096), ("down_proj", [4096], 11008)):
+            qls = [make_ql(dev, n, K, gs, hash((name, i, gs)) & 0xFFFF) for i, n in enumerate(parts)]
+            ql = fuse_quant_linears(qls) if len(qls) > 1 else qls[0]
+            N = sum(parts)
+            lin = torch.nn.Linear(K, N, bias=False).half().to(dev)
+            for M in (1024, 8192, 32768):
+                x = torch.randn((M, K), device=dev, dtype=torch.float16)
+                t_q = time_fn(lambda: ql(x))
+                t_f = time_fn(lambda: lin(x))
+                out.setdefault("fused_layers", {}).setdefault(mode, {}).setdefault(name, {})[str(M)] = {
+                    "quantlinear_us": t_q, "fp16_linear_us": t_f, "speedup_vs_fp16": t_f / t_q}
+                ftot.setdefault(M, [0.0, 0.0])
+                ftot[M][0] += t_q; ftot[M][1] += t_f
+                del x
+            del ql, qls, lin
+            torch.cuda.empty_cache()
+        out.setdefault("sum_of_4_merged_linears", {})[mode] = {str(M): {"quantlinear_us": a, "fp16_us": b, "speedup": b / a} for M, (a, b) in ftot.items()}
     print(json.dumps(out))
 
 
