@@ -9,13 +9,15 @@ per-channel W4A8, M in {1,16,128,1024,4096}, N=8192, K=21760, on synthetic int8 
 range, produced by the fused dynamic_quant of N(0,1) fp16 tokens) and random int4 weights, all resident
 in HBM before the timed region.  Consecutive calls use DIFFERENT 89 MB weight buffers (5 of them, 445 MB
 > the 256 MiB Infinity Cache) so that "HBM GB/s" is not an L3 number.  `value` = sum(2*M*N*K) / time.
+The timed region replays hipGraphs that hold several consecutive steps each (--steps-per-graph, default the largest
+of 10/8/5/4/2/1 that divides K; exactly K steps run): the idle gap at a replay boundary is launch plumbing, not GEMM.
 
 N > 1 (BASELINE configs[4]): same sweep, rows of every point with M >= 64*N sharded over the ranks
 (weights replicated), output shards all-gathered over RCCL/xGMI, chunk-pipelined against the GEMM
 (qqq_amd/parallel.py); smaller points are computed redundantly on every rank (no collective).  Strong
 scaling: the total work is fixed.
 
-Extra objects on the JSON line: `roofline` (dominant kernel = the tiled MFMA kernel at M=4096, durations
+Extra objects on the JSON line: `roofline` (dominant kernel = whatever the dispatcher runs at M=4096, durations
 from HIP event pairs recorded on the launch stream inside this process), `roofline_hbm` (the HBM-bound
 decode kernel at M=1), `cpu_baseline` (the C oracle timed on the host cores, bounded sample) and
 `per_m` (per sweep point: us, TOPS, GB/s, speedup vs torch fp16 GEMM on the same GPU).
@@ -327,6 +329,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-fp16", action="store_true", help="skip the torch fp16 GPU GEMM comparison")
     ap.add_argument("--detail-iters", type=int, default=100)
+    ap.add_argument("--steps-per-graph", type=int, default=0,
+                    help="steps captured per hipGraph of the timed region (0 = the largest of 10/8/5/4/2/1 dividing --steps)")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 PMC traffic passes; quote the committed ones")
     ap.add_argument("--check", action="store_true",
                     help="after the timed region verify the gathered outputs of the sharded points against a local full GEMM")
@@ -394,6 +398,7 @@ def main():
     step_body()
     torch.cuda.synchronize()
     graph = None
+    graph_n, spg = None, 1  # a second graph holding `spg` consecutive steps: fewer replay boundaries inside the timed region
     if world == 1:
         try:
             side = torch.cuda.Stream(device=dev)
@@ -408,6 +413,17 @@ def main():
             g.replay()
             torch.cuda.synchronize()
             graph = g
+            spg = max(d for d in (10, 8, 5, 4, 2, 1) if args.steps % d == 0) if args.steps_per_graph <= 0 else args.steps_per_graph
+            if spg > 1 and args.steps % spg == 0:
+                gn = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gn):
+                    for _ in range(spg):
+                        step_body()
+                gn.replay()
+                torch.cuda.synchronize()
+                graph_n = gn
+            else:
+                spg = 1
         except Exception as e:  # pragma: no cover
             print(f"[bench] hipGraph capture unavailable ({e}); running eager", file=sys.stderr)
             graph = None
@@ -428,8 +444,12 @@ def main():
         run_step()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run_step()
+    if graph_n is not None:
+        for _ in range(args.steps // spg):  # EXACTLY args.steps steps: spg steps per replay
+            graph_n.replay()
+    else:
+        for _ in range(args.steps):
+            run_step()
     barrier()
     dt = time.perf_counter() - t0
     # per-step spread, measured AFTER the timed region with stream events (diagnostic only; `value` uses `dt`)
@@ -474,8 +494,9 @@ def main():
                        + ("W ~ N(0, 0.02^2) quantised GPTQ-style (SURVEY 8d)" if os.environ.get("QQQ_BENCH_WEIGHTS", "gptq") != "uniform"
                           else "uniformly random int4 codes"),
             "tokens": "x ~ N(0,1) fp16 through the fused dynamic int8 quantiser",
-            "launch": ("hipGraph replay (each sweep point bound to one of the rotating weight buffers: a buffer is re-read "
-                       "only after the other four, 356 MB, have passed through the 256 MiB Infinity Cache)") if graph is not None else "eager",
+            "launch": (f"hipGraph replay, {spg} step(s) per graph in the timed region (each sweep point bound to one of the rotating "
+                       "weight buffers: a buffer is re-read only after the other four, 356 MB, have passed through the 256 MiB "
+                       "Infinity Cache)") if graph is not None else "eager",
             "parallelism": "single GPU" if world == 1 else f"M-sharded over {world} GPUs + RCCL all-gather of fp16 shards (points with M >= {64*world})",
         },
     }
