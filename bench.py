@@ -234,8 +234,9 @@ def cpu_baseline(sample_rows=64, budget_s=12.0):
 
 def sustained_matrix_rate(dev, reps=3, iters=20000, nwg=256):
     """What the matrix pipe sustains on THIS part under its power limit, on random int8 operands, in the tiled kernel's
-    k-step shape (dev library probe, tools/mfma_ceiling.py): rung 0 = MFMAs on register operands only, rung 2 = + the
-    k-step's LDS fragment reads + the int4 unpack.  Context for `roofline.frac` (profiles/r02_mfma_power_ceiling.txt)."""
+    k-step shape (dev library probe, tools/mfma_ceiling.py): rung 0 = 32x32x32 MFMAs on register operands only, rung 3 = the
+    same MACs issued as 16x16x64 MFMAs (the panel kernel's instruction: half the accumulator traffic per MAC, it sustains
+    ~15 % more), rung 2 = 32x32x32 + the k-step's LDS fragment reads + the int4 unpack.  Context for `roofline.frac` (profiles/r02_mfma_power_ceiling.txt)."""
     from qqq_amd import _dev
 
     L = _dev.lib()
@@ -244,7 +245,7 @@ def sustained_matrix_rate(dev, reps=3, iters=20000, nwg=256):
     sink = torch.zeros(4, dtype=torch.int32, device=dev)
     st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     out = {}
-    for mode, key in ((0, "mfma_only_tops"), (2, "mfma_lds_unpack_tops")):
+    for mode, key in ((0, "mfma_only_tops"), (3, "mfma_16x16x64_only_tops"), (2, "mfma_lds_unpack_tops")):
         v = []
         for _ in range(reps):
             ms = ctypes.c_float()
@@ -553,6 +554,7 @@ def main():
             "frac_of_ubench_ceiling": a["tops"] / 4404.0,
             "sustained_on_random_int8": sus,
             "frac_of_sustained_mfma_only": (a["tops"] / sus["mfma_only_tops"]) if "mfma_only_tops" in sus else None,
+            "frac_of_sustained_mfma_16x16x64_only": (a["tops"] / sus["mfma_16x16x64_only_tops"]) if "mfma_16x16x64_only_tops" in sus else None,
             "frac_of_sustained_kstep_shape": (a["tops"] / sus["mfma_lds_unpack_tops"]) if "mfma_lds_unpack_tops" in sus else None,
             "note": "peak = 256 CU x 2.4 GHz x 8192 int8 op/clk; 4404 TOPS is the v_mfma_i32_32x32x32_i8 micro-benchmark ceiling; "
                     "under the M=4096 kernels the chip clocks ~1.9 GHz (power), profiles/r02_pmc_*_m4096.txt; "

@@ -48,7 +48,7 @@ int qqq_dev_probe_fill(const void* src, size_t wg_stride, size_t bytes_per_wg, i
 /* Sustained matrix-pipe rate probe (tools/mfma_ceiling.py): `nwg` workgroups of 8 waves, each wave `iters` k-steps of
  * 8 x v_mfma_i32_32x32x32_i8 (the tiled kernel's 4 x 2 fragment grid) on operands from `ops` (>= nwg * 64 KiB of
  * random bytes or zeros).  mode 0: register operands only; 1: + LDS fragment reads at the tiled kernel's volume;
- * 2: + the per-channel int4 unpack.  Times ONE launch (after a warm-up launch); ms_out in host memory. */
+ * 2: + the per-channel int4 unpack; 3: register operands only, on v_mfma_i32_16x16x64_i8 (16 per k-step).  Times ONE launch (after a warm-up launch); ms_out in host memory. */
 int qqq_dev_probe_mfma_rate(int mode, const void* ops, int nwg, int iters, void* sink, int dev, void* stream,
                             float* ms_out);
 const char* qqq_dev_last_error(void);

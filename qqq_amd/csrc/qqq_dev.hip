@@ -153,6 +153,36 @@ __global__ __launch_bounds__(512) void qqq_probe_mfma_rate_kernel(const v4i* __r
   if (f == 0x13579bdf) sink[0] = f;  // keeps the chains alive
 }
 
+// the same register-only loop on v_mfma_i32_16x16x64_i8 (the panel / stream / column kernels' instruction): 16 MFMAs per
+// trip = the MACs of 8 x 32x32x32, operands 4 (weights) x 4 (tokens), two sets alternated
+__global__ __launch_bounds__(512) void qqq_probe_mfma16_rate_kernel(const v4i* __restrict__ ops, const int iters, int* __restrict__ sink) {
+  const int tid = threadIdx.x;
+  const v4i* p = ops + ((size_t)blockIdx.x * 512 + tid) * 12;
+  v4i a[2][4], b[2][2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[s][i] = p[s * 6 + i];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) b[s][i] = p[s * 6 + 4 + i];
+  }
+  v4i acc[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = (v4i){0, 0, 0, 0};
+  for (int it = 0; it < iters; it += 2) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[0][q & 3], b[0][(q >> 2) & 1], acc[q], 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[1][q & 3], b[1][(q >> 2) & 1], acc[q], 0, 0, 0);
+  }
+  int f = 0;
+#pragma unroll
+  for (int q = 0; q < 16; ++q)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) f ^= acc[q][r];
+  if (f == 0x13579bdf) sink[0] = f;
+}
+
 extern "C" int qqq_dev_probe_mfma(int kind, const void* a, const void* b, void* out, int dev, void* stream) {
   DevGuard guard(dev);
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -227,7 +257,8 @@ extern "C" int qqq_dev_probe_mfma_rate(int mode, const void* ops, int nwg, int i
     int* sk = static_cast<int*>(sink);
     if (mode == 0) hipLaunchKernelGGL(qqq_probe_mfma_rate_kernel<0>, dim3(nwg), dim3(512), 0, st, o, iters, sk);
     else if (mode == 1) hipLaunchKernelGGL(qqq_probe_mfma_rate_kernel<1>, dim3(nwg), dim3(512), 0, st, o, iters, sk);
-    else hipLaunchKernelGGL(qqq_probe_mfma_rate_kernel<2>, dim3(nwg), dim3(512), 0, st, o, iters, sk);
+    else if (mode == 2) hipLaunchKernelGGL(qqq_probe_mfma_rate_kernel<2>, dim3(nwg), dim3(512), 0, st, o, iters, sk);
+    else hipLaunchKernelGGL(qqq_probe_mfma16_rate_kernel, dim3(nwg), dim3(512), 0, st, o, iters, sk);  // mode 3
   };
   launch();  // warm-up (and clock settling)
   (void)hipEventRecord(e0, st);
