@@ -147,3 +147,27 @@ def test_dispatch_plan_respects_scratch_contract(L):
     assert p["nslots"] == 0 and p["ksplit"] == 1  # 2 slabs of 1024 rows do not fit in 1024 rows
     p = _lib.plan(2048, 8192, 21760, -1, 16, tune=dict(kernel=2, bm=256, ksplit=2, fused=1))
     assert p["ksplit"] == 1
+
+
+def test_dispatch_of_the_baseline_sweep(L):
+    """The families the cost models pick at the BASELINE layer (N=8192, K=21760), as measured in profiles/r02_dispatch_check*.txt:
+    decode -> column, a few tens of tokens -> stream, 128 tokens -> panel with 4 K slices, from ~768 tokens per-channel -> the
+    panel kernel with 64 columns per wave (pw = 2, no split), per-group large m -> the tiled column-owner tile."""
+    from qqq_amd import _lib
+
+    N, K = 8192, 21760
+    assert _lib.plan(1, N, K, -1, 16)["kernel"] == 3 and _lib.plan(8, N, K, 128, 16)["kernel"] == 3
+    assert _lib.plan(16, N, K, -1, 16)["kernel"] == 1
+    p = _lib.plan(128, N, K, -1, 16)
+    assert (p["kernel"], p["mt"], p["ksplit"]) == (4, 8, 4)
+    for m in (1024, 4096, 8192):
+        p = _lib.plan(m, N, K, -1, 16)
+        assert (p["kernel"], p["bm"], p["mt"], p["pw"], p["ksplit"]) == (4, 256, 8, 2, 1), (m, p)
+        g = _lib.plan(m, N, K, 128, 16)
+        assert g["kernel"] == 2 and g["bm"] == 258, (m, g)
+    # a forced 64-column shape is honoured only where it exists (128-token m-blocks, bm = 256, prefetch depth 3 or 4)
+    assert _lib.plan(300, N, K, -1, 16, tune=dict(kernel=4, bm=256, mt=8, pw=2))["pw"] == 2
+    assert _lib.plan(300, N, K, -1, 16, tune=dict(kernel=4, bm=128, mt=8, pw=2))["pw"] == 1
+    assert _lib.plan(300, N, K, -1, 16, tune=dict(kernel=4, bm=256, mt=4, pw=2))["pw"] == 1
+    # short-K layers keep the tiled kernel at large m (per-tile fixed costs of the panel shape weigh more there)
+    assert _lib.plan(8192, 4096, 4096, -1, 16)["kernel"] == 2
