@@ -51,7 +51,11 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
   constexpr int XPT = (XCH + NT - 1) / NT;  // chunks per thread
   constexpr int SPW = 2 / KG;            // 64-k steps (= weight loads) per wave and stage
   static_assert(PFS % XL == 0 && XL >= 2, "ring periods");
-  constexpr int NBUF = (SPW == 1) ? 2 : 3;  // LDS stage buffers (see `stage`)
+  // LDS stage buffers (see `stage`).  RELAX (64 columns per wave, PFS = 4, XL = 2): the image of a stage is written THREE stages
+  // ahead into one of four buffers, which leaves room for a barrier at the end of every OTHER stage only.
+  constexpr bool RELAX = (HW == 2) && (PFS == 4) && (XL == 2);  // (with XL = 4 the kernel would spill: 256 VGPRs)
+  constexpr int LA = RELAX ? 3 : 2;
+  constexpr int NBUF = RELAX ? 4 : (SPW == 1) ? 2 : 3;
   constexpr int EP_STRIDE = BN + 4;      // ints per row of the epilogue image (bank skew)
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -188,8 +192,8 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
   // step's half 1; while those of half 1 issue, the NEXT step's half 0 -- and refills the ring slot just emptied.
   Operands cur, nxt;
   auto stage = [&](const int i, const int u) {  // u = i % PFS as a compile-time value at every call site
-    store_x((i + 2) % NBUF, xr[(u + 2) % XL]);
-    load_x(i + 2 + XL, xr[(u + 2) % XL]);
+    store_x((i + LA) % NBUF, xr[(u + LA) % XL]);
+    load_x(i + LA + XL, xr[(u + LA) % XL]);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (HW == 2) {
       static_assert(HW == 1 || SPW == 1, "64 columns per wave: two k-groups");
@@ -227,7 +231,10 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
         if (q == 2 * MT - 1) __builtin_amdgcn_sched_group_barrier(0x020, GROUPED ? 4 : 2, 0);  // VMEM reads (ring refills)
       }
       __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();  // stage i+2 is in LDS for everybody
+      // RELAX: stage j's image is written during stage j-3 and read during stage j-1; its buffer held stage j-4, read
+      // during stage j-5: a barrier at the end of every odd stage separates each of these pairs.  (PFS even and the loop
+      // counter a multiple of PFS: the parity of i is the parity of u, a compile-time property.)
+      if (!RELAX || (u & 1)) __syncthreads();
       return;
     }
 #pragma unroll
@@ -282,13 +289,20 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
     }
 #pragma unroll
     for (int j = 2; j < 2 + XL; ++j)
-      if (j % XL >= 2) load_x(j, xr[j % XL]);
+      if (j % XL >= 2 && (!RELAX || j == 2)) load_x(j, xr[j % XL]);  // (RELAX: only stage 2 early; the ring is filled below)
     __builtin_amdgcn_sched_barrier(0);
     store_x(0, xr[0]);
     store_x(1, xr[1]);
+    if constexpr (RELAX) {  // a third stage goes straight into LDS, then the ring takes stages 3 .. 3 + XL - 1
+      if (XL < 3) load_x(2, xr[2 % XL]);
+      store_x(2, xr[2 % XL]);
 #pragma unroll
-    for (int j = 2; j < 2 + XL; ++j)
-      if (j % XL < 2) load_x(j, xr[j % XL]);
+      for (int j = LA; j < LA + XL; ++j) load_x(j, xr[j % XL]);
+    } else {
+#pragma unroll
+      for (int j = 2; j < 2 + XL; ++j)
+        if (j % XL < 2) load_x(j, xr[j % XL]);
+    }
     __syncthreads();
     {  // operands of the first step; its ring slot is refilled like any other
       const int tk0 = (KG == 2) ? kg : 0;
@@ -307,7 +321,7 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
     // Two LDS buffers: stage 0 re-fills buffer 0 (with stage 2) at its very top, and the fragment reads just above are
     // the only reads of a buffer that no stage-end barrier separates from its next write -- a wave delayed behind the
     // barrier (two workgroups sharing a CU) would otherwise read stage 2 rows for its first step.
-    if constexpr (NBUF == 2) __syncthreads();
+    if constexpr (NBUF == 2 || RELAX) __syncthreads();
     // ---- steady state: PFS stages per iteration (ring slots are compile-time registers), branch-free ----
     int i0 = 0;
     for (; i0 + PFS <= nst; i0 += PFS) {

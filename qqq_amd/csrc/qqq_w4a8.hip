@@ -201,7 +201,7 @@ static hipError_t launch_column(const LaunchArgs& a, bool grouped, int mt, int p
 template <int MT, bool GROUPED, int WN, int KG, int PFS, int XL, int HW = 1>
 static hipError_t launch_panel_t(const LaunchArgs& a, int ksplit) {
   constexpr int ROWS = 16 * MT, BN = 32 * WN * HW;
-  constexpr int XBUF = (KG == 2 ? 2 : 3) * ROWS * 128;
+  constexpr int XBUF = ((HW == 2 && PFS == 4 && XL == 2) ? 4 : KG == 2 ? 2 : 3) * ROWS * 128;
   constexpr int EP = ROWS * (BN + 4) * 4;
   constexpr int RED = (KG == 2) ? WN * MT * HW * 2048 : 0;
   constexpr int LDS = XBUF > EP ? (XBUF > RED ? XBUF : RED) : (EP > RED ? EP : RED);
@@ -223,7 +223,7 @@ static hipError_t launch_panel_t(const LaunchArgs& a, int ksplit) {
 
 template <int MT, bool GROUPED, int PFS, int XL>
 static hipError_t launch_panel_shape(const LaunchArgs& a, int bn, int waves, int cw, int ksplit) {
-  if constexpr (MT == 8 && PFS >= 3 && PFS == XL) {  // 64 columns per wave (two k-groups of 4 waves)
+  if constexpr (MT == 8 && PFS >= 3 && (PFS == XL || (PFS == 4 && XL == 2))) {  // 64 columns per wave (two k-groups of 4 waves)
     if (bn == 256 && cw == 2) return launch_panel_t<MT, GROUPED, 4, 2, PFS, XL, 2>(a, ksplit);
   }
   if (bn == 256) return launch_panel_t<MT, GROUPED, 8, 1, PFS, XL>(a, ksplit);
@@ -525,9 +525,11 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
     const bool cw2 = (t.pw == 2 && bn == 256 && mt == 8);
     pl.pf = (t.pf == 2 || t.pf == 3 || t.pf == 8) ? t.pf : (t.pf == 0 && bn == 256 && !cw2 ? 3 : 4);  // weight prefetch depth in stages
     if (pl.pf == 8 && mt > 4) pl.pf = 4;
-    pl.stages = (pl.pf == 4 && t.stages == 2) ? 2 : pl.pf;  // activation prefetch depth in stages
+    // activation prefetch depth in stages; the 64-column shape defaults to 2 (14 registers of slack: no spill with the
+    // four-buffer, barrier-every-other-stage ring; profiles/r02_panel_cw2.txt)
+    pl.stages = (pl.pf == 4 && (t.stages == 2 || (cw2 && t.stages == 0))) ? 2 : pl.pf;
     // 32-column sets per wave: 2 = 4 waves x 64 columns x 2 k-groups for the 256-column, 128-token shape
-    pl.pw = (cw2 && pl.pf >= 3 && pl.pf <= 4 && pl.stages == pl.pf) ? 2 : 1;
+    pl.pw = (cw2 && pl.pf >= 3 && pl.pf <= 4 && (pl.stages == pl.pf || (pl.pf == 4 && pl.stages == 2))) ? 2 : 1;
     pl.ksplit = ksplit;
     pl.fused = 1;
     return pl;

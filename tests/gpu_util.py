@@ -73,10 +73,10 @@ def variants(M, K, N):
             v.append(dict(kernel=4, mt=mt, ksplit=1))
         v += [dict(kernel=4), dict(kernel=4, bm=256), dict(kernel=4, waves=4), dict(kernel=4, pf=2), dict(kernel=4, bm=256, pf=2, mt=2),
               dict(kernel=4, pf=8, mt=1), dict(kernel=4, pf=3), dict(kernel=4, pf=4, stages=2, mt=4),
-              dict(kernel=4, bm=256, mt=8, pw=2), dict(kernel=4, bm=256, mt=8, pw=2, pf=3)]
+              dict(kernel=4, bm=256, mt=8, pw=2), dict(kernel=4, bm=256, mt=8, pw=2, pf=3), dict(kernel=4, bm=256, mt=8, pw=2, pf=4, stages=4)]
         if nst >= 2:
             v += [dict(kernel=4, ksplit=2), dict(kernel=4, bm=256, ksplit=2, mt=4), dict(kernel=4, waves=4, ksplit=2, pf=2),
-                  dict(kernel=4, bm=256, mt=8, pw=2, ksplit=2)]
+                  dict(kernel=4, bm=256, mt=8, pw=2, ksplit=2), dict(kernel=4, bm=256, mt=8, pw=2, stages=4, ksplit=2)]
         if nst >= 3:
             v += [dict(kernel=4, ksplit=3, mt=1), dict(kernel=4, bm=256, ksplit=3), dict(kernel=4, bm=256, mt=8, pw=2, pf=3, ksplit=3)]
     if K % 128 == 0:
