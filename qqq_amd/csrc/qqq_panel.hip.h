@@ -35,6 +35,14 @@
 // grid = (ceil(N / BN), ksplit, ceil(M / (16*MT)));  block = 64 * WN * KG;  BN = 32 * WN * HW.
 // ------------------------------------------------------------------------------------------
 
+// Which shapes run the four-buffer activation ring with a barrier after every OTHER stage (see `stage`): the 64-column shape
+// (two k-groups: every buffer is read in one stage only; ring period 4: the stage parity is a compile-time property of the
+// unrolled loop) with the 2-stage activation register ring -- with 4 stages it sits at 256 VGPRs and would spill.  The
+// 32-column shapes gain nothing from it (measured: HBM / hand-off bound) and keep the plain two-buffer ring.
+__host__ __device__ constexpr bool qqq_panel_relaxed(int KG, int PFS, int XL, int HW) {
+  return KG == 2 && HW == 2 && PFS == 4 && XL == 2;
+}
+
 template <int MT, bool GROUPED, int WN, int KG, int PFS, int XL, int HW>
 __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
     const int8_t* __restrict__ A, const unsigned char* __restrict__ B, int32_t* __restrict__ C,
@@ -51,9 +59,9 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
   constexpr int XPT = (XCH + NT - 1) / NT;  // chunks per thread
   constexpr int SPW = 2 / KG;            // 64-k steps (= weight loads) per wave and stage
   static_assert(PFS % XL == 0 && XL >= 2, "ring periods");
-  // LDS stage buffers (see `stage`).  RELAX (64 columns per wave, PFS = 4, XL = 2): the image of a stage is written THREE stages
+  // LDS stage buffers (see `stage`).  RELAX (qqq_panel_relaxed): the image of a stage is written THREE stages
   // ahead into one of four buffers, which leaves room for a barrier at the end of every OTHER stage only.
-  constexpr bool RELAX = (HW == 2) && (PFS == 4) && (XL == 2);  // (with XL = 4 the kernel would spill: 256 VGPRs)
+  constexpr bool RELAX = qqq_panel_relaxed(KG, PFS, XL, HW);
   constexpr int LA = RELAX ? 3 : 2;
   constexpr int NBUF = RELAX ? 4 : (SPW == 1) ? 2 : 3;
   constexpr int EP_STRIDE = BN + 4;      // ints per row of the epilogue image (bank skew)
@@ -270,7 +278,7 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
       __builtin_amdgcn_sched_barrier(0);
       cur = nxt;
     }
-    __syncthreads();  // stage i+2 is in LDS for everybody
+    if (!RELAX || (u & 1)) __syncthreads();  // stage i+2 is in LDS for everybody (RELAX: see the 64-column path above)
   };
 
   if (nst > 0) {

@@ -201,7 +201,7 @@ static hipError_t launch_column(const LaunchArgs& a, bool grouped, int mt, int p
 template <int MT, bool GROUPED, int WN, int KG, int PFS, int XL, int HW = 1>
 static hipError_t launch_panel_t(const LaunchArgs& a, int ksplit) {
   constexpr int ROWS = 16 * MT, BN = 32 * WN * HW;
-  constexpr int XBUF = ((HW == 2 && PFS == 4 && XL == 2) ? 4 : KG == 2 ? 2 : 3) * ROWS * 128;
+  constexpr int XBUF = (qqq_panel_relaxed(KG, PFS, XL, HW) ? 4 : KG == 2 ? 2 : 3) * ROWS * 128;
   constexpr int EP = ROWS * (BN + 4) * 4;
   constexpr int RED = (KG == 2) ? WN * MT * HW * 2048 : 0;
   constexpr int LDS = XBUF > EP ? (XBUF > RED ? XBUF : RED) : (EP > RED ? EP : RED);
