@@ -425,13 +425,14 @@ static double panel_estimate(int M, int N, int K, bool grouped, bool have_scratc
   // 64 columns per wave (bn = 256, 128-token m-blocks, per-channel): ~0.8 us per stage, workgroups of later rounds start
   // as CUs free up (no per-round launch cost), a per-workgroup fixed part that weighs more on short K slices
   // (profiles/r02_panel_cw2.txt)
-  if (!grouped && mt == 8) {
+  if (mt == 8) {  // (per-group: x1.365 per stage -- the re-quantiser fills the VALU; wins up to ~1-2 K tokens, r02_dispatch_check_g128.txt)
     const long long tl = mblocks * ((N + 255) / 256);
+    const double t2 = 0.805 * (grouped ? 1.365 : 1.0);
     for (int ks = 1; ks <= 4; ++ks) {
       if (ks > 1 && (!have_scratch || 2 * tl > cap_tickets || tl * rows * 256 * (ks - 1) > cap_rows * (long long)N || ks > NST / 4)) break;
       static const double tail[5] = {0.0, 0.0, 7.0, 9.0, 11.0};
       const double nst_k = (double)NST / ks;
-      const double wg_us = 5.0 + 100.0 / nst_k + tail[ks] + nst_k * 0.805 * (ks > 1 ? 1.04 : 1.0);
+      const double wg_us = 5.0 + 100.0 / nst_k + tail[ks] + nst_k * t2 * (ks > 1 ? 1.04 : 1.0);
       const double us = 3.7 + (double)((tl * ks + 255) / 256) * wg_us;
       if (us < best) {
         best = us;
