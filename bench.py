@@ -10,7 +10,7 @@ range, produced by the fused dynamic_quant of N(0,1) fp16 tokens) and random int
 in HBM before the timed region.  Consecutive calls use DIFFERENT 89 MB weight buffers (5 of them, 445 MB
 > the 256 MiB Infinity Cache) so that "HBM GB/s" is not an L3 number.  `value` = sum(2*M*N*K) / time.
 The timed region replays hipGraphs that hold several consecutive steps each (--steps-per-graph, default the largest
-of 10/8/5/4/2/1 that divides K; exactly K steps run): the idle gap at a replay boundary is launch plumbing, not GEMM.
+divisor of K that is <= 10; exactly K steps run): the idle gap at a replay boundary is launch plumbing, not GEMM.
 
 N > 1 (BASELINE configs[4]): same sweep, rows of every point with M >= 64*N sharded over the ranks
 (weights replicated), output shards all-gathered over RCCL/xGMI, chunk-pipelined against the GEMM
@@ -331,7 +331,7 @@ def main():
     ap.add_argument("--no-fp16", action="store_true", help="skip the torch fp16 GPU GEMM comparison")
     ap.add_argument("--detail-iters", type=int, default=100)
     ap.add_argument("--steps-per-graph", type=int, default=0,
-                    help="steps captured per hipGraph of the timed region (0 = the largest of 10/8/5/4/2/1 dividing --steps)")
+                    help="steps captured per hipGraph of the timed region (0 = the largest divisor of --steps that is <= 10)")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 PMC traffic passes; quote the committed ones")
     ap.add_argument("--check", action="store_true",
                     help="after the timed region verify the gathered outputs of the sharded points against a local full GEMM")
@@ -414,7 +414,7 @@ def main():
             g.replay()
             torch.cuda.synchronize()
             graph = g
-            spg = max(d for d in (10, 8, 5, 4, 2, 1) if args.steps % d == 0) if args.steps_per_graph <= 0 else args.steps_per_graph
+            spg = max(d for d in range(1, 11) if args.steps % d == 0) if args.steps_per_graph <= 0 else args.steps_per_graph
             if spg > 1 and args.steps % spg == 0:
                 gn = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gn):
