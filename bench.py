@@ -9,8 +9,8 @@ per-channel W4A8, M in {1,16,128,1024,4096}, N=8192, K=21760, on synthetic int8 
 range, produced by the fused dynamic_quant of N(0,1) fp16 tokens) and random int4 weights, all resident
 in HBM before the timed region.  Consecutive calls use DIFFERENT 89 MB weight buffers (5 of them, 445 MB
 > the 256 MiB Infinity Cache) so that "HBM GB/s" is not an L3 number.  `value` = sum(2*M*N*K) / time.
-The timed region replays hipGraphs that hold several consecutive steps each (--steps-per-graph, default the largest
-divisor of K that is <= 10; exactly K steps run): the idle gap at a replay boundary is launch plumbing, not GEMM.
+The timed region replays hipGraphs that hold several consecutive steps each (--steps-per-graph, default 10, plus one shorter
+graph for the remainder; exactly K steps run): the idle gap at a replay boundary is launch plumbing, not GEMM.
 
 N > 1 (BASELINE configs[4]): same sweep, rows of every point with M >= 64*N sharded over the ranks
 (weights replicated), output shards all-gathered over RCCL/xGMI, chunk-pipelined against the GEMM
@@ -331,7 +331,7 @@ def main():
     ap.add_argument("--no-fp16", action="store_true", help="skip the torch fp16 GPU GEMM comparison")
     ap.add_argument("--detail-iters", type=int, default=100)
     ap.add_argument("--steps-per-graph", type=int, default=0,
-                    help="steps captured per hipGraph of the timed region (0 = the largest divisor of --steps that is <= 10)")
+                    help="steps captured per hipGraph of the timed region (0 = 10; a shorter graph takes the remainder of --steps)")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 PMC traffic passes; quote the committed ones")
     ap.add_argument("--check", action="store_true",
                     help="after the timed region verify the gathered outputs of the sharded points against a local full GEMM")
@@ -399,7 +399,7 @@ def main():
     step_body()
     torch.cuda.synchronize()
     graph = None
-    graph_n, spg = None, 1  # a second graph holding `spg` consecutive steps: fewer replay boundaries inside the timed region
+    graph_n, graph_r, spg = None, None, 1  # graphs holding `spg` (and K % spg) consecutive steps: fewer replay boundaries in the timed region
     if world == 1:
         try:
             side = torch.cuda.Stream(device=dev)
@@ -414,15 +414,18 @@ def main():
             g.replay()
             torch.cuda.synchronize()
             graph = g
-            spg = max(d for d in range(1, 11) if args.steps % d == 0) if args.steps_per_graph <= 0 else args.steps_per_graph
-            if spg > 1 and args.steps % spg == 0:
-                gn = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gn):
-                    for _ in range(spg):
-                        step_body()
-                gn.replay()
-                torch.cuda.synchronize()
-                graph_n = gn
+            spg = min(10, args.steps) if args.steps_per_graph <= 0 else min(args.steps_per_graph, args.steps)
+            if spg > 1:
+                def capture(n):
+                    gg = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gg):
+                        for _ in range(n):
+                            step_body()
+                    gg.replay()
+                    torch.cuda.synchronize()
+                    return gg
+                graph_n = capture(spg)
+                graph_r = capture(args.steps % spg) if args.steps % spg else None
             else:
                 spg = 1
         except Exception as e:  # pragma: no cover
@@ -446,8 +449,10 @@ def main():
     barrier()
     t0 = time.perf_counter()
     if graph_n is not None:
-        for _ in range(args.steps // spg):  # EXACTLY args.steps steps: spg steps per replay
+        for _ in range(args.steps // spg):  # EXACTLY args.steps steps: spg steps per replay ...
             graph_n.replay()
+        if graph_r is not None:             # ... and the remainder in one more graph
+            graph_r.replay()
     else:
         for _ in range(args.steps):
             run_step()
