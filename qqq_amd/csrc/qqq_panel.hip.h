@@ -43,6 +43,13 @@ __host__ __device__ constexpr bool qqq_panel_relaxed(int KG, int PFS, int XL, in
   return KG == 2 && HW == 2 && PFS == 4 && XL == 2;
 }
 
+// Measurement only (tools/ablate_panel.sh, profiles/r02_panel_cw2_ablation.txt): -DQQQ_PANEL_ABLATE=<bits> removes parts of the
+// 64-column shape's steady-state loop -- 1 stage-end barrier, 2 activation staging, 4 transpose + shift/mask, 8 weight-ring
+// refill, 16 LDS fragment reads.  Results are wrong by construction; never defined in a shipped build.
+#ifndef QQQ_PANEL_ABLATE
+#define QQQ_PANEL_ABLATE 0
+#endif
+
 template <int MT, bool GROUPED, int WN, int KG, int PFS, int XL, int HW>
 __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
     const int8_t* __restrict__ A, const unsigned char* __restrict__ B, int32_t* __restrict__ C,
@@ -165,7 +172,11 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
   };
   auto unpack_w = [&](const v4u& w, const h2 sc, const bool valid, const int hf, Operands& o) {
     unsigned y[4];
-    quad_transpose4(w, y);  // y[kq] = word kq of this lane's jt
+    if constexpr (HW == 2 && (QQQ_PANEL_ABLATE & 4)) {
+      y[0] = w[0]; y[1] = w[1]; y[2] = w[2]; y[3] = w[3];
+    } else {
+      quad_transpose4(w, y);  // y[kq] = word kq of this lane's jt
+    }
     // a step past the end of K (trailing half stage) contributes nothing: `valid` is wave-uniform, so it costs a scalar
     // select on the nibble mask (per-channel) or on the group scale (scale 0 re-quantises every nibble to 0)
     if constexpr (GROUPED) {
@@ -183,8 +194,13 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
       const unsigned nm = valid ? QQQ_NIB_MASK : 0u;
 #pragma unroll
       for (int kq = 0; kq < 4; ++kq) {
-        o.a[2 * hf][kq] = (int)(y[kq] & nm);             // odd nibbles  -> 16*w4 of column n      (b = 0)
-        o.a[2 * hf + 1][kq] = (int)((y[kq] << 4) & nm);  // even nibbles -> 16*w4 of column n + 8  (b = 1)
+        if constexpr (HW == 2 && (QQQ_PANEL_ABLATE & 4)) {
+          o.a[2 * hf][kq] = (int)y[kq];
+          o.a[2 * hf + 1][kq] = (int)(y[kq] ^ nm);
+        } else {
+          o.a[2 * hf][kq] = (int)(y[kq] & nm);             // odd nibbles  -> 16*w4 of column n      (b = 0)
+          o.a[2 * hf + 1][kq] = (int)((y[kq] << 4) & nm);  // even nibbles -> 16*w4 of column n + 8  (b = 1)
+        }
       }
     }
   };
@@ -200,8 +216,10 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
   // step's half 1; while those of half 1 issue, the NEXT step's half 0 -- and refills the ring slot just emptied.
   Operands cur, nxt;
   auto stage = [&](const int i, const int u) {  // u = i % PFS as a compile-time value at every call site
-    store_x((i + LA) % NBUF, xr[(u + LA) % XL]);
-    load_x(i + LA + XL, xr[(u + LA) % XL]);
+    if constexpr (!(HW == 2 && (QQQ_PANEL_ABLATE & 2))) {
+      store_x((i + LA) % NBUF, xr[(u + LA) % XL]);
+      load_x(i + LA + XL, xr[(u + LA) % XL]);
+    }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (HW == 2) {
       static_assert(HW == 1 || SPW == 1, "64 columns per wave: two k-groups");
@@ -223,13 +241,15 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
       __builtin_amdgcn_sched_barrier(0);
       // ---- column half 1 of step i ----
       unpack_w(wr[un][0], scr[GROUPED ? un : 0][0], 2 * (st_begin + i + 1) + kg < KS, 0, cur);
-      load_w(i + PFS, 0, wr[u]);
-      if constexpr (GROUPED) load_sc(i + PFS, scr[u]);
+      if constexpr (!(QQQ_PANEL_ABLATE & 8)) {
+        load_w(i + PFS, 0, wr[u]);
+        if constexpr (GROUPED) load_sc(i + PFS, scr[u]);
+      }
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         acc[mt][2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(cur.a[2], x[mt], acc[mt][2], 0, 0, 0);
         acc[mt][3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(cur.a[3], x[mt], acc[mt][3], 0, 0, 0);
-        read_x(i + 1, kg, mt);  // the next step's fragment, in place
+        if constexpr (!(QQQ_PANEL_ABLATE & 16)) read_x(i + 1, kg, mt);  // the next step's fragment, in place
       }
 #pragma unroll
       for (int q = 0; q < 2 * MT; ++q) {
@@ -242,7 +262,8 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
       // RELAX: stage j's image is written during stage j-3 and read during stage j-1; its buffer held stage j-4, read
       // during stage j-5: a barrier at the end of every odd stage separates each of these pairs.  (PFS even and the loop
       // counter a multiple of PFS: the parity of i is the parity of u, a compile-time property.)
-      if (!RELAX || (u & 1)) __syncthreads();
+      if constexpr (!(QQQ_PANEL_ABLATE & 1))
+        if (!RELAX || (u & 1)) __syncthreads();
       return;
     }
 #pragma unroll
