@@ -1,0 +1,59 @@
+"""Static resource check of the built gfx950 code object (no GPU): which kernels carry scratch, and how many registers
+the hot instantiations take.  A register spill inside a main loop is the difference between the measured numbers in
+profiles/ and several times slower (e.g. the 4-stage activation ring of the 64-column panel shape: 304 B of scratch,
+4.5x), so a compiler or source change that introduces one should fail here, before it reaches the GPU box."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+# Instantiations known to keep a few registers in scratch, all OUTSIDE their main loop (checked in the ISA: the
+# scratch_store sits in front of the loop, the scratch_load behind it) or forced test variants the dispatcher never
+# picks on its own (the 8-deep prefetch rings of the small-m panel shapes, the 4-stage per-group 64-column ring).
+KNOWN_SCRATCH = {
+    "qqq_panel_kernel<1,false,8,1,8,8,1>", "qqq_panel_kernel<1,true,8,1,8,8,1>",
+    "qqq_panel_kernel<2,false,8,1,8,8,1>", "qqq_panel_kernel<2,true,8,1,8,8,1>",
+    "qqq_panel_kernel<8,true,4,2,3,3,2>", "qqq_panel_kernel<8,true,4,2,4,2,2>", "qqq_panel_kernel<8,true,4,2,4,4,2>",
+    "qqq_panel_kernel<8,true,8,1,4,4,1>", "qqq_tiled_kernel<256,8,1,1,true,0>",
+}
+
+
+@pytest.fixture(scope="module")
+def table():
+    import code_object
+    from qqq_amd import build
+
+    build.build()
+    return {k["demangled"]: k for k in code_object.kernels(build.LIB)}
+
+
+def test_every_family_is_in_the_code_object(table):
+    fams = {n.split("<")[0] for n in table}
+    assert {"qqq_column_kernel", "qqq_stream_kernel", "qqq_panel_kernel", "qqq_tiled_kernel", "qqq_reduce_kernel",
+            "qqq_dynamic_quant_kernel", "qqq_pack_int4_kernel", "qqq_unpack_int4_kernel"} <= fams
+
+
+def test_scratch_only_where_known(table):
+    spill = {n for n, k in table.items() if k["private_segment_fixed_size"] or k["vgpr_spill_count"] or k["sgpr_spill_count"]}
+    assert spill <= KNOWN_SCRATCH, sorted(spill - KNOWN_SCRATCH)
+    for n in spill:
+        assert table[n]["private_segment_fixed_size"] <= 128, (n, table[n])
+
+
+def test_hot_instantiations(table):
+    # the kernels behind the BASELINE sweep's bench points: per-channel decode column kernel, the M=16 stream kernel,
+    # the M=128 panel shape, the 64-column panel shape (M >= 768) and the per-group large-m tiled tile
+    x2 = table["qqq_panel_kernel<8,false,4,2,4,2,2>"]
+    assert x2["private_segment_fixed_size"] == 0 and x2["vgpr_count"] <= 256 and x2["agpr_count"] == 0  # 2 waves / SIMD
+    m128 = table["qqq_panel_kernel<8,false,4,2,4,4,1>"]
+    assert m128["private_segment_fixed_size"] == 0 and m128["vgpr_count"] <= 256
+    for n, k in table.items():
+        if n.startswith(("qqq_column_kernel", "qqq_stream_kernel", "qqq_dynamic_quant_kernel", "qqq_reduce_kernel")):
+            assert k["private_segment_fixed_size"] == 0, n
+        if n.startswith("qqq_tiled_kernel<256,") and ",false," in n:
+            assert k["private_segment_fixed_size"] == 0 and k["vgpr_count"] <= 256, n
+        # one workgroup must fit a CU: 512 registers per lane and SIMD, 8-wave workgroups -> 2 waves per SIMD
+        assert k["vgpr_count"] <= 512, n
