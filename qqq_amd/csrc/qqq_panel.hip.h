@@ -49,6 +49,24 @@ __host__ __device__ constexpr bool qqq_panel_relaxed(int KG, int PFS, int XL, in
 #ifndef QQQ_PANEL_ABLATE
 #define QQQ_PANEL_ABLATE 0
 #endif
+// Measurement only (tools/trace_panel.py, profiles/r02_panel_m128_timeline.txt): -DQQQ_PANEL_TRACE makes thread 0 of every
+// workgroup write the 100 MHz wall clock at the phase boundaries below into a buffer set through `qqq_trace_set`.
+#ifdef QQQ_PANEL_TRACE
+__device__ unsigned long long* qqq_trace_buf;
+#define QQQ_TR(i)                                                                                                       \
+  do {                                                                                                                  \
+    if (threadIdx.x == 0 && qqq_trace_buf)                                                                              \
+      qqq_trace_buf[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + (i)] = wall_clock64(); \
+  } while (0)
+#define QQQ_TRV(i, v)                                                                                                   \
+  do {                                                                                                                  \
+    if (threadIdx.x == 0 && qqq_trace_buf)                                                                              \
+      qqq_trace_buf[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + (i)] = (unsigned long long)(v); \
+  } while (0)
+#else
+#define QQQ_TR(i) do {} while (0)
+#define QQQ_TRV(i, v) do {} while (0)
+#endif
 
 template <int MT, bool GROUPED, int WN, int KG, int PFS, int XL, int HW>
 __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
@@ -78,6 +96,7 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
+  QQQ_TR(0);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave % WN;  // column set
   const int kg = wave / WN;  // k-group
@@ -351,6 +370,7 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
     // the only reads of a buffer that no stage-end barrier separates from its next write -- a wave delayed behind the
     // barrier (two workgroups sharing a CU) would otherwise read stage 2 rows for its first step.
     if constexpr (NBUF == 2 || RELAX) __syncthreads();
+    QQQ_TR(1);
     // ---- steady state: PFS stages per iteration (ring slots are compile-time registers), branch-free ----
     int i0 = 0;
     for (; i0 + PFS <= nst; i0 += PFS) {
@@ -363,6 +383,13 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
       if (i0 + u < nst) stage(i0 + u, u);
   }
   __syncthreads();
+
+  QQQ_TR(2);
+  // split-K arrival ticket: taken here, ahead of the k-group meet, so the atomic's round trip (agent scope, ~1-2 us) runs
+  // under the LDS exchange below; it is consumed where the slot is chosen
+  const int tile = mblk * gridDim.x + strip;
+  int arrival = 0;
+  if (ksplit > 1 && tid == 0) arrival = __hip_atomic_fetch_add(tickets + 2 * (size_t)tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
   // ---- k-groups meet in LDS (KG == 2).  With MT >= 2 the tile is then FINISHED BY BOTH groups: group kg keeps the
   // m-tiles [kg*MT/2, +MT/2) -- it deposits the other half in LDS, adds the partner's deposit to its own half -- so
@@ -425,20 +452,25 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
     }
   }
 
+  QQQ_TR(3);
   // ---- in-launch split-K: slot = arrival index; the last arrival folds every slot and runs the epilogue ----
   // slot image: wave wn's m-tile mt, operand q at ((wn*MT + mt)*NQ + q) KiB, lane-linear inside
-  const int tile = mblk * gridDim.x + strip;
   if (ksplit > 1) {
     int* tk = tickets + 2 * (size_t)tile;  // [0] arrivals, [1] completed deposits; both zero again on exit
-    if (tid == 0) xch = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) xch = arrival;
     __syncthreads();
-    const int t = xch;
+    const int t = __builtin_amdgcn_readfirstlane(xch);
+    QQQ_TR(4);
+    QQQ_TRV(8, t);
     const size_t slot_ints = (size_t)ROWS * BN;
     const size_t tile_ints = slot_ints * (size_t)(ksplit - 1);
     const size_t wave_ints = ((size_t)wn * MT + mb) * NQ * 256;
     if (t < ksplit - 1) {
       if (finisher) {
-        const unsigned char* sb = reinterpret_cast<const unsigned char*>(C + (size_t)tile * tile_ints + (size_t)t * slot_ints + wave_ints);
+        const unsigned long long sbv = reinterpret_cast<unsigned long long>(C + (size_t)tile * tile_ints + (size_t)t * slot_ints + wave_ints);
+        // wave-uniform by construction; pinned to SGPRs for the "s" operand of the stores below
+        const unsigned char* sb = reinterpret_cast<const unsigned char*>(
+            ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(sbv >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)sbv));
         const unsigned voff = lane * 16;
 #pragma unroll
         for (int j = 0; j < MTO; ++j)
@@ -453,6 +485,7 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       __syncthreads();  // every wave's part of the deposit has reached memory
+      QQQ_TR(5);
       if (tid == 0) __hip_atomic_fetch_add(tk + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return;
     }
@@ -460,16 +493,41 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
       for (int spin = 0; spin < (1 << 24) && __hip_atomic_load(tk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ksplit - 1; ++spin)
         __builtin_amdgcn_s_sleep(2);
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    QQQ_TR(5);
+    // No acquire fence here: at agent scope it is a `buffer_inv sc1` over the whole L2, measured at ~3 us of the finisher's
+    // critical path (tools/trace_panel.py).  The deposits are read with agent-scope atomic loads instead (`sc1`: served
+    // from the coherence point, never from a stale line of this XCD's L2), issued behind the barrier above.
     if (finisher) {
-      for (int s_ = 0; s_ < ksplit - 1; ++s_) {
-        const v4i* p = reinterpret_cast<const v4i*>(C + (size_t)tile * tile_ints + (size_t)s_ * slot_ints + wave_ints);
+      // FB slots in flight at a time: the deposits come back from the fabric (they were written through from other
+      // XCDs), one round trip each if folded slot by slot -- 3 x ~2 us at 4 slices.  The slot index of a batch's
+      // surplus loads is clamped (a valid slot, read twice), only the add is skipped.
+      constexpr int FB = (MTO * NQ <= 8) ? 3 : 1;  // 96 registers of deposits at most (the 64-column shapes sit at the register limit)
+      for (int s0 = 0; s0 < ksplit - 1; s0 += FB) {
+        v4i dep[FB][MTO][NQ];
 #pragma unroll
-        for (int j = 0; j < MTO; ++j)
+        for (int b = 0; b < FB; ++b) {
+          const int sl = min(s0 + b, ksplit - 2);
+          const unsigned long long* p = reinterpret_cast<const unsigned long long*>(C + (size_t)tile * tile_ints + (size_t)sl * slot_ints + wave_ints);
 #pragma unroll
-          for (int q = 0; q < NQ; ++q) fin[j][q] += p[(j * NQ + q) * 64 + lane];
+          for (int j = 0; j < MTO; ++j)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+              const unsigned long long lo = __hip_atomic_load(p + ((j * NQ + q) * 64 + lane) * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              const unsigned long long hi = __hip_atomic_load(p + ((j * NQ + q) * 64 + lane) * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              dep[b][j][q] = (v4i){(int)(unsigned)lo, (int)(unsigned)(lo >> 32), (int)(unsigned)hi, (int)(unsigned)(hi >> 32)};
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < FB; ++b)
+          if (s0 + b < ksplit - 1) {
+#pragma unroll
+            for (int j = 0; j < MTO; ++j)
+#pragma unroll
+              for (int q = 0; q < NQ; ++q) fin[j][q] += dep[b][j][q];
+          }
       }
     }
+    QQQ_TR(6);
     if (tid < 2) __hip_atomic_store(tk + tid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // workspace zero on return
   }
 
@@ -506,6 +564,11 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
       }
     }
   }
+#ifdef QQQ_PANEL_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  QQQ_TR(7);
+  { unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); QQQ_TRV(9, xcc & 15); }
+#endif
 }
 
 #endif  // QQQ_AMD_QQQ_PANEL_HIP_H_

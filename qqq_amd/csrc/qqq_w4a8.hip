@@ -888,3 +888,7 @@ extern "C" int qqq_unpack_int4(const void* B, void* codes, int k, int n, int gro
 extern "C" int qqq_amd_abi_version(void) { return QQQ_AMD_ABI_VERSION; }
 extern "C" const char* qqq_amd_last_error(void) { return g_err; }
 
+#ifdef QQQ_PANEL_TRACE
+// measurement builds only (see qqq_panel.hip.h): where the panel kernel's phase clocks go
+extern "C" int qqq_trace_set(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(qqq_trace_buf), &p, sizeof p); }
+#endif

@@ -16,7 +16,8 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 KNOWN_SCRATCH = {
     "qqq_panel_kernel<1,false,8,1,8,8,1>", "qqq_panel_kernel<1,true,8,1,8,8,1>",
     "qqq_panel_kernel<2,false,8,1,8,8,1>", "qqq_panel_kernel<2,true,8,1,8,8,1>",
-    "qqq_panel_kernel<8,true,4,2,3,3,2>", "qqq_panel_kernel<8,true,4,2,4,2,2>", "qqq_panel_kernel<8,true,4,2,4,4,2>",
+    "qqq_panel_kernel<8,false,4,2,3,3,2>", "qqq_panel_kernel<8,true,4,2,3,3,2>", "qqq_panel_kernel<8,true,4,2,4,2,2>",
+    "qqq_panel_kernel<8,true,4,2,4,4,2>",
     "qqq_panel_kernel<8,true,8,1,4,4,1>", "qqq_tiled_kernel<256,8,1,1,true,0>",
 }
 
