@@ -147,4 +147,17 @@ __device__ __forceinline__ void unpack_pair(const unsigned q, const h2 s_b0, con
 }
 
 
+// 16-byte load with agent-scope coherence (`sc1`: served from the coherence point, never from a stale line of this XCD's L2)
+// through a raw buffer descriptor over a wave-uniform base -- the compiler tracks it like any load (an inline-asm
+// `global_load_dwordx4 ... sc1` would not be), and it stands in for an agent-scope acquire fence, which on this part is a
+// `buffer_inv sc1` over the whole L2 (~3 us, and it throws out the operand lines of every other workgroup on the XCD).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t agent_view(const void* base_uniform) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base_uniform), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ v4i load16_agent(__amdgpu_buffer_rsrc_t view, const unsigned byte_offset) {
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  const u4 v = __builtin_amdgcn_raw_buffer_load_b128(view, byte_offset, 0, /*sc1*/ 16);
+  return (v4i){(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+}
+
 #endif  // QQQ_AMD_QQQ_COMMON_HIP_H_

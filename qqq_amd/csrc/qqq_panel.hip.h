@@ -389,7 +389,10 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
   // under the LDS exchange below; it is consumed where the slot is chosen
   const int tile = mblk * gridDim.x + strip;
   int arrival = 0;
-  if (ksplit > 1 && tid == 0) arrival = __hip_atomic_fetch_add(tickets + 2 * (size_t)tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // (not for the 64-column shapes: with the ticket's register live across the meet hipcc schedules their main loop ~2 % slower
+  //  at M=4096 -- measured, four builds side by side -- and they run with 1-2 slices, where the ticket is a small part)
+  constexpr bool HOIST = (HW == 1);
+  if (HOIST && ksplit > 1 && tid == 0) arrival = __hip_atomic_fetch_add(tickets + 2 * (size_t)tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
   // ---- k-groups meet in LDS (KG == 2).  With MT >= 2 the tile is then FINISHED BY BOTH groups: group kg keeps the
   // m-tiles [kg*MT/2, +MT/2) -- it deposits the other half in LDS, adds the partner's deposit to its own half -- so
@@ -457,7 +460,7 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
   // slot image: wave wn's m-tile mt, operand q at ((wn*MT + mt)*NQ + q) KiB, lane-linear inside
   if (ksplit > 1) {
     int* tk = tickets + 2 * (size_t)tile;  // [0] arrivals, [1] completed deposits; both zero again on exit
-    if (tid == 0) xch = arrival;
+    if (tid == 0) xch = HOIST ? arrival : __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     const int t = __builtin_amdgcn_readfirstlane(xch);
     QQQ_TR(4);
@@ -495,8 +498,8 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
     __syncthreads();
     QQQ_TR(5);
     // No acquire fence here: at agent scope it is a `buffer_inv sc1` over the whole L2, measured at ~3 us of the finisher's
-    // critical path (tools/trace_panel.py).  The deposits are read with agent-scope atomic loads instead (`sc1`: served
-    // from the coherence point, never from a stale line of this XCD's L2), issued behind the barrier above.
+    // critical path (tools/trace_panel.py).  The deposits are read with agent-scope loads instead (`load16_agent`, sc1),
+    // issued behind the barrier above.
     if (finisher) {
       // FB slots in flight at a time: the deposits come back from the fabric (they were written through from other
       // XCDs), one round trip each if folded slot by slot -- 3 x ~2 us at 4 slices.  The slot index of a batch's
@@ -507,15 +510,11 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
 #pragma unroll
         for (int b = 0; b < FB; ++b) {
           const int sl = min(s0 + b, ksplit - 2);
-          const unsigned long long* p = reinterpret_cast<const unsigned long long*>(C + (size_t)tile * tile_ints + (size_t)sl * slot_ints + wave_ints);
+          const __amdgpu_buffer_rsrc_t view = agent_view(C + (size_t)tile * tile_ints + (size_t)sl * slot_ints + wave_ints);
 #pragma unroll
           for (int j = 0; j < MTO; ++j)
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-              const unsigned long long lo = __hip_atomic_load(p + ((j * NQ + q) * 64 + lane) * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              const unsigned long long hi = __hip_atomic_load(p + ((j * NQ + q) * 64 + lane) * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              dep[b][j][q] = (v4i){(int)(unsigned)lo, (int)(unsigned)(lo >> 32), (int)(unsigned)hi, (int)(unsigned)(hi >> 32)};
-            }
+            for (int q = 0; q < NQ; ++q) dep[b][j][q] = load16_agent(view, (unsigned)((j * NQ + q) * 1024 + lane * 16));
         }
 #pragma unroll
         for (int b = 0; b < FB; ++b)
@@ -546,10 +545,14 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
           ep[(16 * (mb + jm) + j) * EP_STRIDE + 64 * gl + 16 * r + 8 * (q & 1) + 4 * (half + (q >> 1)) + cp] = fin[jm][q][r];
   }
   __syncthreads();
-  for (int it = tid; it < ROWS * (BN / 8); it += NT) {
+  // (unrolled: the s1 / s2 loads of every pass are issued together -- pass by pass each paid its own round trip, ~0.7 us)
+  constexpr int EP_ITEMS = ROWS * (BN / 8), EP_PASSES = (EP_ITEMS + NT - 1) / NT;
+#pragma unroll
+  for (int ps = 0; ps < EP_PASSES; ++ps) {
+    const int it = tid + ps * NT;
     const int row = it / (BN / 8), c8 = it % (BN / 8);
     const int m = mbase + row, n = strip * BN + c8 * 8;
-    if (m < M && n < N) {
+    if (it < EP_ITEMS && m < M && n < N) {
       const v4i lo = *reinterpret_cast<const v4i*>(ep + row * EP_STRIDE + c8 * 8);
       const v4i hi4 = *reinterpret_cast<const v4i*>(ep + row * EP_STRIDE + c8 * 8 + 4);
       const float a_s = s1[m];

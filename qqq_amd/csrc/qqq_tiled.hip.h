@@ -561,7 +561,7 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * (2 / NB) * 64) void 
   // and leaves; the last arrival adds every slot to its accumulators and runs the normal epilogue.
   // Whoever is waited for has already arrived (is past its main loop), so the spins are short and cannot
   // deadlock whatever the dispatch order.  Slot images are lane-linear (16 B per lane, full lines); they
-  // are written through (sc0 sc1) and read behind an agent-scope acquire, because the K slices of a tile
+  // are written through (sc0 sc1) and read with agent-scope (sc1) loads, because the K slices of a tile
   // run on different XCDs (= different, mutually non-coherent L2s).  int32 adds commute: bit-exact.
   // tickets[(1 + nslots) * tile + {0: arrivals, 1 + s: deposits completed in slot s}], all zero again on exit.
   bool finish = (ksplit == 1);
@@ -581,11 +581,10 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * (2 / NB) * 64) void 
       if (tid == 0)
         while (__hip_atomic_load(tk + 1 + s_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want)
           __builtin_amdgcn_s_sleep(4);
-      __syncthreads();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __syncthreads();  // no acquire fence (an L2-wide invalidate at agent scope): add_slot reads with agent-scope loads
     };
     auto add_slot = [&](const int s_) {
-      const unsigned char* p = slot_base(s_);
+      const __amdgpu_buffer_rsrc_t view = agent_view(slot_base(s_));
 #pragma unroll
       for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
@@ -594,7 +593,7 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * (2 / NB) * 64) void 
           for (int bi = 0; bi < NB; ++bi)
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
-              const v4i v = *reinterpret_cast<const v4i*>(p + (((mt * JW + jj) * NB + bi) * 4 + gq) * 1024 + (size_t)voff);
+              const v4i v = load16_agent(view, (unsigned)((((mt * JW + jj) * NB + bi) * 4 + gq) * 1024) + voff);
 #pragma unroll
               for (int r = 0; r < 4; ++r) acc[mt][jj][bi][4 * gq + r] += v[r];
             }
