@@ -390,15 +390,17 @@ static double stream_estimate(int M, int N, int K, bool grouped) {
   double per_block = (double)N * K / 2.0 / 5.0e6;  // the weight matrix at ~5 TB/s
   if (per_block < 2.5) per_block = 2.5;
   const int mblocks = (M + 63) / 64;
-  // measured: 1 / 2 / 3 / 4 m-blocks take 1.15 / 1.95 / 3.0 / 3.3 weight passes, plus ~2 us of fixed work per m-block
-  const double passes = (mblocks == 1) ? 1.15 : (mblocks == 2) ? 1.95 : (mblocks == 3) ? 3.0 : 3.3 + 0.8 * (mblocks - 4);
+  // measured: 2 / 3 / 4 m-blocks take 1.95 / 3.0 / 3.3 weight passes, plus ~2 us of fixed work per m-block
+  // (one m-block: 16 / 32 / 48 / 64 tokens measured at 0.6 / 0.8 / 1.0 / 1.2 -- the 16-token tiles of a block share the weights
+  //  in registers but not the MFMA / VALU time)
+  const double passes = (mblocks == 1) ? 0.4 + 0.0125 * M : (mblocks == 2) ? 1.95 : (mblocks == 3) ? 3.0 : 3.3 + 0.8 * (mblocks - 4);
   const double us = 9.0 + per_block * passes + 2.0 * mblocks;
   return grouped ? us * 1.15 : us;
 }
 
 // panel: 128-token m-blocks x bn-column strips x K slices; one workgroup per CU and round (mt = 8); measured ~0.47 us
 // per 128-k stage (bn = 128, per-channel), twice that for bn = 256, x1.45 per-group; ~9 us of launch / pipeline fill /
-// epilogue and 7..11 us for the in-launch split-K hand-off (deposit, ticket, fold by the last arrival)
+// epilogue and 5..8.5 us for the in-launch split-K hand-off (deposit, ticket, fold by the last arrival)
 static double panel_estimate(int M, int N, int K, bool grouped, bool have_scratch, long long cap_rows, long long cap_tickets,
                              int* bn_out, int* ks_out, int* cw_out) {
   const int mt = (M <= 16) ? 1 : (M <= 32) ? 2 : (M <= 64) ? 4 : 8;
@@ -408,10 +410,10 @@ static double panel_estimate(int M, int N, int K, bool grouped, bool have_scratc
   double best = 1e30;
   for (int bn = 128; bn <= 256; bn *= 2) {
     const long long tl = mblocks * ((N + bn - 1) / bn);
-    const double t_stage = ((mt == 8 && bn == 128) ? 0.506 : 0.13 + 0.042 * mt) * (bn == 256 ? 1.9 : 1.0) * (grouped ? 1.45 : 1.0);
+    const double t_stage = ((mt == 8 && bn == 128) ? 0.506 : 0.13 + 0.042 * mt) * (bn == 256 ? 1.9 : 1.0) * (grouped ? (mt == 8 ? 1.45 : 1.6) : 1.0);
     for (int ks = 1; ks <= 4; ++ks) {
       if (ks > 1 && (!have_scratch || 2 * tl > cap_tickets || tl * rows * bn * (ks - 1) > cap_rows * (long long)N || ks > NST / 4)) break;  // slots: tiles x (ks-1) x rows x bn ints inside C
-      static const double tail[5] = {0.0, 0.0, 7.0, 9.0, 11.0};
+      static const double tail[5] = {0.0, 0.0, 5.0, 6.5, 8.5};  // (fold by sc1 loads, no acquire fence: profiles/r02_panel_handoff.txt)
       const double wg_us = 8.7 + tail[ks] + ((double)NST / ks) * t_stage;
       const double us = (double)((tl * ks + 255) / 256) * wg_us;
       if (us < best) {
@@ -567,6 +569,8 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
       // one workgroup per CU: (strips x m-blocks x K-slices) ~ 256, at least 2 steps per wave
       const long long base = (long long)strips * mblocks;
       ksplit = (int)((256 + base / 2) / base);
+      // 8-wave bodies run one workgroup per CU: a 257th workgroup is a second round (n = 11008: 86 strips x 3 slices)
+      if (mt >= 2 && ksplit > 1 && base * ksplit > 256) --ksplit;
       ksplit = clampi(ksplit, 1, KS / (2 * waves) > 0 ? KS / (2 * waves) : 1);
     }
     ksplit = clampi(ksplit, 1, KS);
