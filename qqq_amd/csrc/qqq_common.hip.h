@@ -46,6 +46,17 @@ __device__ __forceinline__ h4 epilogue_vals4(const int v0, const int v1, const i
   return o;
 }
 
+// the same with the two scale pairs already in registers (loaded ahead of a wait)
+__device__ __forceinline__ h4 epilogue_vals4(const int v0, const int v1, const int v2, const int v3, const float a_s,
+                                             const float2 sa, const float2 sb) {
+  h4 o;
+  o[0] = (_Float16)__fmul_rn(__fmul_rn((float)v0, sa.x), a_s);
+  o[1] = (_Float16)__fmul_rn(__fmul_rn((float)v1, sa.y), a_s);
+  o[2] = (_Float16)__fmul_rn(__fmul_rn((float)v2, sb.x), a_s);
+  o[3] = (_Float16)__fmul_rn(__fmul_rn((float)v3, sb.y), a_s);
+  return o;
+}
+
 // ... stored straight from the lane; `bias` (may be null) is added in fp16 AFTER the fp16 round, exactly
 // like the reference's separate `D + self.bias` (qlinear_marlin.py:287).
 __device__ __forceinline__ void epilogue_store4(const int v0, const int v1, const int v2,

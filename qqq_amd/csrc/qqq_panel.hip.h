@@ -456,6 +456,27 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
   }
 
   QQQ_TR(3);
+  // ---- epilogue scales, fetched ahead of the split-K hand-off (32-column shapes: registers to spare): one round trip
+  // less behind the fold.  NT is a multiple of BN / 8, so a thread's 8 columns are the same in every pass.
+  constexpr int EP_ITEMS = ROWS * (BN / 8), EP_PASSES = (EP_ITEMS + NT - 1) / NT;
+  constexpr bool EP_PRE = (HW == 1) && (NT % (BN / 8) == 0);
+  float a_pre[EP_PRE ? EP_PASSES : 1];
+  float2 s2_pre[4];
+  if constexpr (EP_PRE) {
+    const int n = strip * BN + (tid % (BN / 8)) * 8;
+    const int nc = (n < N) ? n : 0;
+    const int i0 = s2_stored_index(nc), i1 = s2_stored_index(nc + 4);
+    s2_pre[0] = *reinterpret_cast<const float2*>(s2 + i0);
+    s2_pre[1] = *reinterpret_cast<const float2*>(s2 + i0 + 8);
+    s2_pre[2] = *reinterpret_cast<const float2*>(s2 + i1);
+    s2_pre[3] = *reinterpret_cast<const float2*>(s2 + i1 + 8);
+#pragma unroll
+    for (int ps = 0; ps < EP_PASSES; ++ps) {
+      const int m = mbase + (tid + ps * NT) / (BN / 8);
+      a_pre[ps] = s1[m < M ? m : M - 1];
+    }
+  }
+
   // ---- in-launch split-K: slot = arrival index; the last arrival folds every slot and runs the epilogue ----
   // slot image: wave wn's m-tile mt, operand q at ((wn*MT + mt)*NQ + q) KiB, lane-linear inside
   if (ksplit > 1) {
@@ -546,7 +567,6 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
   }
   __syncthreads();
   // (unrolled: the s1 / s2 loads of every pass are issued together -- pass by pass each paid its own round trip, ~0.7 us)
-  constexpr int EP_ITEMS = ROWS * (BN / 8), EP_PASSES = (EP_ITEMS + NT - 1) / NT;
 #pragma unroll
   for (int ps = 0; ps < EP_PASSES; ++ps) {
     const int it = tid + ps * NT;
@@ -555,9 +575,15 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
     if (it < EP_ITEMS && m < M && n < N) {
       const v4i lo = *reinterpret_cast<const v4i*>(ep + row * EP_STRIDE + c8 * 8);
       const v4i hi4 = *reinterpret_cast<const v4i*>(ep + row * EP_STRIDE + c8 * 8 + 4);
-      const float a_s = s1[m];
-      const h4 o0 = epilogue_vals4(lo[0], lo[1], lo[2], lo[3], n, a_s, s2);
-      const h4 o1 = epilogue_vals4(hi4[0], hi4[1], hi4[2], hi4[3], n + 4, a_s, s2);
+      h4 o0, o1;
+      if constexpr (EP_PRE) {
+        o0 = epilogue_vals4(lo[0], lo[1], lo[2], lo[3], a_pre[ps], s2_pre[0], s2_pre[1]);
+        o1 = epilogue_vals4(hi4[0], hi4[1], hi4[2], hi4[3], a_pre[ps], s2_pre[2], s2_pre[3]);
+      } else {
+        const float a_s = s1[m];
+        o0 = epilogue_vals4(lo[0], lo[1], lo[2], lo[3], n, a_s, s2);
+        o1 = epilogue_vals4(hi4[0], hi4[1], hi4[2], hi4[3], n + 4, a_s, s2);
+      }
       h8 o = {o0[0], o0[1], o0[2], o0[3], o1[0], o1[1], o1[2], o1[3]};
       if (bias) o = o + *reinterpret_cast<const h8*>(bias + n);  // fp16 add after the fp16 round
       *reinterpret_cast<h8*>(D + (size_t)m * N + n) = o;

@@ -1,10 +1,8 @@
 timeout 600 python -m pytest tests -m gpu -x -q > gpurun_out/b_tests.log 2>&1; echo "tests rc=$?" >> gpurun_out/b_tests.log
 tail -3 gpurun_out/b_tests.log
-timeout 600 python bench.py > gpurun_out/bench_new.json 2> gpurun_out/bench_new.err; tail -c 600 gpurun_out/bench_new.err
-python - <<'PY'
-import json
-d=json.loads(open('gpurun_out/bench_new.json').read().strip().splitlines()[-1])
-print(d['value'], d['ms_per_step'], d['roofline']['frac'])
-for k,v in d['per_m'].items(): print(k, round(v['us'],1), v['kernel'], v['ksplit'], round(v['roof_frac'],3))
-for k,v in d['per_m_g128'].items(): print('g',k, round(v['us'],1))
-PY
+QQQ_AMD_LIB=qqq_amd/libtrace.so MS=128 timeout 300 python tools/trace_panel.py 2>&1 | grep -v amdgpu.ids > gpurun_out/trace_pc4.log
+grep "finisher:\|launches" gpurun_out/trace_pc4.log
+NBUF=4 MODE=pc LIBS=qqq_amd/libbase2.so,qqq_amd/libqqq_amd.so ROUNDS=6 ITERS=4 MS=64,128,256,512 timeout 300 python tools/ab.py 2>&1 | grep -v amdgpu.ids > gpurun_out/b_ab_pc.log
+cat gpurun_out/b_ab_pc.log
+NBUF=4 MODE=pc LIBS=qqq_amd/libqqq_amd.so ROUNDS=5 ITERS=6 MS=16,32 TUNES="[None,dict(kernel=4,mt=1),dict(kernel=4,mt=1,pf=8),dict(kernel=4,mt=1,bm=256),dict(kernel=4,mt=2),dict(kernel=4,mt=2,pf=8),dict(kernel=4,mt=2,bm=256),dict(kernel=4,mt=1,ksplit=3),dict(kernel=4,mt=2,ksplit=3)]" timeout 300 python tools/ab.py 2>&1 | grep -v amdgpu.ids > gpurun_out/b_ab_m16.log
+cat gpurun_out/b_ab_m16.log
