@@ -191,7 +191,7 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
   };
   auto unpack_w = [&](const v4u& w, const h2 sc, const bool valid, const int hf, Operands& o) {
     unsigned y[4];
-    if constexpr (HW == 2 && (QQQ_PANEL_ABLATE & 4)) {
+    if constexpr ((QQQ_PANEL_ABLATE & 4) != 0) {
       y[0] = w[0]; y[1] = w[1]; y[2] = w[2]; y[3] = w[3];
     } else {
       quad_transpose4(w, y);  // y[kq] = word kq of this lane's jt
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
       const unsigned nm = valid ? QQQ_NIB_MASK : 0u;
 #pragma unroll
       for (int kq = 0; kq < 4; ++kq) {
-        if constexpr (HW == 2 && (QQQ_PANEL_ABLATE & 4)) {
+        if constexpr ((QQQ_PANEL_ABLATE & 4) != 0) {
           o.a[2 * hf][kq] = (int)y[kq];
           o.a[2 * hf + 1][kq] = (int)(y[kq] ^ nm);
         } else {
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
   // step's half 1; while those of half 1 issue, the NEXT step's half 0 -- and refills the ring slot just emptied.
   Operands cur, nxt;
   auto stage = [&](const int i, const int u) {  // u = i % PFS as a compile-time value at every call site
-    if constexpr (!(HW == 2 && (QQQ_PANEL_ABLATE & 2))) {
+    if constexpr (!(QQQ_PANEL_ABLATE & 2)) {
       store_x((i + LA) % NBUF, xr[(u + LA) % XL]);
       load_x(i + LA + XL, xr[(u + LA) % XL]);
     }
@@ -294,15 +294,17 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
 #pragma unroll
       for (int hf = 0; hf < HW; ++hf)
         unpack_w(wr[nu * SPW + nt][hf], scr[GROUPED ? nu : 0][hf], 2 * (st_begin + ni) + ntk < KS, hf, nxt);
-      load_w(ni + PFS, nt, wr[nu * SPW + nt]);
-      if constexpr (GROUPED)
-        if (nt == SPW - 1) load_sc(ni + PFS, scr[nu]);
+      if constexpr (!(QQQ_PANEL_ABLATE & 8)) {
+        load_w(ni + PFS, nt, wr[nu * SPW + nt]);
+        if constexpr (GROUPED)
+          if (nt == SPW - 1) load_sc(ni + PFS, scr[nu]);
+      }
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
         for (int q = 0; q < 2 * HW; ++q)
           acc[mt][q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(cur.a[q], x[mt], acc[mt][q], 0, 0, 0);
-        read_x(ni, ntk, mt);  // the next step's fragment, in place
+        if constexpr (!(QQQ_PANEL_ABLATE & 16)) read_x(ni, ntk, mt);  // the next step's fragment, in place
       }
       // issue order inside this region: 1 MFMA, then its share of the VALU / LDS-read / VMEM work
       constexpr int NVALU = (GROUPED ? 68 : 14) * HW;  // compiler-visible VALU of one step's unpack (the transpose is an asm block)
@@ -318,7 +320,8 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
       __builtin_amdgcn_sched_barrier(0);
       cur = nxt;
     }
-    if (!RELAX || (u & 1)) __syncthreads();  // stage i+2 is in LDS for everybody (RELAX: see the 64-column path above)
+    if constexpr (!(QQQ_PANEL_ABLATE & 1))
+      if (!RELAX || (u & 1)) __syncthreads();  // stage i+2 is in LDS for everybody (RELAX: see the 64-column path above)
   };
 
   if (nst > 0) {

@@ -528,9 +528,10 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
     const bool cw2 = (t.pw == 2 && bn == 256 && mt == 8);
     pl.pf = (t.pf == 2 || t.pf == 3 || t.pf == 8) ? t.pf : (t.pf == 0 && bn == 256 && !cw2 ? 3 : 4);  // weight prefetch depth in stages
     if (pl.pf == 8 && mt > 4) pl.pf = 4;
-    // activation prefetch depth in stages; the 64-column shape defaults to 2 (14 registers of slack: no spill with the
-    // four-buffer, barrier-every-other-stage ring; profiles/r02_panel_cw2.txt)
-    pl.stages = (pl.pf == 4 && (t.stages == 2 || (cw2 && t.stages == 0))) ? 2 : pl.pf;
+    // activation prefetch depth in stages: 2 with the 4-deep weight ring (the 64-column shape: 14 registers of slack, no spill
+    // with the four-buffer, barrier-every-other-stage ring, profiles/r02_panel_cw2.txt; the 32-column shapes: 1-4 % faster than
+    // depth 4 on every shape measured, profiles/r02_panel_prefetch_depth.txt)
+    pl.stages = (pl.pf == 4 && t.stages != 4) ? 2 : pl.pf;
     // 32-column sets per wave: 2 = 4 waves x 64 columns x 2 k-groups for the 256-column, 128-token shape
     pl.pw = (cw2 && pl.pf >= 3 && pl.pf <= 4 && (pl.stages == pl.pf || (pl.pf == 4 && pl.stages == 2))) ? 2 : 1;
     pl.ksplit = ksplit;
