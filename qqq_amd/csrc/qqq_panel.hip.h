@@ -38,7 +38,8 @@
 // Which shapes run the four-buffer activation ring with a barrier after every OTHER stage (see `stage`): the 64-column shape
 // (two k-groups: every buffer is read in one stage only; ring period 4: the stage parity is a compile-time property of the
 // unrolled loop) with the 2-stage activation register ring -- with 4 stages it sits at 256 VGPRs and would spill.  The
-// 32-column shapes gain nothing from it (measured: HBM / hand-off bound) and keep the plain two-buffer ring.
+// 32-column shapes gain nothing from it (measured twice, the second time with the cheaper hand-off and the 2-deep activation
+// ring: M = 96-128 1-3 % SLOWER, the extra prologue stage outweighs the barriers saved) and keep the plain two-buffer ring.
 __host__ __device__ constexpr bool qqq_panel_relaxed(int KG, int PFS, int XL, int HW) {
   return KG == 2 && HW == 2 && PFS == 4 && XL == 2;
 }

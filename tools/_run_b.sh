@@ -1,10 +1,6 @@
-timeout 600 python -m pytest tests -m gpu -x -q > gpurun_out/b_tests.log 2>&1; echo "tests rc=$?" >> gpurun_out/b_tests.log
-tail -3 gpurun_out/b_tests.log
-timeout 600 python bench.py --no-cpu > gpurun_out/bench_new.json 2> gpurun_out/bench_new.err
-python - <<'PY'
-import json
-d=json.loads(open('gpurun_out/bench_new.json').read().strip().splitlines()[-1])
-print(d['value'], d['ms_per_step'], d['roofline']['frac'])
-for k,v in d['per_m'].items(): print(k, round(v['us'],1), v['kernel'], v['ksplit'], round(v['roof_frac'],3))
-for k,v in d['per_m_g128'].items(): print('g',k, round(v['us'],1))
-PY
+QQQ_AMD_LIB=qqq_amd/librelax.so timeout 300 python -m pytest tests/test_gpu_parity.py -x -q -k "golden or baseline or stress or splitk or load" 2>&1 | tail -3
+for mode in pc g128; do
+NBUF=4 MODE=$mode LIBS=qqq_amd/libqqq_amd.so,qqq_amd/librelax.so ROUNDS=6 ITERS=4 MS=64,96,128,192 python tools/ab.py 2>&1 | grep -v amdgpu.ids
+done
+NK=4096,4096 NBUF=8 MODE=pc LIBS=qqq_amd/libqqq_amd.so,qqq_amd/librelax.so ROUNDS=6 ITERS=4 MS=256,512,1024 python tools/ab.py 2>&1 | grep -v amdgpu.ids
+NK=4096,11008 NBUF=8 MODE=pc LIBS=qqq_amd/libqqq_amd.so,qqq_amd/librelax.so ROUNDS=6 ITERS=4 MS=256,512,1024 python tools/ab.py 2>&1 | grep -v amdgpu.ids
