@@ -224,9 +224,12 @@ __global__ __launch_bounds__(WAVES * 64) void qqq_stream_kernel(
 
   // in-launch reduction by the last-arriving workgroup of this (strip, m-block) tile:
   // (fused == 1) plain stores -> agent-scope release -> ticket, or (fused == 2) write-through stores ->
-  // drained -> ticket; then one agent-scope acquire in the last arriver (placement independent).
+  // drained -> ticket; the last arriver folds the slabs (placement independent).
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  // The last arriver reads the slabs with agent-scope sc1 loads (load16_agent: 32-bit offsets inside one slab) -- the
+  // acquire fence it replaces is an invalidate of the XCD's whole L2, ~3 us; slabs beyond 2 GB keep the fence.
+  const bool wide = (size_t)M * N * 4 >= 0x7fffffffull;
   int* flag = &red[NQ * 4 * 64];
   if (tid == 0) {
     if (fused == 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(WAVES * 64) void qqq_stream_kernel(
     const int t = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int last = (t == ksplit - 1);
     if (last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      if (wide) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // workspace zero on return
     }
     *flag = last;
@@ -247,8 +250,20 @@ __global__ __launch_bounds__(WAVES * 64) void qqq_stream_kernel(
     item_coords(it, m, n);
     if (m < M && n < N) {
       v4i sum = {0, 0, 0, 0};
-      for (int p = 0; p < ksplit; ++p)
-        sum += *reinterpret_cast<const v4i*>(C + ((size_t)p * M + m) * N + n);
+      if (!wide) {
+        const unsigned off = ((unsigned)m * (unsigned)N + (unsigned)n) * 4u;
+        for (int p0 = 0; p0 < ksplit; p0 += 4) {  // four slabs in flight; surplus loads re-read the last slab, only the add is skipped
+          v4i d[4];
+#pragma unroll
+          for (int b = 0; b < 4; ++b) d[b] = load16_agent(agent_view(C + (size_t)min(p0 + b, ksplit - 1) * M * N), off);
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+            if (p0 + b < ksplit) sum += d[b];
+        }
+      } else {
+        for (int p = 0; p < ksplit; ++p)
+          sum += *reinterpret_cast<const v4i*>(C + ((size_t)p * M + m) * N + n);
+      }
       epilogue_store4(sum[0], sum[1], sum[2], sum[3], m, n, N, s1[m], s2, D, acc_out, bias);
     }
   }
