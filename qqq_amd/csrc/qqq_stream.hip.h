@@ -229,7 +229,8 @@ __global__ __launch_bounds__(WAVES * 64) void qqq_stream_kernel(
   __syncthreads();
   // The last arriver reads the slabs with agent-scope sc1 loads (load16_agent: 32-bit offsets inside one slab) -- the
   // acquire fence it replaces is an invalidate of the XCD's whole L2, ~3 us; slabs beyond 2 GB keep the fence.
-  const bool wide = (size_t)M * N * 4 >= 0x7fffffffull;
+  // (fused == 1 publishes with plain stores + a release fence: sc1 loads stand in for the acquire only behind sc1 stores)
+  const bool wide = fused == 1 || (size_t)M * N * 4 >= 0x7fffffffull;
   int* flag = &red[NQ * 4 * 64];
   if (tid == 0) {
     if (fused == 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
