@@ -172,5 +172,18 @@ def test_dispatch_of_the_baseline_sweep(L):
     assert _lib.plan(300, N, K, -1, 16, tune=dict(kernel=4, bm=256, mt=8, pw=2))["pw"] == 2
     assert _lib.plan(300, N, K, -1, 16, tune=dict(kernel=4, bm=128, mt=8, pw=2))["pw"] == 1
     assert _lib.plan(300, N, K, -1, 16, tune=dict(kernel=4, bm=256, mt=4, pw=2))["pw"] == 1
+    # 48 / 64 tokens (profiles/r02_dispatch_check_handoff.txt): per-channel the panel kernel takes over at 64 (29.0 vs 32.6 us),
+    # the stream kernel keeps 48 (28.7 vs 30.4) and the per-group mode up to 64 (33.9 vs 36.9)
+    assert _lib.plan(48, N, K, -1, 16)["kernel"] == 1 and _lib.plan(64, N, K, -1, 16)["kernel"] == 4
+    assert _lib.plan(64, N, K, 128, 16)["kernel"] == 1
+    # the panel kernel's 32-column shapes stage activations 2 stages ahead under the 4-deep weight ring
+    p = _lib.plan(128, N, K, -1, 16)
+    assert (p["pf"], p["stages"]) == (4, 2)
+    assert _lib.plan(128, N, K, -1, 16, tune=dict(kernel=4, stages=4))["stages"] == 4
+    # the stream kernel never asks for a 257th workgroup (one 8-wave workgroup per CU): 86 strips x 3 slices -> 2 slices
+    p = _lib.plan(64, 11008, 4096, -1, 16)
+    assert p["kernel"] == 1 and p["ksplit"] == 2
+    p = _lib.plan(192, 4096, 4096, -1, 16, tune=dict(kernel=1))
+    assert p["ksplit"] * 3 * 32 <= 256
     # short-K layers keep the tiled kernel at large m (per-tile fixed costs of the panel shape weigh more there)
     assert _lib.plan(8192, 4096, 4096, -1, 16)["kernel"] == 2
