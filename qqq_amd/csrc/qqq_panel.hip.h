@@ -45,12 +45,12 @@ __host__ __device__ constexpr bool qqq_panel_relaxed(int KG, int PFS, int XL, in
 }
 
 // Measurement only (tools/ablate_panel.sh, profiles/r02_panel_cw2_ablation.txt): -DQQQ_PANEL_ABLATE=<bits> removes parts of the
-// 64-column shape's steady-state loop -- 1 stage-end barrier, 2 activation staging, 4 transpose + shift/mask, 8 weight-ring
+// steady-state loop (either shape; profiles/r02_panel_prefetch_depth.txt has the 32-column one) -- 1 stage-end barrier, 2 activation staging, 4 transpose + shift/mask, 8 weight-ring
 // refill, 16 LDS fragment reads.  Results are wrong by construction; never defined in a shipped build.
 #ifndef QQQ_PANEL_ABLATE
 #define QQQ_PANEL_ABLATE 0
 #endif
-// Measurement only (tools/trace_panel.py, profiles/r02_panel_m128_timeline.txt): -DQQQ_PANEL_TRACE makes thread 0 of every
+// Measurement only (tools/trace_panel.py, profiles/r02_panel_timeline.txt): -DQQQ_PANEL_TRACE makes thread 0 of every
 // workgroup write the 100 MHz wall clock at the phase boundaries below into a buffer set through `qqq_trace_set`.
 #ifdef QQQ_PANEL_TRACE
 __device__ unsigned long long* qqq_trace_buf;
