@@ -1,7 +1,7 @@
-"""Lane-level numpy model of the two HIP kernels' data movement (tests only).
+"""Lane-level numpy model of the HIP kernels' data movement (tests only).
 
-It mirrors, formula by formula, the address arithmetic of qqq_amd/csrc/qqq_{stream,column,tiled}.hip.h
-(`qqq_stream_kernel`, `qqq_column_kernel`, `qqq_tiled_kernel`): which bytes each lane loads, how the LDS image is
+It mirrors, formula by formula, the address arithmetic of qqq_amd/csrc/qqq_{stream,column,tiled,panel}.hip.h
+(`qqq_stream_kernel`, `qqq_column_kernel`, `qqq_tiled_kernel`, `qqq_panel_kernel`): which bytes each lane loads, how the LDS image is
 swizzled, which MFMA operand slot they land in, and where each accumulator register is stored.
 The MFMA lane maps assumed here (and checked on the device by tests/test_gpu_probe.py):
 
@@ -311,4 +311,130 @@ def tiled_kernel_model(A, B, s3, M, N, K, BM, MTW, JW, ksplit, grouped, return_t
                                         out[m[ln], n[ln] : n[ln] + 4] += acc[wave, mt, jj, bi, ln, 4 * gq : 4 * gq + 4]
     if return_tile_order:
         return out, seen
+    return out
+
+
+def _quad_transpose4(w):
+    """quad_transpose4 of qqq_common.hip.h: y[e](lane q of a quad) = w[q](lane e); w, y: [64 lanes, 4] uint32."""
+    lane = np.arange(64)
+    odd, hi = (lane & 1) != 0, (lane & 2) != 0
+    z = np.zeros_like(w)
+    y = np.zeros_like(w)
+    for e in range(4):
+        z[:, e] = np.where(odd == bool(e & 1), w[:, e], _quad_perm(w[:, e ^ 1], [1, 0, 3, 2]))
+    for e in range(4):
+        y[:, e] = np.where(hi == bool(e & 2), z[:, e], _quad_perm(z[:, e ^ 2], [2, 3, 0, 1]))
+    return y
+
+
+def panel_stage_image(Ab, M, K, mbase, ROWS, st, k_tail_stage):
+    """LDS image of one 128-k activation stage as store_x writes it: chunk (row, 16-byte piece pos) at
+    row*128 + ((pos ^ ((row >> 1) & 7)) << 4); the upper half of a trailing 64-k stage re-fetches the lower half."""
+    img = np.zeros(ROWS * 128, np.uint8)
+    for row in range(ROWS):
+        grow = min(mbase + row, M - 1)
+        for pos in range(8):
+            src = grow * K + st * 128 + pos * 16 - (64 if (k_tail_stage and pos >= 4) else 0)
+            dst = row * 128 + ((pos ^ ((row >> 1) & 7)) << 4)
+            img[dst : dst + 16] = Ab[src : src + 16]
+    return img
+
+
+def panel_fragment_addr(mt, tk):
+    """byte address inside a stage image of lane l's ds_read_b128 for m-tile mt, 64-k step tk of the stage"""
+    lane = np.arange(64)
+    h = lane >> 4
+    return (lane & 15) * 128 + mt * 2048 + (((4 * tk + h) ^ (((lane & 15) >> 1) & 7)) << 4)
+
+
+def panel_slot_index(MT, WN, KG, HW):
+    """int32 index inside a split-K slot of every (wave column set wn, m-tile, operand q, lane, register r) a finishing wave
+    deposits: must tile the ROWS x BN ints of the slot exactly once."""
+    NQ = 2 * HW
+    split = KG == 2 and MT >= 2
+    MTO = MT // 2 if split else MT
+    idx = []
+    for kg in range(KG if split else 1):
+        mb = kg * MTO if split else 0
+        for wn in range(WN):
+            for j in range(MTO):
+                for q in range(NQ):
+                    base = ((wn * MT + mb) * NQ + (j * NQ + q)) * 256
+                    idx.append(base + np.arange(64)[:, None] * 4 + np.arange(4)[None, :])
+    return np.concatenate([i.reshape(-1) for i in idx])
+
+
+def panel_kernel_model(A, B, s3, M, N, K, MT, WN, KG, HW, ksplit, grouped):
+    """qqq_panel_kernel: a workgroup = 16*MT tokens x BN = 32*WN*HW columns x one K slice; wave (wn, kg) owns HW 32-column
+    sets of a 64-column group and (KG == 2) the 64-k half kg of every 128-k stage; weights by 16-byte loads + quad transpose,
+    activations through the swizzled LDS stage image; D lane -> (token j = l & 15, c' = l >> 4, jt = register)."""
+    Bb = np.ascontiguousarray(B).view(np.uint8).reshape(-1)
+    Ab = np.ascontiguousarray(A).view(np.uint8).reshape(-1)
+    s3h = None if not grouped else np.ascontiguousarray(s3).reshape(-1)
+    rowbytes = N * 8
+    BN, ROWS = 32 * WN * HW, 16 * MT
+    KS = K >> 6
+    NST = (KS + 1) >> 1
+    k_tail = (KS & 1) != 0
+    SPW = 2 // KG
+    ngroups = N >> 6
+    lane = np.arange(64)
+    h, cq, q4 = lane >> 4, (lane >> 2) & 3, lane & 3
+    out = np.zeros((M, N), np.int64)
+    for mblk in range((M + ROWS - 1) // ROWS):
+        mbase = mblk * ROWS
+        for strip in range((N + BN - 1) // BN):
+            tile = np.zeros((ROWS, BN), np.int64)  # what the epilogue image holds after every slice is folded
+            for sp in range(ksplit):
+                st_begin, st_end = (NST * sp) // ksplit, (NST * (sp + 1)) // ksplit
+                for wave in range(WN * KG):
+                    wn, kg = wave % WN, wave // WN
+                    gl = (wn * HW) >> 1
+                    ng = min(strip * (BN // 64) + gl, ngroups - 1)
+                    half = 0 if HW == 2 else (wn & 1)
+                    wptr = h * rowbytes + ng * 512 + (4 * half + cq) * 64 + q4 * 16
+                    sptr = ng * 64 + (4 * half + cq) * 8 + 2 * q4
+                    acc = np.zeros((MT, 2 * HW, 64, 4), np.int64)
+                    for st in range(st_begin, st_end):
+                        img = panel_stage_image(Ab, M, K, mbase, ROWS, st, k_tail and st == NST - 1)
+                        for t in range(SPW):
+                            tk = kg if KG == 2 else t
+                            s = 2 * st + tk
+                            valid = s < KS
+                            sl = min(s, KS - 1)
+                            ops = []
+                            for hf in range(HW):
+                                src = wptr + 4 * sl * rowbytes + 256 * hf
+                                w = Bb[src[:, None] + np.arange(16)[None, :]].reshape(64, 4, 4)
+                                w = (w.astype(np.uint32) << (8 * np.arange(4, dtype=np.uint32))).sum(-1).astype(np.uint32)
+                                y = _quad_transpose4(w)
+                                if grouped:
+                                    so = sptr + st * N + 32 * hf
+                                    sc0, sc1 = s3h[so][:, None], s3h[so + 1][:, None]
+                                    if not valid:  # scale 0 re-quantises every nibble to 0
+                                        sc0, sc1 = np.zeros_like(sc0), np.zeros_like(sc1)
+                                    w0, w1 = unpack_pair(y, True, sc0, sc1)
+                                else:
+                                    nm = MASK if valid else np.uint32(0)
+                                    w0, w1 = y & nm, (y << np.uint32(4)) & nm
+                                ops += [_bytes_to_i8(w0), _bytes_to_i8(w1)]  # q = 2*hf + b
+                            for mt in range(MT):
+                                ad = panel_fragment_addr(mt, tk)
+                                x = img[ad[:, None] + np.arange(16)[None, :]].view(np.int8)
+                                for q in range(2 * HW):
+                                    acc[mt, q] += mfma_16x16x64(ops[q], x)
+                    # epilogue image: token row 16*mt + j, column 64*gl + 16*r + 8*b + 4*(half + hf) + c'
+                    j, cp = lane & 15, lane >> 4
+                    for mt in range(MT):
+                        for q in range(2 * HW):
+                            for r in range(4):
+                                col = 64 * gl + 16 * r + 8 * (q & 1) + 4 * (half + (q >> 1)) + cp
+                                np.add.at(tile, (16 * mt + j, col), acc[mt, q, :, r])
+            for row in range(ROWS):
+                m = mbase + row
+                if m < M:
+                    n0 = strip * BN
+                    w = min(BN, N - n0)
+                    if w > 0:
+                        out[m, n0 : n0 + w] += tile[row, :w]
     return out

@@ -73,3 +73,37 @@ def test_lds_swizzles_are_bank_conflict_free():
         assert worst(h * 2048 + g * 512 + (4 * c + (kq ^ g)) * 16) == 1
     for t in range(4):
         assert worst(16384 + li * 128 + (((2 * t + h) ^ ((li >> 1) & 7)) * 16)) == 1
+
+
+@pytest.mark.parametrize("grouped", [False, True])
+def test_panel_kernel_model(grouped):
+    """The panel kernel's shapes: 32 / 64 columns per wave (HW), one / two k-groups, in-launch split-K, a trailing 64-k half
+    stage (K % 128 == 64, per-channel only: group size 128), N not a multiple of the strip, ragged m."""
+    rng = np.random.default_rng(14)
+    K = 256 if grouped else 320
+    A, B, s3, acc = _case(rng, 40, 320, K, grouped)
+    kw = dict(grouped=grouped)
+    assert np.array_equal(LM.panel_kernel_model(A, B, s3, 40, 320, K, MT=2, WN=4, KG=2, HW=1, ksplit=1, **kw), acc)   # BN = 128
+    assert np.array_equal(LM.panel_kernel_model(A, B, s3, 40, 320, K, MT=1, WN=8, KG=1, HW=1, ksplit=2, **kw), acc)   # BN = 256, one k-group
+    assert np.array_equal(LM.panel_kernel_model(A, B, s3, 40, 320, K, MT=4, WN=4, KG=2, HW=2, ksplit=2, **kw), acc)   # 64 columns per wave
+    A, B, s3, acc = _case(rng, 130, 256, K, grouped)
+    assert np.array_equal(LM.panel_kernel_model(A, B, s3, 130, 256, K, MT=8, WN=4, KG=2, HW=2, ksplit=1, **kw), acc)  # the M >= 768 shape
+
+
+def test_panel_split_k_slot_and_fragment_layout():
+    """Every finishing wave's deposit lands on its own ints of the slot (the fold of the last arrival reads them back with
+    the same formula), and the activation fragment reads are bank-conflict free (ds_read_b128: 4 groups of 16 lanes)."""
+    for MT, WN, KG, HW in ((8, 4, 2, 1), (8, 4, 2, 2), (8, 8, 1, 1), (4, 4, 2, 1), (2, 4, 2, 2), (1, 4, 2, 1), (1, 8, 1, 1)):
+        idx = LM.panel_slot_index(MT, WN, KG, HW)
+        assert idx.size == 16 * MT * 32 * WN * HW and np.array_equal(np.sort(idx), np.arange(idx.size)), (MT, WN, KG, HW)
+    groups = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+    groups += [[x + 32 for x in grp] for grp in groups]
+    for mt in (0, 3, 7):
+        for tk in (0, 1):
+            addr = LM.panel_fragment_addr(mt, tk)
+            for grp in groups:
+                banks = {}
+                for l in grp:
+                    for d in range(4):
+                        banks.setdefault(((addr[l] // 4) + d) % 64, set()).add(int(addr[l]) + 4 * d)
+                assert max(len(v) for v in banks.values()) == 1, (mt, tk)
