@@ -390,11 +390,15 @@ static double stream_estimate(int M, int N, int K, bool grouped) {
   double per_block = (double)N * K / 2.0 / 5.0e6;  // the weight matrix at ~5 TB/s
   if (per_block < 2.5) per_block = 2.5;
   const int mblocks = (M + 63) / 64;
-  // measured: 2 / 3 / 4 m-blocks take 1.95 / 3.0 / 3.3 weight passes, plus ~2 us of fixed work per m-block
+  // measured: 2 / 3 / 4 m-blocks take 1.85 / 3.2 / 3.3 weight passes
   // (one m-block: 16 / 32 / 48 / 64 tokens measured at 0.6 / 0.8 / 1.0 / 1.2 -- the 16-token tiles of a block share the weights
   //  in registers but not the MFMA / VALU time)
-  const double passes = (mblocks == 1) ? 0.4 + 0.0125 * M : (mblocks == 2) ? 1.95 : (mblocks == 3) ? 3.0 : 3.3 + 0.8 * (mblocks - 4);
-  const double us = 9.0 + per_block * passes + 2.0 * mblocks;
+  const double passes = (mblocks == 1) ? 0.4 + 0.0125 * M : (mblocks == 2) ? 1.85 : (mblocks == 3) ? 3.2 : 3.3 + 0.8 * (mblocks - 4);
+  // fixed part: 2 and 3 m-blocks in one round of workgroups measured at 10.6 (3 blocks: 18.0 / 25.0 / 68 us at 1.7 / 4.5 / 17.8 us
+  // per pass; 2 blocks: 16.3 / 18.9 / 43.5; profiles/r02_dispatch_check_handoff.txt); more than 256 workgroups even unsplit
+  // (n = 11008: 86 strips x 3) is a second round
+  double us = ((mblocks == 2 || mblocks == 3) ? 10.6 : 9.0 + 2.0 * mblocks) + per_block * passes;
+  if ((long long)((N + 127) / 128) * mblocks > 256) us *= 1.35;
   return grouped ? us * 1.15 : us;
 }
 
