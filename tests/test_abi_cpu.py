@@ -101,45 +101,56 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
         _lib.lib()
 
 
+def _check_plan(m, n, k, grouped, max_par):
+    """the invariants every automatic plan must keep: the reference's buffers (C = max_par*64 rows x n int32, workspace =
+    n/128*max_par ints; qlinear_marlin.py:117-133) bound every split, and no plan needs scratch it was not given"""
+    from qqq_amd import _lib
+
+    gs = 128 if grouped else -1
+    p = _lib.plan(m, n, k, gs, max_par)
+    assert p["kernel"] in (1, 2, 3, 4) and p["ksplit"] >= 1
+    cap_rows, cap_tk = max_par * 64, (n // 128) * max_par
+    if p["kernel"] == 4:  # panel: one slot of C per depositing slice, two ticket words per tile
+        rows, bn = 16 * p["mt"], p["bm"]
+        mblocks, strips = -(-m // rows), -(-n // bn)
+        assert n % 64 == 0 and k % 64 == 0 and bn in (128, 256) and p["mt"] in (1, 2, 4, 8)
+        if p["ksplit"] > 1:
+            assert mblocks * strips * rows * bn * (p["ksplit"] - 1) <= cap_rows * n and 2 * mblocks * strips <= cap_tk
+            assert p["ksplit"] <= ((k // 64 + 1) // 2)
+        assert _lib.plan(m, n, k, gs, max_par, have_scratch=False)["ksplit"] == 1
+        return p
+    if p["kernel"] == 3:
+        assert m <= 32 and n % 64 == 0 and k % 64 == 0 and p["ksplit"] == 1
+        return p
+    if p["kernel"] == 1:
+        assert m <= 256 or k % 128 or n % 64  # the stream family is only chosen for a few m-blocks
+        if p["ksplit"] > 1:
+            assert p["ksplit"] * m <= cap_rows and p["fused"] == 2
+            if p["mt"] >= 2:  # 8-wave bodies, one workgroup per CU: the split never asks for a second round
+                assert -(-n // 128) * -(-m // (16 * p["mt"])) * p["ksplit"] <= 256
+        return p
+    rows = 256 if p["bm"] >= 256 else 128 if p["bm"] >= 128 else 64
+    tiles = -(-m // rows) * -(-n // 256)
+    assert p["ksplit"] <= k // 128
+    if p["ksplit"] > 1 and p["nslots"] > 0:  # in-launch: slots + tickets must fit
+        assert p["nslots"] * tiles * rows * 256 <= cap_rows * n
+        assert tiles * (1 + p["nslots"]) <= cap_tk and p["nslots"] <= p["ksplit"] - 1
+    elif p["ksplit"] > 1:  # slabs
+        assert p["ksplit"] * m <= cap_rows
+    # without scratch there is never a split
+    assert _lib.plan(m, n, k, gs, max_par, have_scratch=False)["ksplit"] == 1
+    return p
+
+
 def test_dispatch_plan_respects_scratch_contract(L):
-    """qqq_w4a8_plan is pure host logic: for every shape the plan must stay inside what the reference's
-    buffers guarantee (C = max_par*64 rows x n int32, workspace = n/128*max_par ints; qlinear_marlin.py:117-133)."""
+    """qqq_w4a8_plan is pure host logic: for every shape the plan must stay inside what the reference's buffers guarantee."""
     from qqq_amd import _lib
 
     for grouped in (False, True):
         for n, k in ((8192, 21760), (4096, 4096), (11008, 4096), (4096, 11008), (256, 128), (320, 1536)):
             for max_par in (1, 4, 16):
                 for m in (1, 7, 16, 64, 128, 129, 200, 256, 300, 512, 640, 1000, 1024, 1025, 2048, 4096, 32768):
-                    p = _lib.plan(m, n, k, 128 if grouped else -1, max_par)
-                    assert p["kernel"] in (1, 2, 3, 4) and p["ksplit"] >= 1
-                    cap_rows, cap_tk = max_par * 64, (n // 128) * max_par
-                    if p["kernel"] == 4:  # panel: one slot of C per depositing slice, two ticket words per tile
-                        rows, bn = 16 * p["mt"], p["bm"]
-                        mblocks, strips = -(-m // rows), -(-n // bn)
-                        assert n % 64 == 0 and k % 64 == 0 and bn in (128, 256) and p["mt"] in (1, 2, 4, 8)
-                        if p["ksplit"] > 1:
-                            assert mblocks * strips * rows * bn * (p["ksplit"] - 1) <= cap_rows * n and 2 * mblocks * strips <= cap_tk
-                            assert p["ksplit"] <= ((k // 64 + 1) // 2)
-                        assert _lib.plan(m, n, k, 128 if grouped else -1, max_par, have_scratch=False)["ksplit"] == 1
-                        continue
-                    if p["kernel"] == 3:
-                        assert m <= 32 and n % 64 == 0 and k % 64 == 0 and p["ksplit"] == 1
-                        continue
-                    if p["kernel"] == 1:
-                        assert m <= 256 or k % 128 or n % 64  # the stream family is only chosen for a few m-blocks
-                        if p["ksplit"] > 1:
-                            assert p["ksplit"] * m <= cap_rows and p["fused"] == 2
-                        continue
-                    rows = 256 if p["bm"] >= 256 else 128 if p["bm"] >= 128 else 64
-                    tiles = -(-m // rows) * -(-n // 256)
-                    assert p["ksplit"] <= k // 128
-                    if p["ksplit"] > 1 and p["nslots"] > 0:  # in-launch: slots + tickets must fit
-                        assert p["nslots"] * tiles * rows * 256 <= cap_rows * n
-                        assert tiles * (1 + p["nslots"]) <= cap_tk and p["nslots"] <= p["ksplit"] - 1
-                    elif p["ksplit"] > 1:  # slabs
-                        assert p["ksplit"] * m <= cap_rows
-                    # without scratch there is never a split
-                    assert _lib.plan(m, n, k, 128 if grouped else -1, max_par, have_scratch=False)["ksplit"] == 1
+                    _check_plan(m, n, k, grouped, max_par)
     # forced variants are honoured, and an impossible in-launch request falls back to slabs or no split
     p = _lib.plan(1024, 8192, 21760, -1, 16, tune=dict(kernel=2, bm=256, ksplit=2, fused=1))
     assert (p["bm"], p["ksplit"], p["nslots"], p["fused"]) == (256, 2, 1, 1)
@@ -147,6 +158,25 @@ def test_dispatch_plan_respects_scratch_contract(L):
     assert p["nslots"] == 0 and p["ksplit"] == 1  # 2 slabs of 1024 rows do not fit in 1024 rows
     p = _lib.plan(2048, 8192, 21760, -1, 16, tune=dict(kernel=2, bm=256, ksplit=2, fused=1))
     assert p["ksplit"] == 1
+
+
+def test_dispatch_plan_invariants_on_random_shapes(L):
+    """the same invariants on shapes nobody picked by hand (hypothesis): any m, n and k in the reference's 64-multiples,
+    group size 128 needs k % 128 == 0, max_par 1..16"""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=400, deadline=None, derandomize=True)
+    @given(m=st.one_of(st.integers(1, 600), st.integers(1, 70000)), n64=st.integers(1, 400), k64=st.integers(1, 400),
+           grouped=st.booleans(), max_par=st.integers(1, 16))
+    def run(m, n64, k64, grouped, max_par):
+        n, k = 64 * n64, 64 * k64
+        if grouped:
+            k = max(128, k // 128 * 128)
+        if n == 64 and k % 128:  # reference: n = 64 needs thread_k = 128 (csrc/qqq_gemm.cu:867-897)
+            k += 64
+        _check_plan(m, n, k, grouped, max_par)
+
+    run()
 
 
 def test_dispatch_of_the_baseline_sweep(L):
