@@ -69,8 +69,9 @@ typedef struct qqq_tune {
   int bm;      /* tiled: rows per workgroup tile (64, 128, 256); panel: COLUMNS per workgroup (128, 256); 0 auto */
   int glds;    /* tiled: 1 = direct global->LDS loads, 2 = register staged; 0 auto          */
   int pf;      /* stream: prefetch depth in 4 KiB steps per wave (3, 5, 7); column: 1 KiB steps per wave
-                  (2..12); 0 auto                                                                  */
-  int stages;  /* tiled + LDS-DMA: ring depth 2..4 (0 auto)                                      */
+                  (2..12); panel: weight ring depth in 128-k stages (2, 3, 4; 8 for mt <= 4); 0 auto      */
+  int stages;  /* tiled + LDS-DMA: ring depth 2..7 (0 auto); panel: activation lead in stages -- with pf = 4 it is 2
+                  unless 4 is asked for, otherwise it equals pf                                            */
   int mt;      /* stream: 16-token tiles per workgroup (1..4); column: 1..2; panel: 1, 2, 4, 8; 0 auto  */
   int pw;      /* tiled: weight strips per XCD panel of the tile order (4, 8, 16, 32); panel (bm = 256, mt = 8):
                   32-column sets per wave (1, or 2 = 4 waves x 64 columns x 2 k-groups); 0 auto            */
@@ -89,7 +90,7 @@ int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, const void*
 
 /* The dispatch decision qqq_w4a8_gemm_ex would take for this problem, without touching the GPU (pure host
  * logic; used by tests and tools).  have_scratch / have_workspace: whether C / workspace would be non-NULL.
- * plan_out: kernel, ksplit, fused, waves, pf, mt (stream) or bm, glds, stages, pw (tiled) as chosen;
+ * plan_out: kernel, ksplit, fused, waves, pf, mt (stream / column), bm, glds, stages, pw (tiled), bm, mt, pf, stages, pw (panel) as chosen;
  * nslots = number of tile-sized slots of C used by the tiled in-launch split-K (0 = slabs or no split). */
 int qqq_w4a8_plan(int prob_m, int prob_n, int prob_k, int groupsize, int max_par, int have_scratch,
                   int have_workspace, const qqq_tune_t* tune, qqq_tune_t* plan_out);
