@@ -58,3 +58,47 @@ def test_hot_instantiations(table):
             assert k["private_segment_fixed_size"] == 0 and k["vgpr_count"] <= 256, n
         # one workgroup must fit a CU: 512 registers per lane and SIMD, 8-wave workgroups -> 2 waves per SIMD
         assert k["vgpr_count"] <= 512, n
+
+
+def _loop(name):
+    import code_object
+    from qqq_amd import build
+
+    sym = [k["name"] for k in code_object.kernels(build.LIB) if k["demangled"] == name][0]
+    mix = code_object.hottest_loop(build.LIB, sym)
+    waits = mix.pop("waits")
+    return mix, waits
+
+
+def _count(mix, prefix, exclude=()):
+    return sum(v for o, v in mix.items() if o.startswith(prefix) and not any(o.startswith(e) for e in exclude))
+
+
+def test_steady_state_loops(table):
+    """Instruction mix of the hot loops, from the disassembly (tools/code_object.py::hottest_loop).  What the measured numbers rest
+    on and a source or compiler change could silently undo: the unroll (MFMAs per trip), no scratch and no full `vmcnt(0)` drain
+    inside a register-ring loop (the waits are counted), the barrier count, and the VALU : MFMA issue ratio of the panel shapes
+    (VALU and MFMA share the SIMD's issue port -- 3.1 per MFMA had the loop VALU-issue bound)."""
+    # 64 columns per wave, per-channel: 4 stages x (8 m-tiles x 4 operands); barrier after every other stage
+    mix, waits = _loop("qqq_panel_kernel<8,false,4,2,4,2,2>")
+    assert mix["v_mfma_i32_16x16x64_i8"] == 128 and mix["s_barrier"] == 2
+    assert _count(mix, "scratch") == 0 and not any("vmcnt(0)" in w for w in waits)
+    assert mix["ds_read_b128"] == 32 and mix["ds_write_b128"] == 8 and mix["global_load_dwordx4"] == 16
+    assert _count(mix, "v_", exclude=("v_mfma",)) <= 1.6 * 128
+    # ... per-group: the re-quantiser (3 v_pk_fma + v_pk_add + 2 v_and_or + v_perm + v_xor per 4 weights) on top
+    mix, waits = _loop("qqq_panel_kernel<8,true,4,2,4,2,2>")
+    assert mix["v_mfma_i32_16x16x64_i8"] == 128 and mix["s_barrier"] == 2 and _count(mix, "scratch") == 0
+    assert mix["v_pk_fma_f16"] == 192 and mix["v_and_or_b32"] == 128 and not any("vmcnt(0)" in w for w in waits)
+    # 32 columns per wave, 128 tokens (the M = 128 point): 4 stages x (8 m-tiles x 2 operands), a barrier per stage
+    mix, waits = _loop("qqq_panel_kernel<8,false,4,2,4,2,1>")
+    assert mix["v_mfma_i32_16x16x64_i8"] == 64 and mix["s_barrier"] == 4
+    assert _count(mix, "scratch") == 0 and not any("vmcnt(0)" in w for w in waits)
+    assert _count(mix, "v_", exclude=("v_mfma",)) <= 2.0 * 64
+    # decode and a-few-tokens kernels: counted waits only, no LDS in the loop, no scratch
+    for name in ("qqq_column_kernel<1,false,8,3>", "qqq_column_kernel<1,true,8,3>", "qqq_stream_kernel<1,false,4,3>"):
+        mix, waits = _loop(name)
+        assert _count(mix, "scratch") == 0 and _count(mix, "ds_") == 0 and mix.get("s_barrier", 0) == 0, name
+        assert waits and not any("vmcnt(0)" in w for w in waits), (name, waits)
+    # the large-m LDS-DMA tile: 32 x v_mfma_i32_32x32x32_i8 per 128-k block, no scratch
+    mix, _ = _loop("qqq_tiled_kernel<256,2,2,2,false,7>")
+    assert mix["v_mfma_i32_32x32x32_i8"] == 32 and _count(mix, "scratch") == 0

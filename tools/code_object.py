@@ -63,6 +63,50 @@ def kernels(lib):
     return out
 
 
+def hottest_loop(lib, symbol):
+    """Instruction mix of the loop with the most MFMAs in kernel `symbol` (mangled name) of `lib`: {opcode: count} over the
+    instructions between a backward branch and its target, plus "waits" = the s_waitcnt operands seen inside.  The loop is
+    found from the disassembly alone (a backward s_cbranch), so this needs neither a GPU nor compiler remarks."""
+    lib = os.path.abspath(lib)
+    with tempfile.TemporaryDirectory() as td:
+        link = os.path.join(td, "lib.so")
+        os.symlink(lib, link)
+        subprocess.run([f"{LLVM}/llvm-objdump", "--offloading", link], cwd=td, check=True, capture_output=True)
+        co = [f for f in os.listdir(td) if "gfx950" in f][0]
+        dis = subprocess.run([f"{LLVM}/llvm-objdump", "-d", f"--disassemble-symbols={symbol}", os.path.join(td, co)],
+                             check=True, capture_output=True, text=True).stdout
+    ins = []  # (address, opcode, operands)
+    for line in dis.split("\n"):
+        m = re.match(r"\s+(\S+)\s*(.*?)\s*//\s*([0-9A-Fa-f]+):(.*)", line)
+        if m:
+            ins.append((int(m.group(3), 16), m.group(1), m.group(2), m.group(4)))
+    if not ins:
+        raise RuntimeError(f"{symbol} not found in {lib}")
+    base = ins[0][0]
+    best = None
+    for addr, op, args, tail in ins:
+        if not op.startswith("s_cbranch"):
+            continue
+        m = re.search(r"\+0x([0-9a-fA-F]+)>", tail)
+        if not m:
+            continue
+        tgt = base + int(m.group(1), 16)
+        if tgt >= addr:
+            continue  # forward
+        body = [x for x in ins if tgt <= x[0] <= addr]
+        n = sum(1 for x in body if x[1].startswith("v_mfma"))
+        if best is None or n > best[0]:
+            best = (n, body)
+    mix = {}
+    waits = []
+    for _, op, args, _t in (best[1] if best else []):
+        mix[op] = mix.get(op, 0) + 1
+        if op == "s_waitcnt":
+            waits.append(args)
+    mix["waits"] = waits
+    return mix
+
+
 if __name__ == "__main__":
     lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "qqq_amd", "libqqq_amd.so")
     ks = kernels(lib)
