@@ -18,6 +18,12 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
 #define QQQ_NIB_MASK 0xF0F0F0F0u
+// In-launch split-K: polls (each behind an s_sleep, ~0.1-0.3 us) the last arrival of a tile spends waiting for the deposits
+// of slices that have, by construction, already arrived -- microseconds in practice.  Beyond the limit (seconds) the kernel
+// traps: the launch fails loudly instead of folding whatever is in the slots.
+#ifndef QQQ_SPIN_LIMIT
+#define QQQ_SPIN_LIMIT (1 << 24)
+#endif
 
 // ------------------------------------------------------------------------------------------
 // small device helpers

@@ -375,6 +375,10 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
     // barrier (two workgroups sharing a CU) would otherwise read stage 2 rows for its first step.
     if constexpr (NBUF == 2 || RELAX) __syncthreads();
     QQQ_TR(1);
+#ifdef QQQ_PANEL_PRIO
+    // measurement: static priority for the later-dispatched half of the waves (the arbitration loser of every SIMD pair)
+    if (__builtin_amdgcn_readfirstlane(tid) >= NT / 2) __builtin_amdgcn_s_setprio(1);
+#endif
     // ---- steady state: PFS stages per iteration (ring slots are compile-time registers), branch-free ----
     int i0 = 0;
     for (; i0 + PFS <= nst; i0 += PFS) {
@@ -517,10 +521,19 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
       if (tid == 0) __hip_atomic_fetch_add(tk + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return;
     }
-    if (tid == 0)  // everybody waited for has arrived already (is depositing): short, and bounded as a matter of principle
-      for (int spin = 0; spin < (1 << 24) && __hip_atomic_load(tk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ksplit - 1; ++spin)
+    if (tid == 0) {  // everybody waited for has arrived already (is depositing): short, and bounded as a matter of principle
+      int spin = 0;
+      while (__hip_atomic_load(tk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ksplit - 1) {
+        // a depositor that never completes (pre-empted for seconds, a debugger) must not end in a silently wrong D:
+        // the launch is aborted and the host sees the error at its next synchronisation
+        if (++spin > QQQ_SPIN_LIMIT) __builtin_trap();
         __builtin_amdgcn_s_sleep(2);
+      }
+    }
     __syncthreads();
+#ifdef QQQ_HANDOFF_ACQUIRE_FENCE  // debugging switch: the formal agent-scope acquire in front of the fold (~3 us per finisher)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
     QQQ_TR(5);
     // No acquire fence here: at agent scope it is a `buffer_inv sc1` over the whole L2, measured at ~3 us of the finisher's
     // critical path (tools/trace_panel.py).  The deposits are read with agent-scope loads instead (`load16_agent`, sc1),

@@ -578,10 +578,17 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * (2 / NB) * 64) void 
                                                     (size_t)wave * NQ4 * 256);
     };
     auto wait_done = [&](const int s_, const int want) {
-      if (tid == 0)
-        while (__hip_atomic_load(tk + 1 + s_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want)
+      if (tid == 0) {
+        int spin = 0;
+        while (__hip_atomic_load(tk + 1 + s_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+          if (++spin > QQQ_SPIN_LIMIT) __builtin_trap();  // never a silently wrong D: abort the launch (see the panel kernel)
           __builtin_amdgcn_s_sleep(4);
+        }
+      }
       __syncthreads();  // no acquire fence (an L2-wide invalidate at agent scope): add_slot reads with agent-scope loads
+#ifdef QQQ_HANDOFF_ACQUIRE_FENCE
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
     };
     auto add_slot = [&](const int s_) {
       const __amdgpu_buffer_rsrc_t view = agent_view(slot_base(s_));

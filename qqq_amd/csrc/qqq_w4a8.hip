@@ -42,6 +42,8 @@
 // with ONE packed-fp16 FMA exactly like dequant_per_group (csrc/qqq_gemm.cu:167-210).
 
 #include <thread>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "qqq_common.hip.h"
@@ -49,6 +51,7 @@
 #include "qqq_column.hip.h"
 #include "qqq_panel.hip.h"
 #include "qqq_tiled.hip.h"
+#include "qqq_wide.hip.h"
 #include "qqq_small.hip.h"
 
 // ------------------------------------------------------------------------------------------
@@ -334,6 +337,37 @@ static hipError_t launch_tiled(const LaunchArgs& a, bool grouped, int bm, int st
                  : launch_tiled_bm<false>(a, bm, stages, ksplit, nslots, pw);
 }
 
+template <bool GROUPED, int P, int XL, int RS>
+static hipError_t launch_wide_t(const LaunchArgs& a, int pw) {
+  constexpr int XBUF = P * 256 * 128, EP = 64 * (256 + 4) * 4;
+  constexpr int LDS = XBUF > EP ? XBUF : EP;
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  static bool attr_set[64] = {};  // per instantiation, per device
+  auto kern = qqq_wide_kernel<GROUPED, P, XL, RS>;
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  if (cur < 0 || cur >= 64 || !attr_set[cur]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return e;
+    if (cur >= 0 && cur < 64) attr_set[cur] = true;
+  }
+  const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256;
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), LDS, a.stream, a.A, a.B, a.D, a.s1, a.s2, a.s3, a.acc_out,
+                     a.bias, a.M, a.N, a.K, tiles_m, tiles_n, pw);
+  return hipGetLastError();
+}
+
+// pf: weight ring in 64-k steps (3 or 6); stages: activation register lead in 128-k stages (1 or 3; 3 only with pf = 3 --
+// both deep rings together spill inside the loop)
+static hipError_t launch_wide(const LaunchArgs& a, bool grouped, int pf, int stages, int pw) {
+  if (grouped) {
+    if (stages == 3) return launch_wide_t<true, 3, 3, 3>(a, pw);
+    return pf == 3 ? launch_wide_t<true, 3, 1, 3>(a, pw) : launch_wide_t<true, 3, 1, 6>(a, pw);
+  }
+  if (stages == 3) return launch_wide_t<false, 3, 3, 3>(a, pw);
+  return pf == 3 ? launch_wide_t<false, 3, 1, 3>(a, pw) : launch_wide_t<false, 3, 1, 6>(a, pw);
+}
+
 static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // ---- cost models (microseconds) used by the automatic dispatch; constants fitted to profiles/r02_dispatch_check*.txt ----
@@ -501,10 +535,21 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
       }
     }
   }
-  if ((kernel == 3 || kernel == 4) && !column_ok) kernel = 1;
+  if ((kernel == 3 || kernel == 4 || kernel == 5) && !column_ok) kernel = 1;
+  if (kernel == 5 && (long long)N * K / 2 >= (1ll << 32)) kernel = 2;  // 32-bit offsets into the packed weights
   if (kernel == 2 && (K % 128) != 0) kernel = 1;
   pl.kernel = kernel;
   int ksplit = 1;
+
+  if (kernel == 5) {
+    // wide: 256 tokens x 256 columns per workgroup, 4 waves with 512 registers each, no split-K
+    pl.stages = (t.stages == 3) ? 3 : 1;                  // activation register lead in stages
+    pl.pf = (t.pf == 3 || pl.stages == 3) ? 3 : 6;        // weight ring in 64-k steps
+    pl.pw = (t.pw == 4 || t.pw == 8 || t.pw == 16 || t.pw == 32) ? t.pw : 8;
+    pl.ksplit = 1;
+    pl.fused = 1;
+    return pl;
+  }
 
   if (kernel == 4) {
     // panel: all tokens of an m-block (16*mt <= 128) x bn columns x a K slice per workgroup; in-launch split-K with one
@@ -724,7 +769,11 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
     snprintf(g_err, sizeof(g_err), "m=%d exceeds the grid of the small-m kernels (forced by tune)", M);
     return QQQ_ERR_ARG;
   }
-  if (pl.kernel == 4) {
+  if (pl.kernel == 5) {
+    e = launch_wide(a, grouped, pl.pf, pl.stages, pl.pw);
+    if (e != hipSuccess) return fail_hip(e, "qqq_wide_kernel launch");
+    reduce_launch = false;
+  } else if (pl.kernel == 4) {
     e = launch_panel(a, grouped, pl.mt, pl.bm, pl.waves, pl.pw, pl.pf, pl.stages, pl.ksplit);
     if (e != hipSuccess) return fail_hip(e, "qqq_panel_kernel launch");
     reduce_launch = false;

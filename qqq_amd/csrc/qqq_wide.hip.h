@@ -1,0 +1,428 @@
+// qqq_wide.hip.h -- "wide" kernel (round 3): 256 tokens x 256 columns per workgroup, FOUR waves -- one per SIMD, 512 registers
+// each (256 int32 accumulators in the accumulation half of the unified register file).  Large m.
+// Part of the single translation unit qqq_w4a8.hip (see its header comment for the design).
+#ifndef QQQ_AMD_QQQ_WIDE_HIP_H_
+#define QQQ_AMD_QQQ_WIDE_HIP_H_
+
+// ------------------------------------------------------------------------------------------
+// Why this shape.  In the panel kernel's large-m shape (128 tokens x 256 columns, 8 waves = 4 column waves x 2 k-groups) a
+// wave owns 64 columns x 128 tokens: every unpacked weight operand (and in the per-group mode every RE-QUANTISED one) feeds
+// 8 m-tiles, every activation fragment read from LDS feeds 4 MFMAs, and the 128 accumulators fill half of the 256 registers
+// two waves per SIMD leave each wave.  The per-SIMD register file holds 512 per lane: ONE wave per SIMD can keep 256
+// accumulators (16 m-tiles x 4 column sets) next to 256 working registers.  A wave then owns 64 columns x 256 tokens:
+//   * unpack / re-quantise VALU per MFMA halves (per-channel 1.5 -> 0.75, per-group 5.1 -> 2.4 -- the per-group mode was
+//     VALU-issue bound at 128 tokens per weight operand: "re-quantise once, multiply many");
+//   * 256 x 256 tiles: the L2 <-> fabric traffic of the tiled kernel (2 rounds x 8 XCDs x (4 m-tiles + 8 strips)), not the
+//     128-row m-blocks' 4 rounds;
+//   * no k-group meet at the end, one barrier per 128-k stage between FOUR waves.
+// The price: nothing hides a wave's own stalls (no partner on the SIMD), so the loop is software-pipelined like the panel
+// kernel's 64-column path -- weights HBM -> VGPR ring (RS = 2P steps ahead), 4x4 quad transpose in registers, operands
+// unpacked half a step ahead in place, activation fragments re-read in place right behind their last MFMA, activations
+// staged global -> VGPR -> LDS two stages ahead -- with the instruction interleave pinned by sched_group_barrier.
+//
+// grid = tiles_m * tiles_n (XCD-aware order as in the tiled kernel), block = 256.  No split-K: the host picks this shape
+// only when tiles >= ~1 round of the chip.
+// Addresses: wave-uniform buffer descriptors + 32-bit lane offsets + scalar step offsets (buffer_load ... v_off, s[rsrc],
+// s_off): no 64-bit per-lane address arithmetic on the issue port the MFMAs share.
+// ------------------------------------------------------------------------------------------
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>), in order: compile-time indices for hand-placed code
+template <int... S, class F>
+__device__ __forceinline__ void qqq_static_for(std::integer_sequence<int, S...>, F&& f) {
+  (f(std::integral_constant<int, S>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void qqq_static_for(F&& f) {
+  qqq_static_for(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wide_view(const void* base_uniform) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base_uniform), 0, 0xffffffff, 0x00020000);
+}
+__device__ __forceinline__ v4u wide_load16(__amdgpu_buffer_rsrc_t view, const unsigned voff, const unsigned soff) {
+  return __builtin_amdgcn_raw_buffer_load_b128(view, voff, soff, 0);
+}
+
+template <bool GROUPED, int P, int XL, int RS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void qqq_wide_kernel(
+    const int8_t* __restrict__ A, const unsigned char* __restrict__ B, _Float16* __restrict__ D,
+    const float* __restrict__ s1, const float* __restrict__ s2, const _Float16* __restrict__ s3,
+    int32_t* __restrict__ acc_out, const _Float16* __restrict__ bias, const int M, const int N, const int K,
+    const int tiles_m, const int tiles_n, const int PW) {
+  constexpr int MT = 16;                 // m-tiles of 16 tokens per wave (= per workgroup)
+  constexpr int ROWS = 16 * MT;          // 256 tokens
+  constexpr int BN = 256;                // 4 waves x 64 columns
+  constexpr int NT = 256;
+  constexpr int XB = ROWS * 128;         // bytes of one activation stage (128 k)
+  constexpr int XPT = XB / 16 / NT;      // 8 16-byte chunks per thread and stage
+  static_assert((2 * P) % RS == 0, "weight ring (in 64-k steps) must divide the unroll period");
+  constexpr int LA = 2;                  // stage i + LA is written to LDS during stage i (its buffer was last read in i - 1)
+  static_assert(P == 3 && (P % XL) == 0, "ring periods");
+  constexpr int EPR = 64;                // rows per epilogue pass
+  constexpr int EP_STRIDE = BN + 4;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);  // 64-column group of the strip
+  QQQ_TR(0);  // (measurement builds only, -DQQQ_PANEL_TRACE: see qqq_panel.hip.h; grid is 1-D here)
+
+  // ---- XCD-aware tile order (speed only): block b runs on XCD b % 8; an XCD walks panels of PW strips x all m-tiles ----
+  int tile_m, tile_n;
+  {
+    const int ntiles = tiles_m * tiles_n;
+    const int bid = blockIdx.x;
+    const int q = ntiles >> 3, rr = ntiles & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int lin = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+    const int full = (tiles_n / PW) * PW * tiles_m;
+    if (lin < full) {
+      const int panel = lin / (PW * tiles_m), within = lin % (PW * tiles_m);
+      tile_m = within / PW;
+      tile_n = panel * PW + within % PW;
+    } else {
+      const int rem = lin - full, pw = tiles_n % PW;
+      tile_m = rem / pw;
+      tile_n = (tiles_n / PW) * PW + rem % pw;
+    }
+  }
+  const int mbase = tile_m * ROWS;
+  const int ngroups = N >> 6;
+  int ng = tile_n * 4 + wn;
+  if (ng >= ngroups) ng = ngroups - 1;   // N % 256 != 0: surplus waves of the last strip compute on clamped columns, store nothing
+  const unsigned rowbytes = (unsigned)N * 8u;
+
+  const int KS = K >> 6;                 // 64-k steps
+  const int NST = (KS + 1) >> 1;         // 128-k stages (a trailing half stage when K % 128 == 64)
+
+  // ---- per-lane sources ----
+  const int h = lane >> 4, cq = (lane >> 2) & 3, q4 = lane & 3;  // q4: kq as a load lane, jt as an MFMA lane
+  const __amdgpu_buffer_rsrc_t wview = wide_view(B + (size_t)ng * 512);
+  const unsigned woff = (unsigned)h * rowbytes + (unsigned)(cq * 64 + q4 * 16);   // + step * 4 * rowbytes (scalar) + 256 * hf
+  const __amdgpu_buffer_rsrc_t sview = wide_view(GROUPED ? (const void*)(s3 + (size_t)ng * 64) : (const void*)B);
+  const unsigned soff_l = (unsigned)((cq * 8 + 2 * q4) * 2);                      // + stage * N * 2 (scalar) + 64 * hf
+  // activation staging: chunk ci = tid + q * NT of the stage image = (row ci >> 3 = (tid >> 3) + 32 q, 16-byte piece tid & 7)
+  const __amdgpu_buffer_rsrc_t xview = wide_view(A + (size_t)mbase * K);
+  const int xr0 = tid >> 3, xpos = tid & 7;
+  unsigned xoff[XPT];
+#pragma unroll
+  for (int q = 0; q < XPT; ++q) {
+    int row = xr0 + 32 * q;
+    if (mbase + row >= M) row = M - 1 - mbase;  // rows past M: re-read the last row (computed, never stored)
+    xoff[q] = (unsigned)row * (unsigned)K + (unsigned)(xpos * 16);
+  }
+  const unsigned xdst = (unsigned)(xr0 * 128 + ((xpos ^ ((xr0 >> 1) & 7)) << 4));  // + q * 4096 (rows 32 apart: same swizzle)
+  const bool k_tail = (KS & 1) != 0;
+  const unsigned xtail = xpos >= 4 ? 64u : 0u;  // the upper 64 k of a trailing half stage lie outside the row
+
+  // stage / step indices past the end are redirected to the last one (loaded, never used): the loop stays branch-free
+  auto load_x = [&](const int st_rel, v4u (&r)[XPT]) {
+    const int st = st_rel < NST ? st_rel : NST - 1;
+    // ... fetch the lower half again instead (never used: the weights of that step are zeroed)
+    const unsigned adj = (k_tail && st == NST - 1) ? xtail : 0u;
+    const unsigned so = (unsigned)st * 128u;
+#pragma unroll
+    for (int q = 0; q < XPT; ++q) r[q] = wide_load16(xview, xoff[q] - adj, so);
+  };
+  auto store_x = [&](const int buf, const v4u (&r)[XPT]) {
+#pragma unroll
+    for (int q = 0; q < XPT; ++q) *reinterpret_cast<v4u*>(smem + buf * XB + xdst + q * 4096) = r[q];
+  };
+  auto load_w = [&](const int step_rel, v4u (&dst)[2]) {
+    const int s = step_rel < KS ? step_rel : KS - 1;
+    const unsigned so = (unsigned)(4 * s) * rowbytes;
+    dst[0] = wide_load16(wview, woff, so);
+    dst[1] = wide_load16(wview, woff + 256u, so);
+  };
+  auto load_sc = [&](const int st_rel, h2 (&dst)[2]) {
+    const int st = st_rel < NST ? st_rel : NST - 1;
+    const unsigned so = (unsigned)st * (unsigned)N * 2u;
+    dst[0] = __builtin_bit_cast(h2, __builtin_amdgcn_raw_buffer_load_b32(sview, soff_l, so, 0));
+    dst[1] = __builtin_bit_cast(h2, __builtin_amdgcn_raw_buffer_load_b32(sview, soff_l + 64u, so, 0));
+  };
+
+  v4i acc[MT][4];  // [mt][2 * hf + b]
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[mt][q] = (v4i){0, 0, 0, 0};
+
+  v4u wr[RS][2];
+  v4u xr[XL][XPT];
+  h2 scr[GROUPED ? P : 1][2];
+  v4i x[MT];     // activation fragments of the current step; x[mt] is re-read for the next step right behind its last MFMA
+  v4i a[4];      // weight operands [2 * hf + b] of the current step, unpacked half a step ahead, in place
+  const unsigned xrd = (unsigned)((lane & 15) * 128);  // + mt * 2048; chunk = (4 * t + h) ^ ((row >> 1) & 7), row = 16 * mt + j
+  const int xsw = ((lane & 15) >> 1) & 7;
+  const unsigned xrd_t[2] = {xrd + (unsigned)(((0 + h) ^ xsw) << 4), xrd + (unsigned)(((4 + h) ^ xsw) << 4)};
+
+  auto read_x = [&](const int buf, const int t, const int mt) {
+    x[mt] = *reinterpret_cast<const v4i*>(smem + buf * XB + xrd_t[t] + mt * 2048);
+  };
+
+  // ---- the unpack of one 32-column half (hf) of a step, cut into pieces that are placed one by one between the MFMAs ----
+  // transpose: the two butterfly stages of quad_transpose4 (qqq_common.hip.h) as four 3-instruction pieces (lane masks kept
+  // in SGPR pairs, one s_mov_b64 into VCC per piece); pieces sit in different issue slots, which also covers the two wait
+  // states a DPP source needs behind the VALU that wrote it
+  unsigned z[4], y[4];
+  const unsigned long long km5 = 0x5555555555555555ull, kma = 0xaaaaaaaaaaaaaaaaull, km3 = 0x3333333333333333ull, kmc = 0xccccccccccccccccull;
+  auto tr_piece = [&](auto pc, const v4u& w) {
+    constexpr int pi = decltype(pc)::value;
+    (void)y[0];  // (odr-use outside the discarded branches: clang does not capture from inside them)
+    (void)z[0];
+    if constexpr (pi == 0)       // z0 = even ? w0 : w1',  z2 = even ? w2 : w3'
+      asm volatile("s_mov_b64 vcc, %6\n\t"
+                   "v_cndmask_b32_dpp %0, %3, %2, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                   "v_cndmask_b32_dpp %1, %5, %4, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+                   : "=&v"(z[0]), "=&v"(z[2]) : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "s"(km5) : "vcc");
+    else if constexpr (pi == 1)  // z1 = odd ? w1 : w0',  z3 = odd ? w3 : w2'
+      asm volatile("s_mov_b64 vcc, %6\n\t"
+                   "v_cndmask_b32_dpp %0, %2, %3, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                   "v_cndmask_b32_dpp %1, %4, %5, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+                   : "=&v"(z[1]), "=&v"(z[3]) : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "s"(kma) : "vcc");
+    else if constexpr (pi == 2)  // y0 = lo ? z0 : z2'',  y1 = lo ? z1 : z3''
+      asm volatile("s_mov_b64 vcc, %6\n\t"
+                   "v_cndmask_b32_dpp %0, %4, %2, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                   "v_cndmask_b32_dpp %1, %5, %3, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+                   : "=&v"(y[0]), "=&v"(y[1]) : "v"(z[0]), "v"(z[1]), "v"(z[2]), "v"(z[3]), "s"(km3) : "vcc");
+    else                         // y2 = hi ? z2 : z0'',  y3 = hi ? z3 : z1''
+      asm volatile("s_mov_b64 vcc, %6\n\t"
+                   "v_cndmask_b32_dpp %0, %2, %4, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                   "v_cndmask_b32_dpp %1, %3, %5, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+                   : "=&v"(y[2]), "=&v"(y[3]) : "v"(z[0]), "v"(z[1]), "v"(z[2]), "v"(z[3]), "s"(kmc) : "vcc");
+  };
+  // per-channel: 12 VALU (and | shift, and per packed word); per-group: 8 x dequant_group4 in 4 two-instruction parts
+  unsigned nmask = 0;          // per-channel: nibble mask of the half being unpacked (0 for a step past the end of K)
+  h2 sb[2];                    // per-group: the half's two group scales, broadcast (0 for a step past the end of K)
+  unsigned gt0 = 0, gt1 = 0;   // per-group: one re-quantisation in flight
+  h2 gha, ghb;
+  constexpr int UPARTS = GROUPED ? 32 : 12;
+  auto un_setup = [&](const h2 sc, const bool valid) {
+    if constexpr (GROUPED) {
+      const h2 zero = {(_Float16)0, (_Float16)0};
+      const h2 sv = valid ? sc : zero;  // scale 0 re-quantises every nibble to 0
+      sb[0] = (h2){sv[0], sv[0]};
+      sb[1] = (h2){sv[1], sv[1]};
+    } else {
+      nmask = valid ? QQQ_NIB_MASK : 0u;
+    }
+  };
+  auto un_part = [&](auto pc, auto hfc) {
+    constexpr int pi = decltype(pc)::value, hf = decltype(hfc)::value;
+    if constexpr (GROUPED) {
+      constexpr int it = pi / 4, part = pi % 4, kq = it / 2, b = it % 2;
+      if constexpr (part == 0) {
+        const unsigned qv = b ? (y[kq] >> 8) : y[kq];
+        const unsigned magic = qqq_fp16_1024x2();
+        gt0 = (qv & 0x000f000fu) | magic;  // {1024+p0, 1024+p4}
+        gt1 = (qv & 0x00f000f0u) | magic;  // {1024+16*p1, 1024+16*p5}
+      } else if constexpr (part == 1) {
+        const h2 c_sub = {(_Float16)-1032.0f, (_Float16)-1032.0f};
+        const h2 c_mul = {(_Float16)0.0625f, (_Float16)0.0625f};
+        const h2 c_add = {(_Float16)-72.0f, (_Float16)-72.0f};
+        gha = __builtin_bit_cast(h2, gt0) + c_sub;                                    // exact
+        ghb = __builtin_elementwise_fma(__builtin_bit_cast(h2, gt1), c_mul, c_add);  // exact
+      } else if constexpr (part == 2) {
+        const h2 c_mag = {(_Float16)1152.0f, (_Float16)1152.0f};
+        gha = __builtin_elementwise_fma(gha, sb[b], c_mag);
+        ghb = __builtin_elementwise_fma(ghb, sb[b], c_mag);
+      } else {
+        a[2 * hf + b][kq] = (int)(__builtin_amdgcn_perm(__builtin_bit_cast(unsigned, ghb), __builtin_bit_cast(unsigned, gha), 0x06040200u) ^ 0x80808080u);
+      }
+    } else {
+      constexpr int kq = pi / 3, part = pi % 3;
+      if constexpr (part == 0) a[2 * hf][kq] = (int)(y[kq] & nmask);         // odd nibbles  -> 16*w4 of column n      (b = 0)
+      else if constexpr (part == 1) gt0 = y[kq] << 4;
+      else a[2 * hf + 1][kq] = (int)(gt0 & nmask);                           // even nibbles -> 16*w4 of column n + 8  (b = 1)
+    }
+  };
+  // unpack piece of issue slot s (0..31) of a half-step: slots 0..3 the transpose pieces (+ the scale / mask set-up in
+  // slot 0), slots 4.. the UPARTS unpack parts (per-group: 32 parts over 28 slots)
+  auto un_slot = [&](auto sc_, auto hfc, const v4u& w, const h2 sc, const bool valid) {
+    constexpr int s_ = decltype(sc_)::value;
+    if constexpr (s_ < 4) {
+      if constexpr (s_ == 0) un_setup(sc, valid);
+      tr_piece(sc_, w);
+    } else {
+      constexpr int lo = GROUPED ? ((s_ - 4) * UPARTS + 27) / 28 : s_ - 4;
+      constexpr int hi = GROUPED ? ((s_ - 3) * UPARTS + 27) / 28 : s_ - 3;
+      if constexpr (lo < UPARTS) un_part(std::integral_constant<int, lo>{}, hfc);
+      if constexpr (hi - lo > 1 && lo + 1 < UPARTS) un_part(std::integral_constant<int, lo + 1>{}, hfc);
+    }
+  };
+  auto mfma = [&](v4i& c, const v4i& wa, const v4i& xb) {
+    // inline asm: the accumulator is updated IN PLACE in the accumulation registers.  (The builtin selects the untied
+    // form there, and with all 256 of them live hipcc's allocator bounces accumulators through VGPRs and scratch.)
+    asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+a"(c) : "v"(wa), "v"(xb));
+  };
+
+  // One 64-k step (stage i, half t of it; u = i % P and t compile-time at every call site).  While the matrix pipe works on
+  // column half 0 the wave unpacks THIS step's half 1; while it works on half 1, the NEXT step's half 0 -- refills the ring
+  // slot just emptied, and re-reads every activation fragment for the next step right behind its last MFMA.  The issue
+  // order is pinned slot by slot (sched_barrier): one MFMA (16 cycles of the matrix pipe = 4 issue slots of a lone wave)
+  // followed by at most three other instructions.  The stage's activation traffic goes into the first step: LDS image of
+  // stage i + LA out of the staging registers behind the unpack of half 0, loads of stage i + LA + XL behind that of half 1.
+  auto step = [&](const int i, const int u, auto tc) {
+    constexpr int t = decltype(tc)::value;
+    const int sl = (2 * u + t) % RS;            // ring slot of this step
+    const int sn = (sl + 1) % RS;               // ... of the next one
+    const int step_abs = 2 * i + t;
+    const int xs = (u + LA) % XL;
+    const int su0 = GROUPED ? u : 0, su1 = GROUPED ? ((t == 1) ? (u + 1) % P : u) : 0;
+    // ---- column half 0 ----
+    auto half0 = [&](auto mc) {
+      constexpr int mt = decltype(mc)::value;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        mfma(acc[mt][e], a[e], x[mt]);
+        if (e == 0) un_slot(std::integral_constant<int, 2 * mt>{}, std::integral_constant<int, 1>{}, wr[sl][1], scr[su0][1], step_abs < KS);
+        else un_slot(std::integral_constant<int, 2 * mt + 1>{}, std::integral_constant<int, 1>{}, wr[sl][1], scr[su0][1], step_abs < KS);
+        if constexpr (t == 0 && mt >= 12) {  // activation staging: 8 x ds_write_b128 behind the unpack
+          const int q = 2 * (mt - 12) + e;
+          *reinterpret_cast<v4u*>(smem + ((i + LA) % P) * XB + xdst + q * 4096) = xr[xs][q];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    qqq_static_for<MT>(half0);
+    // ---- column half 1 ----
+    const int st_x = i + LA + XL < NST ? i + LA + XL : NST - 1;
+    const unsigned xadj = (k_tail && st_x == NST - 1) ? xtail : 0u;
+    const unsigned xso = (unsigned)st_x * 128u;
+    auto half1 = [&](auto mc) {
+      constexpr int mt = decltype(mc)::value;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        mfma(acc[mt][2 + e], a[2 + e], x[mt]);
+        if (e == 0) un_slot(std::integral_constant<int, 2 * mt>{}, std::integral_constant<int, 0>{}, wr[sn][0], scr[su1][0], step_abs + 1 < KS);
+        else un_slot(std::integral_constant<int, 2 * mt + 1>{}, std::integral_constant<int, 0>{}, wr[sn][0], scr[su1][0], step_abs + 1 < KS);
+        if (e == 1) read_x(t == 0 ? (i % P) : ((i + 1) % P), t == 0 ? 1 : 0, mt);  // the next step's fragment, in place
+        if constexpr (t == 0 && mt >= 8)
+          if (e == 0) xr[xs][mt - 8] = wide_load16(xview, xoff[mt - 8] - xadj, xso);  // activation staging
+        if (e == 1 && mt == 8) load_w(step_abs + RS, wr[sl]);  // ring refill (both halves of this slot are consumed)
+        if constexpr (GROUPED)
+          if (t == 1 && e == 1 && mt == 10) load_sc(i + P, scr[u]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    qqq_static_for<MT>(half1);
+  };
+
+  // ---- prologue: stages 0 and 1 go straight into LDS; the weight ring and the scales are issued before the wait for them ----
+  load_x(0, xr[0]);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int j = 0; j < RS; ++j) load_w(j, wr[j]);
+  if constexpr (GROUPED) {
+#pragma unroll
+    for (int j = 0; j < P; ++j) load_sc(j, scr[j]);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  store_x(0, xr[0]);
+  load_x(1, xr[0]);
+  __builtin_amdgcn_sched_barrier(0);
+  store_x(1 % P, xr[0]);
+#pragma unroll
+  for (int j = 0; j < XL; ++j) load_x(LA + j, xr[(LA + j) % XL]);
+  __syncthreads();
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) read_x(0, 0, mt);
+  {
+    const std::integral_constant<int, 0> hf0;
+    un_slot(std::integral_constant<int, 0>{}, hf0, wr[0][0], scr[0][0], 0 < KS);
+    un_slot(std::integral_constant<int, 1>{}, hf0, wr[0][0], scr[0][0], 0 < KS);
+    __builtin_amdgcn_sched_barrier(0);
+    un_slot(std::integral_constant<int, 2>{}, hf0, wr[0][0], scr[0][0], 0 < KS);
+    un_slot(std::integral_constant<int, 3>{}, hf0, wr[0][0], scr[0][0], 0 < KS);
+    __builtin_amdgcn_sched_barrier(0);
+    qqq_static_for<28>([&](auto sc_) { un_slot(std::integral_constant<int, decltype(sc_)::value + 4>{}, hf0, wr[0][0], scr[0][0], 0 < KS); });
+  }
+  __builtin_amdgcn_sched_barrier(0);
+
+  QQQ_TR(1);
+  // ---- steady state: P stages per iteration (ring slots and LDS buffers are compile-time), branch-free ----
+  int i0 = 0;
+  for (; i0 + P <= NST; i0 += P) {
+#ifdef QQQ_PANEL_TRACE
+    if (i0 < 12 * P) QQQ_TRV(4 + i0 / P, __builtin_amdgcn_s_memtime());  // shader clock at the top of the first 12 trips
+#endif
+#pragma unroll
+    for (int u = 0; u < P; ++u) {
+      step(i0 + u, u, std::integral_constant<int, 0>{});
+      step(i0 + u, u, std::integral_constant<int, 1>{});
+      __syncthreads();  // stage i + LA is in LDS for everybody; buffer (i % P) is free
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < P - 1; ++u)
+    if (i0 + u < NST) {
+      step(i0 + u, u, std::integral_constant<int, 0>{});
+      step(i0 + u, u, std::integral_constant<int, 1>{});
+      __syncthreads();
+    }
+
+  // ---- epilogue: EPR rows at a time: int32 -> LDS (row-major, skewed rows) -> 8 consecutive n per thread -> 16-byte stores ----
+  // D lane ln of the MFMA holds token j = ln & 15, rows 4 * (ln >> 4) + r -> c' = ln >> 4, jt = r:
+  //   column inside the strip  nl = 64 * wn + 16 * jt + 8 * b + 4 * hf + c'
+  QQQ_TR(2);
+  // (the MFMAs are inline asm: hipcc does not know that the accumulators it is about to read were written by the matrix pipe)
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  int* ep = reinterpret_cast<int*>(smem);
+  const int ej = lane & 15, ecp = lane >> 4;
+  constexpr int EP_ITEMS = EPR * (BN / 8), EP_PASSES = EP_ITEMS / NT;  // 8
+  const int c8 = tid % (BN / 8), er0 = tid / (BN / 8);                 // this thread's 8 columns; rows er0 + 8 * ps
+  const int n = tile_n * BN + c8 * 8;
+  float2 s2v[4] = {};
+  h8 bv = {};
+  if (n < N) {
+    const int i0s = s2_stored_index(n), i1s = s2_stored_index(n + 4);
+    s2v[0] = *reinterpret_cast<const float2*>(s2 + i0s);
+    s2v[1] = *reinterpret_cast<const float2*>(s2 + i0s + 8);
+    s2v[2] = *reinterpret_cast<const float2*>(s2 + i1s);
+    s2v[3] = *reinterpret_cast<const float2*>(s2 + i1s + 8);
+    if (bias) bv = *reinterpret_cast<const h8*>(bias + n);
+  }
+#pragma unroll
+  for (int pass = 0; pass < ROWS / EPR; ++pass) {
+    if (pass) __syncthreads();
+#pragma unroll
+    for (int jm = 0; jm < EPR / 16; ++jm)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          ep[(16 * jm + ej) * EP_STRIDE + 64 * wn + 16 * r + 8 * (q & 1) + 4 * (q >> 1) + ecp] = acc[pass * (EPR / 16) + jm][q][r];
+    __syncthreads();
+    float a_s[EP_PASSES];
+#pragma unroll
+    for (int ps = 0; ps < EP_PASSES; ++ps) {
+      const int m = mbase + pass * EPR + er0 + 8 * ps;
+      a_s[ps] = s1[m < M ? m : M - 1];
+    }
+#pragma unroll
+    for (int ps = 0; ps < EP_PASSES; ++ps) {
+      const int row = er0 + 8 * ps;
+      const int m = mbase + pass * EPR + row;
+      if (m < M && n < N) {
+        const v4i lo = *reinterpret_cast<const v4i*>(ep + row * EP_STRIDE + c8 * 8);
+        const v4i hi4 = *reinterpret_cast<const v4i*>(ep + row * EP_STRIDE + c8 * 8 + 4);
+        const h4 o0 = epilogue_vals4(lo[0], lo[1], lo[2], lo[3], a_s[ps], s2v[0], s2v[1]);
+        const h4 o1 = epilogue_vals4(hi4[0], hi4[1], hi4[2], hi4[3], a_s[ps], s2v[2], s2v[3]);
+        h8 o = {o0[0], o0[1], o0[2], o0[3], o1[0], o1[1], o1[2], o1[3]};
+        if (bias) o = o + bv;  // fp16 add after the fp16 round
+        *reinterpret_cast<h8*>(D + (size_t)m * N + n) = o;
+        if (acc_out) {
+          *reinterpret_cast<v4i*>(acc_out + (size_t)m * N + n) = lo;
+          *reinterpret_cast<v4i*>(acc_out + (size_t)m * N + n + 4) = hi4;
+        }
+      }
+    }
+  }
+#ifdef QQQ_PANEL_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  QQQ_TR(3);
+#endif
+}
+
+#endif  // QQQ_AMD_QQQ_WIDE_HIP_H_

@@ -38,3 +38,13 @@ def layer_inputs(group_size, N=N_FULL, K=K_FULL):
 def c0_tokens(M=16, K=K_FULL):
     rng = np.random.Generator(np.random.PCG64(C0_SEED))
     return rng.standard_normal((M, K), dtype=np.float32).astype(np.float16)
+
+
+SWEEP_SEED = 2025_0904
+SWEEP_MS = (1, 16, 128, 1024, 4096)  # BASELINE configs[1] / configs[2]
+
+
+def sweep_tokens(M=4096, K=K_FULL):
+    """tokens of the pinned BASELINE sweep: the sweep's M values are row prefixes of this draw"""
+    rng = np.random.Generator(np.random.PCG64(SWEEP_SEED))
+    return rng.standard_normal((M, K), dtype=np.float32).astype(np.float16)

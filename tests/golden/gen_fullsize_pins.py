@@ -12,7 +12,11 @@ The file also carries the BASELINE configs[0] pin ("single qqq_gemm call M=16 N=
 fake-quant reference"): digests of the oracle's int32 accumulators and fp16 outputs for that call, whose operands
 (`B`, `s_channel` from the reference's pack(), `xq`, `s1` from the reference's dynamic_quant()) are reference-produced.
 
-usage: python tests/golden/gen_fullsize_pins.py
+`sweep_per_channel` / `sweep_g128`: the same for BASELINE configs[1] / configs[2] -- M in {1, 16, 128, 1024, 4096} as row
+prefixes of one 4096-token draw, activations quantised by the reference's dynamic_quant, per-prefix digests of the oracle's
+accumulators and outputs (the -m gpu suite runs the HIP kernels on exactly these operands and compares digests).
+
+usage: python tests/golden/gen_fullsize_pins.py   (~15 minutes on 8 cores: two 4096-token oracle GEMMs)
 """
 import hashlib
 import json
@@ -68,6 +72,20 @@ def main():
                               "oracle_D": sha(D.view(np.uint16)), "max_abs_D": float(np.abs(D.astype(np.float32)).max()),
                               "max_abs_err_vs_fakequant": err}
             print("config0", out["config0"])
+        # BASELINE configs[1] / configs[2] on reference-made operands: the sweep's token counts (row prefixes of one
+        # 4096-token draw; rows are independent), activations quantised by the REFERENCE's dynamic_quant, weights
+        # from the REFERENCE's pack(); digests of the oracle's accumulators / outputs per prefix.  The -m gpu test
+        # test_gpu_parity.py::test_baseline_sweep_on_reference_operands_pinned holds the HIP kernels to them.
+        xs = FI.sweep_tokens()
+        xq, s1 = ql.dynamic_quant(torch.from_numpy(xs))
+        xq, s1 = xq.numpy(), s1.numpy()
+        D, acc = C.qqq_gemm(xq, B, s1, s_channel, s_group if gs != -1 else None, return_acc=True)
+        sw = {"in_x": sha(xs), "ref_xq": sha(xq), "ref_s1": sha(s1), "Ms": list(FI.SWEEP_MS)}
+        for M in FI.SWEEP_MS:
+            sw[f"oracle_acc_m{M}"] = sha(acc[:M])
+            sw[f"oracle_D_m{M}"] = sha(D[:M].view(np.uint16))
+        out["sweep_" + mode] = sw
+        print("sweep", mode, sw)
         del ql, lin, W_fq
     path = os.path.join(HERE, "fullsize_pins.json")
     json.dump(out, open(path, "w"), indent=1)

@@ -243,6 +243,53 @@ def test_baseline_sizes_against_oracle(grouped, dev):
     assert np.array_equal((D2.astype(np.float32) * 2)[fin], D.astype(np.float32)[fin])
 
 
+@pytest.mark.parametrize("gs,mode", [(-1, "per_channel"), (128, "g128")])
+def test_baseline_sweep_on_reference_operands_pinned(gs, mode, dev):
+    """BASELINE configs[1] / configs[2] on REFERENCE-MADE operands at full size (N=8192, K=21760): weights packed by the
+    reference's pack(), activations quantised by the reference's dynamic_quant() (digests in tests/golden/fullsize_pins.json,
+    made by tests/golden/gen_fullsize_pins.py in the build container); the HIP kernels -- automatic dispatch, plus the other
+    large-m families where they apply -- must reproduce the committed SHA-256 digests of the oracle's int32 accumulators
+    and fp16 outputs for every token count of the sweep."""
+    import hashlib
+    import json
+    import os
+
+    import fullsize_inputs as FI
+    from oracle import c_oracle as C
+    from qqq_amd import QuantLinear
+
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    pins = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "fullsize_pins.json")))
+    if "sweep_" + mode not in pins:
+        pytest.skip("fullsize_pins.json carries no sweep pins")
+    W_fq, scale, s_extra = FI.layer_inputs(gs)
+    xs = FI.sweep_tokens()
+    sw = pins["sweep_" + mode]
+    if sha(W_fq) != pins[mode]["in_W_fq"] or sha(scale) != pins[mode]["in_scale"] or sha(xs) != sw["in_x"]:
+        pytest.skip("numpy draws a different PCG64 normal stream than the pinned one: the pins do not apply")
+    lin = torch.nn.Linear(FI.K_FULL, FI.N_FULL, bias=False).half()
+    lin.weight.data = torch.from_numpy(W_fq)
+    ql = QuantLinear(4, gs, FI.K_FULL, FI.N_FULL, bias=False).to(dev)
+    ql.pack(lin.to(dev), torch.from_numpy(scale).to(dev), None if s_extra is None else torch.from_numpy(s_extra).to(dev))
+    assert sha(ql.B.cpu().numpy()) == pins[mode]["ref_B"] and sha(ql.s_channel.cpu().numpy()) == pins[mode]["ref_s_channel"]
+    assert sha(ql.s_group.cpu().numpy()) == pins[mode]["ref_s_group"]
+    xq, s1 = C.dynamic_quant(xs, "div")  # the reference expression as the CPU evaluates it -- checked against the reference's run
+    assert sha(xq) == sw["ref_xq"] and sha(s1) == sw["ref_s1"]
+    h = GemmHarness(ql.B, ql.s_channel, ql.s_group if gs != -1 else None, dev)
+    for M in sw["Ms"]:
+        tunes = [None]
+        if M >= 1024:
+            tunes += [dict(kernel=2), dict(kernel=4, bm=256, mt=8, pw=2), dict(kernel=5)]
+        elif M >= 128:
+            tunes += [dict(kernel=1), dict(kernel=4, bm=256)]
+        else:
+            tunes += [dict(kernel=1), dict(kernel=3)]
+        for tune in tunes:
+            D, acc = h.run(xq[:M], s1[:M], tune)
+            assert sha(acc) == sw[f"oracle_acc_m{M}"], (mode, M, tune)
+            assert sha(D.view(np.uint16)) == sw[f"oracle_D_m{M}"], (mode, M, tune)
+
+
 def test_llama7b_linear_shapes(dev):
     """BASELINE config 4 shapes (llama-2-7b linears), batch*seq rows subsampled for the CPU oracle."""
     from oracle import c_oracle as C
