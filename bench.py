@@ -295,8 +295,8 @@ def live_traffic(timeout_s=240):
                 if r["Counter_Name"] != c:
                     continue
                 name = r["Kernel_Name"]
-                # the child runs M=1 (decode: column / stream kernel, <= 512 workgroups) and M=4096 (tiled / panel)
-                big = any(k in name for k in ("qqq_tiled_kernel", "qqq_panel_kernel"))
+                # the child runs M=1 (decode: column / stream kernel, <= 512 workgroups) and M=4096 (wide / tiled / panel)
+                big = any(k in name for k in ("qqq_tiled_kernel", "qqq_panel_kernel", "qqq_wide_kernel"))
                 small = any(k in name for k in ("qqq_column_kernel", "qqq_stream_kernel"))
                 key = "tiled_m4096" if big else "column_m1" if small else None
                 if key:
@@ -390,7 +390,7 @@ def main():
             for j, M in enumerate(SWEEP_M):
                 if M in sharded:
                     sg, a_loc, s1_loc = sharded[M]
-                    sg(a_loc, s1_loc, M, N_FULL, Dfull[M])
+                    sg(a_loc, s1_loc, M, N_FULL, Dfull[M], local=True)
                 else:
                     A, s1 = toks[M]
                     ops.qqq_gemm(A, layer.Bs[j % NBUF], layer.C, Dfull[M], s1, layer.s2, layer.s3, layer.ws, -1, -1, -1, MAX_PAR)
@@ -531,7 +531,7 @@ def main():
                 "outliers_dropped": int(len(cold) - len(keep)),
                 "tops": algorithmic_ops(M, N_FULL, K_FULL) / us / 1e6,
                 "gbs": algorithmic_bytes(M, N_FULL, K_FULL) / us / 1e3,
-                "kernel": {1: "stream", 2: "tiled", 3: "column", 4: "panel"}[pln["kernel"]], "ksplit": pln["ksplit"],
+                "kernel": {1: "stream", 2: "tiled", 3: "column", 4: "panel", 5: "wide"}[pln["kernel"]], "ksplit": pln["ksplit"],
             }
             # the roof that binds this point: HBM below the ridge (~629 op/B), MFMA above
             hbm_us = algorithmic_bytes(M, N_FULL, K_FULL) / PEAK_HBM_GBS / 1e3
@@ -552,7 +552,7 @@ def main():
         live, traffic_note = ({}, "skipped (--no-pmc)") if args.no_pmc else live_traffic()
         a = per_m["4096"]
         sus = sustained_matrix_rate(dev)
-        fam = a["kernel"]  # the family the dispatcher runs at M=4096 ("panel": 64 columns per wave, or "tiled")
+        fam = a["kernel"]  # the family the dispatcher runs at M=4096 ("wide" since round 3; "panel" / "tiled" before)
         result["roofline"] = {
             "kernel": f"qqq_{fam}_kernel (M=4096)", "bound": "mfma", "achieved": a["tops"], "peak": PEAK_MFMA_TOPS,
             "unit": "TOPS", "frac": a["tops"] / PEAK_MFMA_TOPS,

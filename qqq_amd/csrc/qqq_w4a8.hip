@@ -339,7 +339,7 @@ static hipError_t launch_tiled(const LaunchArgs& a, bool grouped, int bm, int st
 
 template <bool GROUPED, int P, int XL, int RS>
 static hipError_t launch_wide_t(const LaunchArgs& a, int pw) {
-  constexpr int XBUF = P * 256 * 128, EP = 64 * (256 + 4) * 4;
+  constexpr int XBUF = P * 256 * 128, EP = 128 * (256 + 4) * 4;
   constexpr int LDS = XBUF > EP ? XBUF : EP;
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static bool attr_set[64] = {};  // per instantiation, per device
@@ -485,10 +485,20 @@ static double panel_estimate(int M, int N, int K, bool grouped, bool have_scratc
   return best;
 }
 
+// wide: 256 x 256 tiles, one per CU and round, no split-K: ~25 us per tile round of fixed cost (first operands from HBM with
+// every CU in its prologue at once, 130 KiB epilogue image, launch ramp) + 1.32 us per 128-k stage (per-group 1.66: the
+// re-quantiser of a lone wave is issue-bound); profiles/r03_wide_first_numbers.txt
+static double wide_estimate(int M, int N, int K, bool grouped) {
+  if ((long long)N * K / 2 >= (1ll << 32)) return 1e30;  // 32-bit offsets into the packed weights
+  const long long tl = (long long)((M + 255) / 256) * ((N + 255) / 256);
+  const int NST = (K / 64 + 1) / 2;
+  return 3.7 + (double)((tl + 255) / 256) * (25.0 + NST * (grouped ? 1.66 : 1.32));
+}
+
 // The dispatch decision of one call, as plain data (pure host logic: also exported as qqq_w4a8_plan so
 // that it can be inspected and tested without a GPU).
 struct Plan {
-  int kernel;  // 1 stream, 2 tiled, 3 column, 4 panel
+  int kernel;  // 1 stream, 2 tiled, 3 column, 4 panel, 5 wide
   int ksplit;
   int fused;   // stream: 1 / 3 in-launch, 2 separate reduce.  tiled: 1 in-launch slots, 2 slabs + reduce
   int mt, waves, pf;      // stream
@@ -525,7 +535,10 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
       const double e_panel = ((long long)(M + 127) / 128 <= 65535) ? panel_estimate(M, N, K, grouped, have_scratch && have_ws, cap_rows, cap_tk, &pbn, &pks, &pcw) : 1e30;
       const double e_stream = (M <= 256) ? stream_estimate(M, N, K, grouped) : 1e30;
       const double e_tiled = ((K % 128) == 0 && M > 64) ? tiled_estimate(M, N, K, grouped, have_scratch, cap_rows, cap_tk, false, &tbm, &tks) : 1e30;
-      if (e_panel <= e_stream && e_panel <= e_tiled) {
+      const double e_wide = (M > 256) ? wide_estimate(M, N, K, grouped) : 1e30;
+      if (e_wide < e_panel && e_wide < e_stream && e_wide < e_tiled) {
+        kernel = 5;
+      } else if (e_panel <= e_stream && e_panel <= e_tiled) {
         kernel = 4;
         if (t.bm == 0 && t.pw == 0 && t.mt == 0 && pcw == 2) t.pw = 2;
         if (t.bm == 0) t.bm = pbn;
@@ -544,7 +557,7 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
   if (kernel == 5) {
     // wide: 256 tokens x 256 columns per workgroup, 4 waves with 512 registers each, no split-K
     pl.stages = (t.stages == 3) ? 3 : 1;                  // activation register lead in stages
-    pl.pf = (t.pf == 3 || pl.stages == 3) ? 3 : 6;        // weight ring in 64-k steps
+    pl.pf = (t.pf == 6 && pl.stages != 3) ? 6 : 3;        // weight ring in 64-k steps (3: measured 1-5 % faster than 6)
     pl.pw = (t.pw == 4 || t.pw == 8 || t.pw == 16 || t.pw == 32) ? t.pw : 8;
     pl.ksplit = 1;
     pl.fused = 1;

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   static_assert((2 * P) % RS == 0, "weight ring (in 64-k steps) must divide the unroll period");
   constexpr int LA = 2;                  // stage i + LA is written to LDS during stage i (its buffer was last read in i - 1)
   static_assert(P == 3 && (P % XL) == 0, "ring periods");
-  constexpr int EPR = 64;                // rows per epilogue pass
+  constexpr int EPR = 128;               // rows per epilogue pass (int32 image: 128 x 260 x 4 B = 130 KiB of LDS)
   constexpr int EP_STRIDE = BN + 4;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -309,6 +309,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     qqq_static_for<MT>(half1);
   };
 
+  // ---- epilogue operands that do not depend on the accumulators: fetched here, 12 registers carried through the loop ----
+  const int c8 = tid % (BN / 8), er0 = tid / (BN / 8);  // epilogue: this thread's 8 columns; rows er0 + 8 * ps of a pass
+  const int n = tile_n * BN + c8 * 8;
+  float2 s2v[4] = {};
+  h8 bv = {};
+  if (n < N) {
+    const int i0s = s2_stored_index(n), i1s = s2_stored_index(n + 4);
+    s2v[0] = *reinterpret_cast<const float2*>(s2 + i0s);
+    s2v[1] = *reinterpret_cast<const float2*>(s2 + i0s + 8);
+    s2v[2] = *reinterpret_cast<const float2*>(s2 + i1s);
+    s2v[3] = *reinterpret_cast<const float2*>(s2 + i1s + 8);
+    if (bias) bv = *reinterpret_cast<const h8*>(bias + n);
+  }
+
   // ---- prologue: stages 0 and 1 go straight into LDS; the weight ring and the scales are issued before the wait for them ----
   load_x(0, xr[0]);
   __builtin_amdgcn_sched_barrier(0);
@@ -370,19 +384,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
   int* ep = reinterpret_cast<int*>(smem);
   const int ej = lane & 15, ecp = lane >> 4;
-  constexpr int EP_ITEMS = EPR * (BN / 8), EP_PASSES = EP_ITEMS / NT;  // 8
-  const int c8 = tid % (BN / 8), er0 = tid / (BN / 8);                 // this thread's 8 columns; rows er0 + 8 * ps
-  const int n = tile_n * BN + c8 * 8;
-  float2 s2v[4] = {};
-  h8 bv = {};
-  if (n < N) {
-    const int i0s = s2_stored_index(n), i1s = s2_stored_index(n + 4);
-    s2v[0] = *reinterpret_cast<const float2*>(s2 + i0s);
-    s2v[1] = *reinterpret_cast<const float2*>(s2 + i0s + 8);
-    s2v[2] = *reinterpret_cast<const float2*>(s2 + i1s);
-    s2v[3] = *reinterpret_cast<const float2*>(s2 + i1s + 8);
-    if (bias) bv = *reinterpret_cast<const h8*>(bias + n);
-  }
+  constexpr int EP_ITEMS = EPR * (BN / 8), EP_PASSES = EP_ITEMS / NT;  // 16 rows per thread and pass
+  // every token scale this thread needs, fetched up front (pass by pass each batch paid its own round trip)
+  float a_s[ROWS / EPR][EP_PASSES];
+#pragma unroll
+  for (int pass = 0; pass < ROWS / EPR; ++pass)
+#pragma unroll
+    for (int ps = 0; ps < EP_PASSES; ++ps) {
+      const int m = mbase + pass * EPR + er0 + 8 * ps;
+      a_s[pass][ps] = s1[m < M ? m : M - 1];
+    }
 #pragma unroll
   for (int pass = 0; pass < ROWS / EPR; ++pass) {
     if (pass) __syncthreads();
@@ -394,12 +405,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int r = 0; r < 4; ++r)
           ep[(16 * jm + ej) * EP_STRIDE + 64 * wn + 16 * r + 8 * (q & 1) + 4 * (q >> 1) + ecp] = acc[pass * (EPR / 16) + jm][q][r];
     __syncthreads();
-    float a_s[EP_PASSES];
-#pragma unroll
-    for (int ps = 0; ps < EP_PASSES; ++ps) {
-      const int m = mbase + pass * EPR + er0 + 8 * ps;
-      a_s[ps] = s1[m < M ? m : M - 1];
-    }
 #pragma unroll
     for (int ps = 0; ps < EP_PASSES; ++ps) {
       const int row = er0 + 8 * ps;
@@ -407,8 +412,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       if (m < M && n < N) {
         const v4i lo = *reinterpret_cast<const v4i*>(ep + row * EP_STRIDE + c8 * 8);
         const v4i hi4 = *reinterpret_cast<const v4i*>(ep + row * EP_STRIDE + c8 * 8 + 4);
-        const h4 o0 = epilogue_vals4(lo[0], lo[1], lo[2], lo[3], a_s[ps], s2v[0], s2v[1]);
-        const h4 o1 = epilogue_vals4(hi4[0], hi4[1], hi4[2], hi4[3], a_s[ps], s2v[2], s2v[3]);
+        const h4 o0 = epilogue_vals4(lo[0], lo[1], lo[2], lo[3], a_s[pass][ps], s2v[0], s2v[1]);
+        const h4 o1 = epilogue_vals4(hi4[0], hi4[1], hi4[2], hi4[3], a_s[pass][ps], s2v[2], s2v[3]);
         h8 o = {o0[0], o0[1], o0[2], o0[3], o1[0], o1[1], o1[2], o1[3]};
         if (bias) o = o + bv;  // fp16 add after the fp16 round
         *reinterpret_cast<h8*>(D + (size_t)m * N + n) = o;

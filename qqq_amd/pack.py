@@ -14,6 +14,8 @@ from . import _lib
 def _native(fn_name: str, src: torch.Tensor, dst: torch.Tensor, K: int, N: int, grouped: bool) -> None:
     L = _lib.lib()
     on_dev = src.is_cuda
+    if src.data_ptr() % 8:  # a view at an odd storage offset: the native entry points want 8-byte aligned buffers
+        src = src.clone()
     stream = torch.cuda.current_stream(src.device).cuda_stream if on_dev else None
     rc = getattr(L, fn_name)(src.data_ptr(), dst.data_ptr(), K, N, int(grouped), int(on_dev),
                              (src.device.index or 0) if on_dev else 0, stream)

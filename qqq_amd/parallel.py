@@ -21,19 +21,41 @@ import torch
 import torch.distributed as dist
 
 
-def shard_rows(M: int, world: int, rank: int) -> Tuple[int, int]:
-    """Balanced contiguous row partition: the first M % world ranks get one extra row (chunks == 1 ownership is
-    `row_spans`, which pads instead; this helper remains for callers that want a plain balanced split)."""
-    base, extra = divmod(M, world)
-    start = rank * base + min(rank, extra)
-    return start, start + base + (1 if rank < extra else 0)
+# xGMI / GEMM cost model of the chunk choice: a ring all-gather moves (world-1)/world of the
+# output through every GPU's links; one link carries ~153 GB/s per direction.  The GEMM of r rows on the BASELINE layer takes
+# ~ 25 us + r * 0.125 us from a few hundred rows up (profiles/r02_dispatch_check*.txt, r03_*: 60 us at 256 rows, 148 at 1024,
+# 265 at 2048, 500 at 4096), scaled by the layer's N*K.
+XGMI_LINK_GBS = 153.0
 
 
-def pick_chunks(M: int, N: int, world: int) -> int:
-    """Chunks of the pipeline: a chunk must stay a LARGE-m GEMM (>= 1024 rows per rank: below that the GEMM loses more
-    efficiency than the overlap wins back, profiles/) -- so small shards go in one piece, big ones in up to 4."""
-    rows = -(-M // max(world, 1))
-    return max(1, min(4, rows // 1024))
+def gemm_us_model(rows: int, N: int, K: int) -> float:
+    scale = (N * K) / (8192.0 * 21760.0)
+    return (25.0 + 0.125 * max(rows, 0)) * scale if rows > 0 else 0.0
+
+
+def allgather_us_model(rows_per_rank: int, N: int, world: int) -> float:
+    """ring all-gather of `rows_per_rank` fp16 rows per rank: (world-1) steps, each moving one piece over one link"""
+    return 20.0 + (world - 1) * rows_per_rank * N * 2 / (XGMI_LINK_GBS * 1e3)
+
+
+def pick_chunks(M: int, N: int, world: int, K: int = 21760) -> int:
+    """Chunks of the GEMM / all-gather pipeline, from the cost model above: with c chunks the step takes about
+    gemm(first chunk) + (c - 1) * max(gemm(chunk), gather(chunk)) + gather(last chunk); every extra chunk costs the GEMM's
+    fixed part once more.  The chunk count with the smallest estimate wins; a chunk never drops below 256 rows per rank
+    (a full panel-kernel m-block pair -- below that the GEMM stops being a large-m GEMM)."""
+    if world <= 1 or M <= 0:
+        return 1
+    rows = -(-M // world)
+    best, best_us = 1, None
+    for c in (1, 2, 3, 4):
+        w = -(-rows // c)
+        if c > 1 and w < 256:
+            break
+        g, a = gemm_us_model(w, N, K), allgather_us_model(w, N, world)
+        us = g + (c - 1) * max(g, a) + a
+        if best_us is None or us < best_us * 0.98:  # a further chunk must pay for itself
+            best, best_us = c, us
+    return best
 
 
 def row_spans(M: int, world: int, rank: int, chunks: int) -> List[Tuple[int, int]]:
@@ -60,8 +82,10 @@ class ShardedGemm:
     """D_full[M,N] = all_gather_rows( gemm(A_local) ) with the chunk-cyclic row ownership of `row_spans`.
 
     gemm_fn(a_rows, s1_rows, d_rows_out) computes one contiguous block of local rows in place (the product passes a
-    closure over qqq_amd.qqq_gemm; the CPU/gloo tests pass the oracle).  A_local / s1_local hold this rank's rows in
-    span order (`take_rows`).
+    closure over qqq_amd.qqq_gemm; the CPU/gloo tests pass the oracle).  The inputs are either the REPLICATED [M_total, ..]
+    tensors (sliced here -- the form to prefer: the ownership is not a contiguous shard, and a caller that cut its own
+    contiguous shard would get rows of D_full in the wrong places) or this rank's rows in span order, made with
+    `take_rows(t, sg.spans(M_total, N))` and passed with `local=True`.
     """
 
     def __init__(self, gemm_fn: Callable, group: Optional[dist.ProcessGroup] = None, chunks: Optional[int] = None,
@@ -77,13 +101,21 @@ class ShardedGemm:
         chunks = self.chunks if self.chunks else pick_chunks(M_total, N, world)
         return row_spans(M_total, world, dist.get_rank(self.group), chunks)
 
-    def __call__(self, A_local: torch.Tensor, s1_local: torch.Tensor, M_total: int, N: int,
-                 D_full: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def __call__(self, A: torch.Tensor, s1: torch.Tensor, M_total: int, N: int,
+                 D_full: Optional[torch.Tensor] = None, local: bool = False) -> torch.Tensor:
         world = dist.get_world_size(self.group)
         rank = dist.get_rank(self.group)
         chunks = self.chunks if self.chunks else pick_chunks(M_total, N, world)
         spans = row_spans(M_total, world, rank, chunks)
-        assert A_local.shape[0] == sum(e - s for s, e in spans), (A_local.shape, spans)
+        if local:
+            A_local, s1_local = A, s1
+            if A_local.shape[0] != sum(e - s for s, e in spans):
+                raise ValueError(f"ShardedGemm: {A_local.shape[0]} local rows, but this rank owns the spans {spans} (take_rows)")
+        else:
+            if A.shape[0] != M_total or s1.shape[0] != M_total:
+                raise ValueError(f"ShardedGemm: expected the replicated [{M_total}, ...] inputs (got {A.shape[0]} rows); rows cut by "
+                                 "the caller must follow `spans()` and be passed with local=True")
+            A_local, s1_local = take_rows(A, spans), take_rows(s1, spans)
         dev = A_local.device
         w = -(-M_total // (world * chunks)) if M_total > 0 else 0
         if D_full is None:

@@ -61,7 +61,7 @@ class QuantLinear(nn.Module):
         else:
             self.bias = None
 
-    def _apply(self, fn):
+    def _apply(self, fn, recurse=True):
         # Keep scale dtypes pinned across .half()/.to() (qlinear_marlin.py:141-145) -- and the bias: the fused epilogue
         # reads it as fp16 bits, and the reference's own `prepare_for_inference` does model.to(bf16/fp32).  Unlike the
         # reference's pin (cast there and back: fp32 -> bf16 -> fp32 rounds the scales to 8 bits), the stored VALUES are
@@ -69,7 +69,7 @@ class QuantLinear(nn.Module):
         keep = {"s_group": self.s_group, "s_channel": self.s_channel}
         if self.bias is not None:
             keep["bias"] = self.bias
-        super()._apply(fn)
+        super()._apply(fn, recurse=recurse)
         for name, old in keep.items():
             cur = getattr(self, name)
             if cur.dtype != old.dtype:  # a dtype cast: take the original values to wherever the module now lives

@@ -108,8 +108,12 @@ def _check_plan(m, n, k, grouped, max_par):
 
     gs = 128 if grouped else -1
     p = _lib.plan(m, n, k, gs, max_par)
-    assert p["kernel"] in (1, 2, 3, 4) and p["ksplit"] >= 1
+    assert p["kernel"] in (1, 2, 3, 4, 5) and p["ksplit"] >= 1
     cap_rows, cap_tk = max_par * 64, (n // 128) * max_par
+    if p["kernel"] == 5:  # wide: 256 x 256 tiles, no split-K, no scratch at all; 32-bit offsets into the packed weights
+        assert m > 256 and n % 64 == 0 and k % 64 == 0 and p["ksplit"] == 1 and n * k // 2 < 2**32
+        assert p["pf"] in (3, 6) and p["stages"] in (1, 3) and p["pw"] in (4, 8, 16, 32)
+        return p
     if p["kernel"] == 4:  # panel: one slot of C per depositing slice, two ticket words per tile
         rows, bn = 16 * p["mt"], p["bm"]
         mblocks, strips = -(-m // rows), -(-n // bn)
@@ -180,9 +184,9 @@ def test_dispatch_plan_invariants_on_random_shapes(L):
 
 
 def test_dispatch_of_the_baseline_sweep(L):
-    """The families the cost models pick at the BASELINE layer (N=8192, K=21760), as measured in profiles/r02_dispatch_check*.txt:
-    decode -> column, a few tens of tokens -> stream, 128 tokens -> panel with 4 K slices, from ~768 tokens per-channel -> the
-    panel kernel with 64 columns per wave (pw = 2, no split), per-group from 2 K tokens -> the tiled column-owner tile."""
+    """The families the cost models pick at the BASELINE layer (N=8192, K=21760), as measured in profiles/r02_dispatch_check*.txt
+    and profiles/r03_*: decode -> column, a few tens of tokens -> stream, 128 tokens -> panel with 4 K slices, from ~768 tokens
+    -> the panel kernel with 64 columns per wave (pw = 2, no split), from ~1.5 K tokens -> the wide kernel (both modes)."""
     from qqq_amd import _lib
 
     N, K = 8192, 21760
@@ -190,14 +194,18 @@ def test_dispatch_of_the_baseline_sweep(L):
     assert _lib.plan(16, N, K, -1, 16)["kernel"] == 1
     p = _lib.plan(128, N, K, -1, 16)
     assert (p["kernel"], p["mt"], p["ksplit"]) == (4, 8, 4)
-    for m in (1024, 4096, 8192):
-        p = _lib.plan(m, N, K, -1, 16)
-        assert (p["kernel"], p["bm"], p["mt"], p["pw"], p["ksplit"]) == (4, 256, 8, 2, 1), (m, p)
-        g = _lib.plan(m, N, K, 128, 16)
-        if m >= 2048:  # per-group: the 64-column panel shape up to ~1 K tokens, the tiled column-owner tile above
-            assert g["kernel"] == 2 and g["bm"] == 258, (m, g)
-        else:
-            assert (g["kernel"], g["bm"], g["pw"]) == (4, 256, 2), (m, g)
+    # 1024 tokens (one round of 128 x 256 tiles): the panel kernel with 64 columns per wave, both modes
+    p, g = _lib.plan(1024, N, K, -1, 16), _lib.plan(1024, N, K, 128, 16)
+    assert (p["kernel"], p["bm"], p["mt"], p["pw"], p["ksplit"]) == (4, 256, 8, 2, 1), p
+    assert (g["kernel"], g["bm"], g["pw"]) == (4, 256, 2), g
+    # from ~1.5 K tokens (>= 3/4 of a round of 256 x 256 tiles) the wide kernel, both modes (round 3:
+    # profiles/r03_wide_first_numbers.txt -- M=4096 556 -> 500 us per-channel, 759 -> 618 us per-group)
+    for m in (1536, 2048, 4096, 8192):
+        for gs in (-1, 128):
+            p = _lib.plan(m, N, K, gs, 16)
+            assert (p["kernel"], p["ksplit"], p["pf"], p["stages"], p["pw"]) == (5, 1, 3, 1, 8), (m, gs, p)
+    assert _lib.plan(4096, N, K, -1, 16, tune=dict(kernel=5, pf=6))["pf"] == 6
+    assert _lib.plan(4096, N, K, -1, 16, tune=dict(kernel=5, stages=3, pf=6))["pf"] == 3  # both deep rings together spill
     # a forced 64-column shape is honoured only where it exists (128-token m-blocks, bm = 256, prefetch depth 3 or 4)
     assert _lib.plan(300, N, K, -1, 16, tune=dict(kernel=4, bm=256, mt=8, pw=2))["pw"] == 2
     assert _lib.plan(300, N, K, -1, 16, tune=dict(kernel=4, bm=128, mt=8, pw=2))["pw"] == 1

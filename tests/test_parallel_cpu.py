@@ -10,17 +10,26 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from qqq_amd.parallel import ShardedGemm, pick_chunks, row_spans, shard_rows, take_rows
+from qqq_amd.parallel import ShardedGemm, allgather_us_model, gemm_us_model, pick_chunks, row_spans, take_rows
 
 
-def test_shard_rows_partition():
-    for M in (0, 1, 7, 16, 4096, 4097):
-        for P in (1, 2, 3, 8):
-            spans = [shard_rows(M, P, r) for r in range(P)]
-            assert spans[0][0] == 0 and spans[-1][1] == M
-            assert all(spans[i][1] == spans[i + 1][0] for i in range(P - 1))
-            sizes = [b - a for a, b in spans]
-            assert max(sizes) - min(sizes) <= 1
+def test_pick_chunks_follows_the_cost_model():
+    """the BASELINE point M=4096: communication ~ compute at 4 and 8 GPUs -> the pipeline must have >= 2 chunks
+    there; a chunk never drops below 256 rows per rank; tiny shards go in one piece"""
+    assert pick_chunks(4096, 8192, 1) == 1
+    for P in (2, 4, 8):
+        c = pick_chunks(4096, 8192, P)
+        assert c >= 2 and -(-(4096 // P) // c) >= 256, (P, c)
+    assert pick_chunks(512, 8192, 8) == 1 and pick_chunks(128, 8192, 2) == 1
+    assert pick_chunks(32768, 4096, 2, K=4096) >= 2
+    # the model itself: the estimate of the chosen count is within 2 % of the best count's
+    for (M, N, P) in ((4096, 8192, 2), (4096, 8192, 8), (1024, 8192, 4), (32768, 11008, 8)):
+        def est(c):
+            w = -(-(-(-M // P)) // c)
+            g, a = gemm_us_model(w, N, 21760), allgather_us_model(w, N, P)
+            return g + (c - 1) * max(g, a) + a
+        feasible = [c for c in (1, 2, 3, 4) if c == 1 or -(-(-(-M // P)) // c) >= 256]
+        assert est(pick_chunks(M, N, P)) <= min(est(c) for c in feasible) * 1.021
 
 
 def test_row_spans_cover_every_row_once():
@@ -40,7 +49,6 @@ def test_row_spans_cover_every_row_once():
                             assert (owner[s:e] == -1).all()
                             owner[s:e] = r
                 assert (owner >= 0).all()
-    assert pick_chunks(4096, 8192, 8) == 1 and pick_chunks(4096, 8192, 2) == 2 and pick_chunks(32768, 4096, 2) == 4
     t = torch.arange(10).reshape(10, 1)
     assert take_rows(t, [(0, 2), (6, 8)]).flatten().tolist() == [0, 1, 6, 7]
 
@@ -79,12 +87,20 @@ def _worker(rank, world, port, M, chunks, q):
 
         sg = ShardedGemm(gemm_fn, chunks=chunks)
         spans = sg.spans(M, N)
-        D = sg(take_rows(torch.from_numpy(A), spans), take_rows(torch.from_numpy(s1), spans), M, N)
+        D = sg(torch.from_numpy(A), torch.from_numpy(s1), M, N)  # replicated inputs, sliced by ShardedGemm
         ok = np.array_equal(D.numpy().view(np.uint16), full.view(np.uint16))
-        # caller-owned output, called twice (scratch slab reuse)
+        # caller-owned output, rows cut by the caller along spans() (local=True), called twice (scratch slab reuse)
         D2 = torch.full((M, N), float("nan"), dtype=torch.float16)
-        sg(take_rows(torch.from_numpy(A), spans), take_rows(torch.from_numpy(s1), spans), M, N, D2)
+        sg(take_rows(torch.from_numpy(A), spans), take_rows(torch.from_numpy(s1), spans), M, N, D2, local=True)
         ok = ok and np.array_equal(D2.numpy().view(np.uint16), full.view(np.uint16))
+        # a contiguous shard cut by the caller (the pre-round-2 ownership) must fail loudly, not mis-order rows
+        if world > 1 and M >= world:
+            lo, hi = rank * M // world, (rank + 1) * M // world
+            try:
+                sg(torch.from_numpy(A[lo:hi]), torch.from_numpy(s1[lo:hi]), M, N)
+                ok = False
+            except ValueError:
+                pass
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
