@@ -337,13 +337,14 @@ static hipError_t launch_tiled(const LaunchArgs& a, bool grouped, int bm, int st
                  : launch_tiled_bm<false>(a, bm, stages, ksplit, nslots, pw);
 }
 
-template <bool GROUPED, int P, int XL, int RS>
+template <bool GROUPED, int MT, int P, int XL, int RS>
 static hipError_t launch_wide_t(const LaunchArgs& a, int pw) {
-  constexpr int XBUF = P * 256 * 128, EP = 128 * (256 + 4) * 4;
+  constexpr int ROWS = 16 * MT;
+  constexpr int XBUF = P * ROWS * 128, EP = (MT == 16 ? 128 : 64) * (256 + 4) * 4;
   constexpr int LDS = XBUF > EP ? XBUF : EP;
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static bool attr_set[64] = {};  // per instantiation, per device
-  auto kern = qqq_wide_kernel<GROUPED, P, XL, RS>;
+  auto kern = qqq_wide_kernel<GROUPED, MT, P, XL, RS>;
   int cur = 0;
   (void)hipGetDevice(&cur);
   if (cur < 0 || cur >= 64 || !attr_set[cur]) {
@@ -351,21 +352,25 @@ static hipError_t launch_wide_t(const LaunchArgs& a, int pw) {
     if (e != hipSuccess) return e;
     if (cur >= 0 && cur < 64) attr_set[cur] = true;
   }
-  const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256;
+  const int tiles_m = (a.M + ROWS - 1) / ROWS, tiles_n = (a.N + 255) / 256;
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), LDS, a.stream, a.A, a.B, a.D, a.s1, a.s2, a.s3, a.acc_out,
                      a.bias, a.M, a.N, a.K, tiles_m, tiles_n, pw);
   return hipGetLastError();
 }
 
-// pf: weight ring in 64-k steps (3 or 6); stages: activation register lead in 128-k stages (1 or 3; 3 only with pf = 3 --
-// both deep rings together spill inside the loop)
-static hipError_t launch_wide(const LaunchArgs& a, bool grouped, int pf, int stages, int pw) {
-  if (grouped) {
-    if (stages == 3) return launch_wide_t<true, 3, 3, 3>(a, pw);
-    return pf == 3 ? launch_wide_t<true, 3, 1, 3>(a, pw) : launch_wide_t<true, 3, 1, 6>(a, pw);
-  }
-  if (stages == 3) return launch_wide_t<false, 3, 3, 3>(a, pw);
-  return pf == 3 ? launch_wide_t<false, 3, 1, 3>(a, pw) : launch_wide_t<false, 3, 1, 6>(a, pw);
+// mt: 16 (256-token tiles) or 8 (128-token tiles, per-channel only in the automatic dispatch); pf: weight ring in 64-k steps
+// (3 or 6); stages: activation register lead in 128-k stages (1 or 3; 3 only with pf = 3 -- both deep rings together spill
+// inside the loop)
+template <bool GROUPED, int MT>
+static hipError_t launch_wide_m(const LaunchArgs& a, int pf, int stages, int pw) {
+#if !QQQ_WIDE_UNIFORM  // (the uniform slot schedule reloads its one staging register set chunk by chunk: a full stage of lead already)
+  if (stages == 3) return launch_wide_t<GROUPED, MT, 3, 3, 3>(a, pw);
+#endif
+  return pf == 3 ? launch_wide_t<GROUPED, MT, 3, 1, 3>(a, pw) : launch_wide_t<GROUPED, MT, 3, 1, 6>(a, pw);
+}
+static hipError_t launch_wide(const LaunchArgs& a, bool grouped, int mt, int pf, int stages, int pw) {
+  if (mt == 8) return grouped ? launch_wide_m<true, 8>(a, pf, stages, pw) : launch_wide_m<false, 8>(a, pf, stages, pw);
+  return grouped ? launch_wide_m<true, 16>(a, pf, stages, pw) : launch_wide_m<false, 16>(a, pf, stages, pw);
 }
 
 static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -485,14 +490,14 @@ static double panel_estimate(int M, int N, int K, bool grouped, bool have_scratc
   return best;
 }
 
-// wide: 256 x 256 tiles, one per CU and round, no split-K: ~25 us per tile round of fixed cost (first operands from HBM with
-// every CU in its prologue at once, 130 KiB epilogue image, launch ramp) + 1.32 us per 128-k stage (per-group 1.66: the
-// re-quantiser of a lone wave is issue-bound); profiles/r03_wide_first_numbers.txt
+// wide: 256 x 256 tiles, one per CU and round, no split-K: ~12 us per tile round of fixed cost (first operands from HBM with
+// every CU in its prologue at once ~4 us, epilogue ~7 us) + 1.34 us per 128-k stage (per-group 1.76: the re-quantiser of a
+// lone wave is issue-bound); profiles/r03_wide_uniform_schedule.txt, r03_wide_timeline.txt
 static double wide_estimate(int M, int N, int K, bool grouped) {
   if ((long long)N * K / 2 >= (1ll << 32)) return 1e30;  // 32-bit offsets into the packed weights
   const long long tl = (long long)((M + 255) / 256) * ((N + 255) / 256);
   const int NST = (K / 64 + 1) / 2;
-  return 3.7 + (double)((tl + 255) / 256) * (25.0 + NST * (grouped ? 1.66 : 1.32));
+  return 3.7 + (double)((tl + 255) / 256) * (12.0 + NST * (grouped ? 1.76 : 1.34));
 }
 
 // The dispatch decision of one call, as plain data (pure host logic: also exported as qqq_w4a8_plan so
@@ -556,7 +561,8 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
 
   if (kernel == 5) {
     // wide: 256 tokens x 256 columns per workgroup, 4 waves with 512 registers each, no split-K
-    pl.stages = (t.stages == 3) ? 3 : 1;                  // activation register lead in stages
+    pl.mt = (t.mt == 8) ? 8 : 16;                         // 16-token m-tiles per workgroup: 256- or 128-token tiles
+    pl.stages = (t.stages == 3 && !QQQ_WIDE_UNIFORM) ? 3 : 1;  // activation register lead in stages (first schedule only)
     pl.pf = (t.pf == 6 && pl.stages != 3) ? 6 : 3;        // weight ring in 64-k steps (3: measured 1-5 % faster than 6)
     pl.pw = (t.pw == 4 || t.pw == 8 || t.pw == 16 || t.pw == 32) ? t.pw : 8;
     pl.ksplit = 1;
@@ -783,7 +789,7 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
     return QQQ_ERR_ARG;
   }
   if (pl.kernel == 5) {
-    e = launch_wide(a, grouped, pl.pf, pl.stages, pl.pw);
+    e = launch_wide(a, grouped, pl.mt, pl.pf, pl.stages, pl.pw);
     if (e != hipSuccess) return fail_hip(e, "qqq_wide_kernel launch");
     reduce_launch = false;
   } else if (pl.kernel == 4) {

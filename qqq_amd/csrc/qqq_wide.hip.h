@@ -26,6 +26,21 @@
 // s_off): no 64-bit per-lane address arithmetic on the issue port the MFMAs share.
 // ------------------------------------------------------------------------------------------
 
+// Measurement only (tools/ablate_wide.sh): -DQQQ_WIDE_ABLATE=<bits> removes parts of the steady-state loop -- 1 stage-end
+// barrier, 2 activation staging, 4 transpose + unpack VALU, 8 weight-ring refill, 16 LDS fragment reads.  Results are wrong
+// by construction; never defined in a shipped build.
+#ifndef QQQ_WIDE_ABLATE
+#define QQQ_WIDE_ABLATE 0
+#endif
+// 1 (shipped): the uniform slot schedule -- the MFMAs of a step run m-tile by m-tile (all four column sets of an m-tile back
+// to back), the NEXT step's weight operands are unpacked into a second register set over the whole step, and the fragment
+// re-reads, the activation staging (ds_write + reload, chunk by chunk) and the ring refills are spread evenly over the step,
+// so the four lock-stepped waves of a workgroup never burst the LDS store path or the vector-memory issue together.
+// 0: the first version (two column halves per step, operands unpacked half a step ahead in place, staging in a burst).
+#ifndef QQQ_WIDE_UNIFORM
+#define QQQ_WIDE_UNIFORM 1
+#endif
+
 // f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>), in order: compile-time indices for hand-placed code
 template <int... S, class F>
 __device__ __forceinline__ void qqq_static_for(std::integer_sequence<int, S...>, F&& f) {
@@ -43,22 +58,22 @@ __device__ __forceinline__ v4u wide_load16(__amdgpu_buffer_rsrc_t view, const un
   return __builtin_amdgcn_raw_buffer_load_b128(view, voff, soff, 0);
 }
 
-template <bool GROUPED, int P, int XL, int RS>
+template <bool GROUPED, int MT, int P, int XL, int RS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void qqq_wide_kernel(
     const int8_t* __restrict__ A, const unsigned char* __restrict__ B, _Float16* __restrict__ D,
     const float* __restrict__ s1, const float* __restrict__ s2, const _Float16* __restrict__ s3,
     int32_t* __restrict__ acc_out, const _Float16* __restrict__ bias, const int M, const int N, const int K,
     const int tiles_m, const int tiles_n, const int PW) {
-  constexpr int MT = 16;                 // m-tiles of 16 tokens per wave (= per workgroup)
-  constexpr int ROWS = 16 * MT;          // 256 tokens
+  static_assert(MT == 16 || MT == 8, "m-tiles of 16 tokens per wave (= per workgroup): 256 or 128 tokens");
+  constexpr int ROWS = 16 * MT;
   constexpr int BN = 256;                // 4 waves x 64 columns
   constexpr int NT = 256;
   constexpr int XB = ROWS * 128;         // bytes of one activation stage (128 k)
-  constexpr int XPT = XB / 16 / NT;      // 8 16-byte chunks per thread and stage
+  constexpr int XPT = XB / 16 / NT;      // 16-byte chunks per thread and stage (8 / 4)
   static_assert((2 * P) % RS == 0, "weight ring (in 64-k steps) must divide the unroll period");
   constexpr int LA = 2;                  // stage i + LA is written to LDS during stage i (its buffer was last read in i - 1)
   static_assert(P == 3 && (P % XL) == 0, "ring periods");
-  constexpr int EPR = 128;               // rows per epilogue pass (int32 image: 128 x 260 x 4 B = 130 KiB of LDS)
+  constexpr int EPR = (MT == 16) ? 128 : 64;  // rows per epilogue pass (int32 image: EPR x 260 x 4 B = 130 / 65 KiB of LDS)
   constexpr int EP_STRIDE = BN + 4;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -152,7 +167,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   v4u xr[XL][XPT];
   h2 scr[GROUPED ? P : 1][2];
   v4i x[MT];     // activation fragments of the current step; x[mt] is re-read for the next step right behind its last MFMA
-  v4i a[4];      // weight operands [2 * hf + b] of the current step, unpacked half a step ahead, in place
+  v4i aop[2][4]; // weight operands [set][2 * hf + b]: the current step's and (uniform schedule) the next step's
   const unsigned xrd = (unsigned)((lane & 15) * 128);  // + mt * 2048; chunk = (4 * t + h) ^ ((row >> 1) & 7), row = 16 * mt + j
   const int xsw = ((lane & 15) >> 1) & 7;
   const unsigned xrd_t[2] = {xrd + (unsigned)(((0 + h) ^ xsw) << 4), xrd + (unsigned)(((4 + h) ^ xsw) << 4)};
@@ -208,7 +223,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       nmask = valid ? QQQ_NIB_MASK : 0u;
     }
   };
-  auto un_part = [&](auto pc, auto hfc) {
+  auto un_part = [&](auto pc, auto hfc, v4i (&a)[4]) {
     constexpr int pi = decltype(pc)::value, hf = decltype(hfc)::value;
     if constexpr (GROUPED) {
       constexpr int it = pi / 4, part = pi % 4, kq = it / 2, b = it % 2;
@@ -237,18 +252,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       else a[2 * hf + 1][kq] = (int)(gt0 & nmask);                           // even nibbles -> 16*w4 of column n + 8  (b = 1)
     }
   };
-  // unpack piece of issue slot s (0..31) of a half-step: slots 0..3 the transpose pieces (+ the scale / mask set-up in
-  // slot 0), slots 4.. the UPARTS unpack parts (per-group: 32 parts over 28 slots)
+  // unpack piece of issue slot s (0 .. 2 MT - 1) of a half-step: slots 0..3 the transpose pieces (+ the scale / mask set-up
+  // in slot 0), the remaining NSL slots share the UPARTS unpack parts evenly
+  constexpr int NSL = 2 * MT - 4;
   auto un_slot = [&](auto sc_, auto hfc, const v4u& w, const h2 sc, const bool valid) {
+    v4i (&a)[4] = aop[0];
     constexpr int s_ = decltype(sc_)::value;
-    if constexpr (s_ < 4) {
+    if constexpr ((QQQ_WIDE_ABLATE & 4) != 0) {
+      if constexpr (s_ == 0) { a[0] = a[1] = a[2] = a[3] = (v4i){(int)w[0], (int)w[1], (int)w[2], (int)w[3]}; }
+    } else if constexpr (s_ < 4) {
       if constexpr (s_ == 0) un_setup(sc, valid);
       tr_piece(sc_, w);
     } else {
-      constexpr int lo = GROUPED ? ((s_ - 4) * UPARTS + 27) / 28 : s_ - 4;
-      constexpr int hi = GROUPED ? ((s_ - 3) * UPARTS + 27) / 28 : s_ - 3;
-      if constexpr (lo < UPARTS) un_part(std::integral_constant<int, lo>{}, hfc);
-      if constexpr (hi - lo > 1 && lo + 1 < UPARTS) un_part(std::integral_constant<int, lo + 1>{}, hfc);
+      constexpr int lo = ((s_ - 4) * UPARTS + NSL - 1) / NSL;
+      constexpr int hi = ((s_ - 3) * UPARTS + NSL - 1) / NSL;
+      qqq_static_for<(hi > lo ? hi - lo : 0)>([&](auto pc) {
+        constexpr int pi = lo + decltype(pc)::value;
+        if constexpr (pi < UPARTS) un_part(std::integral_constant<int, pi>{}, hfc, a);
+      });
     }
   };
   auto mfma = [&](v4i& c, const v4i& wa, const v4i& xb) {
@@ -263,23 +284,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // order is pinned slot by slot (sched_barrier): one MFMA (16 cycles of the matrix pipe = 4 issue slots of a lone wave)
   // followed by at most three other instructions.  The stage's activation traffic goes into the first step: LDS image of
   // stage i + LA out of the staging registers behind the unpack of half 0, loads of stage i + LA + XL behind that of half 1.
-  auto step = [&](const int i, const int u, auto tc) {
-    constexpr int t = decltype(tc)::value;
+  auto step = [&](const int i, auto uc, auto tc) __attribute__((always_inline)) {
+    constexpr int t = decltype(tc)::value, u = decltype(uc)::value;
     const int sl = (2 * u + t) % RS;            // ring slot of this step
     const int sn = (sl + 1) % RS;               // ... of the next one
     const int step_abs = 2 * i + t;
     const int xs = (u + LA) % XL;
     const int su0 = GROUPED ? u : 0, su1 = GROUPED ? ((t == 1) ? (u + 1) % P : u) : 0;
     // ---- column half 0 ----
-    auto half0 = [&](auto mc) {
+    auto half0 = [&](auto mc) __attribute__((always_inline)) {
       constexpr int mt = decltype(mc)::value;
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        mfma(acc[mt][e], a[e], x[mt]);
+        mfma(acc[mt][e], aop[0][e], x[mt]);
         if (e == 0) un_slot(std::integral_constant<int, 2 * mt>{}, std::integral_constant<int, 1>{}, wr[sl][1], scr[su0][1], step_abs < KS);
         else un_slot(std::integral_constant<int, 2 * mt + 1>{}, std::integral_constant<int, 1>{}, wr[sl][1], scr[su0][1], step_abs < KS);
-        if constexpr (t == 0 && mt >= 12) {  // activation staging: 8 x ds_write_b128 behind the unpack
-          const int q = 2 * (mt - 12) + e;
+        if constexpr (t == 0 && mt >= MT - XPT / 2 && !(QQQ_WIDE_ABLATE & 2)) {  // activation staging: XPT x ds_write_b128 in the last slots
+          const int q = 2 * (mt - (MT - XPT / 2)) + e;
           *reinterpret_cast<v4u*>(smem + ((i + LA) % P) * XB + xdst + q * 4096) = xr[xs][q];
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -290,23 +311,73 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int st_x = i + LA + XL < NST ? i + LA + XL : NST - 1;
     const unsigned xadj = (k_tail && st_x == NST - 1) ? xtail : 0u;
     const unsigned xso = (unsigned)st_x * 128u;
-    auto half1 = [&](auto mc) {
+    auto half1 = [&](auto mc) __attribute__((always_inline)) {
       constexpr int mt = decltype(mc)::value;
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        mfma(acc[mt][2 + e], a[2 + e], x[mt]);
+        mfma(acc[mt][2 + e], aop[0][2 + e], x[mt]);
         if (e == 0) un_slot(std::integral_constant<int, 2 * mt>{}, std::integral_constant<int, 0>{}, wr[sn][0], scr[su1][0], step_abs + 1 < KS);
         else un_slot(std::integral_constant<int, 2 * mt + 1>{}, std::integral_constant<int, 0>{}, wr[sn][0], scr[su1][0], step_abs + 1 < KS);
-        if (e == 1) read_x(t == 0 ? (i % P) : ((i + 1) % P), t == 0 ? 1 : 0, mt);  // the next step's fragment, in place
-        if constexpr (t == 0 && mt >= 8)
-          if (e == 0) xr[xs][mt - 8] = wide_load16(xview, xoff[mt - 8] - xadj, xso);  // activation staging
-        if (e == 1 && mt == 8) load_w(step_abs + RS, wr[sl]);  // ring refill (both halves of this slot are consumed)
+        if constexpr (!(QQQ_WIDE_ABLATE & 16))
+          if (e == 1) read_x(t == 0 ? (i % P) : ((i + 1) % P), t == 0 ? 1 : 0, mt);  // the next step's fragment, in place
+        if constexpr (t == 0 && mt >= MT - XPT && !(QQQ_WIDE_ABLATE & 2))
+          if (e == 0) xr[xs][mt - (MT - XPT)] = wide_load16(xview, xoff[mt - (MT - XPT)] - xadj, xso);  // activation staging
+        if constexpr (!(QQQ_WIDE_ABLATE & 8))
+          if (e == 1 && mt == MT / 2) load_w(step_abs + RS, wr[sl]);  // ring refill (both halves of this slot are consumed)
         if constexpr (GROUPED)
-          if (t == 1 && e == 1 && mt == 10) load_sc(i + P, scr[u]);
+          if (t == 1 && e == 1 && mt == MT / 2 + 2) load_sc(i + P, scr[u]);
         __builtin_amdgcn_sched_barrier(0);
       }
     };
     qqq_static_for<MT>(half1);
+  };
+
+  // The uniform slot schedule (QQQ_WIDE_UNIFORM): slot k of a step = MFMA (m-tile k / 4, column set k % 4) + its share of
+  // everything else.  Step s unpacks step s + 1 into the other operand set (2 x (4 transpose pieces + UPARTS parts), evenly
+  // over the 4 MT slots), re-reads fragment x[mt] for step s + 1 right behind its fourth MFMA, refills ring slot s % RS (read by
+  // the unpack that ran during step s - 1) with step s + RS, and moves one 16-byte chunk per thread of the activation stage
+  // every 16 slots: ds_write of stage i + LA, four slots later the reload of the same register for stage i + LA + 1.
+  auto step_u = [&](const int i, auto uc, auto tc) __attribute__((always_inline)) {
+    constexpr int t = decltype(tc)::value, u = decltype(uc)::value;
+    constexpr int cur = t, nxt = 1 - t;         // 2 P steps per trip: the step's parity is its t
+    constexpr int sl = (2 * u + t) % RS, sn = (sl + 1) % RS;
+    const int step_abs = 2 * i + t;
+    constexpr int su = GROUPED ? ((t == 1) ? (u + 1) % P : u) : 0;  // scales of the NEXT step's stage
+    const bool nvalid = step_abs + 1 < KS;
+    const int st_x = i + LA + 1 < NST ? i + LA + 1 : NST - 1;
+    const unsigned xadj = (k_tail && st_x == NST - 1) ? xtail : 0u;
+    const unsigned xso = (unsigned)st_x * 128u;
+    constexpr int NSLOT = 4 * MT, NI = 2 * (4 + UPARTS);
+    auto slot = [&](auto kc) __attribute__((always_inline)) {
+      constexpr int k = decltype(kc)::value, mt = k / 4, q = k % 4;
+      mfma(acc[mt][q], aop[cur][q], x[mt]);
+      if constexpr (!(QQQ_WIDE_ABLATE & 4)) {
+        constexpr int lo = (k * NI) / NSLOT, hi = ((k + 1) * NI) / NSLOT;
+        qqq_static_for<(hi - lo)>([&](auto jc) {
+          constexpr int it = lo + decltype(jc)::value;
+          constexpr int hf = it / (4 + UPARTS), w_ = it % (4 + UPARTS);
+          if constexpr (w_ < 4) {
+            if constexpr (w_ == 0) un_setup(scr[su][hf], nvalid);
+            tr_piece(std::integral_constant<int, w_>{}, wr[sn][hf]);
+          } else {
+            un_part(std::integral_constant<int, w_ - 4>{}, std::integral_constant<int, hf>{}, aop[nxt]);
+          }
+        });
+      } else if constexpr (k == 0) {
+        aop[nxt][0] = aop[nxt][1] = (v4i){(int)wr[sn][0][0], (int)wr[sn][0][1], (int)wr[sn][0][2], (int)wr[sn][0][3]};
+        aop[nxt][2] = aop[nxt][3] = (v4i){(int)wr[sn][1][0], (int)wr[sn][1][1], (int)wr[sn][1][2], (int)wr[sn][1][3]};
+      }
+      if constexpr (q == 3 && !(QQQ_WIDE_ABLATE & 16)) read_x(t == 0 ? (i % P) : ((i + 1) % P), t == 0 ? 1 : 0, mt);
+      if constexpr (!(QQQ_WIDE_ABLATE & 2)) {
+        constexpr int qi = (XPT / 2) * t + k / 16;  // this thread's chunk of the stage
+        if constexpr (k % 16 == 5) *reinterpret_cast<v4u*>(smem + ((i + LA) % P) * XB + xdst + qi * 4096) = xr[0][qi];
+        if constexpr (k % 16 == 9) xr[0][qi] = wide_load16(xview, xoff[qi] - xadj, xso);
+      }
+      if constexpr (k == 2 && !(QQQ_WIDE_ABLATE & 8)) load_w(step_abs + RS, wr[sl]);
+      if constexpr (GROUPED && t == 1 && k == 6) load_sc(i + P, scr[u]);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    qqq_static_for<NSLOT>(slot);
   };
 
   // ---- epilogue operands that do not depend on the accumulators: fetched here, 12 registers carried through the loop ----
@@ -343,7 +414,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   __syncthreads();
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) read_x(0, 0, mt);
-  {
+  if constexpr (QQQ_WIDE_UNIFORM) {  // both halves of step 0 into operand set 0
+    static_assert(!QQQ_WIDE_UNIFORM || XL == 1, "uniform schedule: one staging register set, reloaded chunk by chunk");
+    qqq_static_for<2>([&](auto hfc) {
+      constexpr int hf = decltype(hfc)::value;
+      un_setup(scr[0][hf], 0 < KS);
+      qqq_static_for<4>([&](auto pc) { tr_piece(pc, wr[0][hf]); __builtin_amdgcn_sched_barrier(0); });
+      qqq_static_for<UPARTS>([&](auto pc) { un_part(pc, hfc, aop[0]); });
+    });
+  } else {
     const std::integral_constant<int, 0> hf0;
     un_slot(std::integral_constant<int, 0>{}, hf0, wr[0][0], scr[0][0], 0 < KS);
     un_slot(std::integral_constant<int, 1>{}, hf0, wr[0][0], scr[0][0], 0 < KS);
@@ -351,10 +430,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     un_slot(std::integral_constant<int, 2>{}, hf0, wr[0][0], scr[0][0], 0 < KS);
     un_slot(std::integral_constant<int, 3>{}, hf0, wr[0][0], scr[0][0], 0 < KS);
     __builtin_amdgcn_sched_barrier(0);
-    qqq_static_for<28>([&](auto sc_) { un_slot(std::integral_constant<int, decltype(sc_)::value + 4>{}, hf0, wr[0][0], scr[0][0], 0 < KS); });
+    qqq_static_for<NSL>([&](auto sc_) { un_slot(std::integral_constant<int, decltype(sc_)::value + 4>{}, hf0, wr[0][0], scr[0][0], 0 < KS); });
   }
   __builtin_amdgcn_sched_barrier(0);
 
+  auto do_stage = [&](const int i, auto uc) __attribute__((always_inline)) {  // one 128-k stage: two steps and the barrier that publishes stage i + LA
+    if constexpr (QQQ_WIDE_UNIFORM) {
+      step_u(i, uc, std::integral_constant<int, 0>{});
+      step_u(i, uc, std::integral_constant<int, 1>{});
+    } else {
+      step(i, uc, std::integral_constant<int, 0>{});
+      step(i, uc, std::integral_constant<int, 1>{});
+    }
+    if constexpr (!(QQQ_WIDE_ABLATE & 1)) __syncthreads();  // stage i + LA is in LDS for everybody; buffer (i % P) is free
+  };
   QQQ_TR(1);
   // ---- steady state: P stages per iteration (ring slots and LDS buffers are compile-time), branch-free ----
   int i0 = 0;
@@ -362,20 +451,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #ifdef QQQ_PANEL_TRACE
     if (i0 < 12 * P) QQQ_TRV(4 + i0 / P, __builtin_amdgcn_s_memtime());  // shader clock at the top of the first 12 trips
 #endif
-#pragma unroll
-    for (int u = 0; u < P; ++u) {
-      step(i0 + u, u, std::integral_constant<int, 0>{});
-      step(i0 + u, u, std::integral_constant<int, 1>{});
-      __syncthreads();  // stage i + LA is in LDS for everybody; buffer (i % P) is free
-    }
+    qqq_static_for<P>([&](auto uc) __attribute__((always_inline)) { do_stage(i0 + decltype(uc)::value, uc); });
   }
-#pragma unroll
-  for (int u = 0; u < P - 1; ++u)
-    if (i0 + u < NST) {
-      step(i0 + u, u, std::integral_constant<int, 0>{});
-      step(i0 + u, u, std::integral_constant<int, 1>{});
-      __syncthreads();
-    }
+  qqq_static_for<P - 1>([&](auto uc) __attribute__((always_inline)) {  // ragged tail (< P stages)
+    if (i0 + decltype(uc)::value < NST) do_stage(i0 + decltype(uc)::value, uc);
+  });
 
   // ---- epilogue: EPR rows at a time: int32 -> LDS (row-major, skewed rows) -> 8 consecutive n per thread -> 16-byte stores ----
   // D lane ln of the MFMA holds token j = ln & 15, rows 4 * (ln >> 4) + r -> c' = ln >> 4, jt = r:

@@ -149,12 +149,19 @@ def _compiling(*tensors) -> bool:
     # trip of a Python custom op costs ~9 us per call -- more than a decode GEMM on a 4096x4096 layer takes on
     # the GPU (tools/host_overhead.py) -- so those calls go straight to the ctypes binding.
     # QQQ_AMD_FORCE_DISPATCHER=1 forces the dispatcher path everywhere.
-    if torch.compiler.is_compiling() or _FORCE_DISPATCHER or torch._C._len_torch_dispatch_stack() > 0:
+    if torch.compiler.is_compiling() or _FORCE_DISPATCHER or _dispatch_modes_active():
         return True
     for t in tensors:
         if t is not None and type(t) not in _PLAIN:
             return True
     return False
+
+
+_len_dispatch_stack = getattr(torch._C, "_len_torch_dispatch_stack", None)  # private: absent -> always the dispatcher path
+
+
+def _dispatch_modes_active() -> bool:
+    return True if _len_dispatch_stack is None else _len_dispatch_stack() > 0
 
 
 def qqq_gemm_bias(A, B, C, D, s1, s2, s3, workspace, bias, max_par=16) -> None:

@@ -112,7 +112,7 @@ def _check_plan(m, n, k, grouped, max_par):
     cap_rows, cap_tk = max_par * 64, (n // 128) * max_par
     if p["kernel"] == 5:  # wide: 256 x 256 tiles, no split-K, no scratch at all; 32-bit offsets into the packed weights
         assert m > 256 and n % 64 == 0 and k % 64 == 0 and p["ksplit"] == 1 and n * k // 2 < 2**32
-        assert p["pf"] in (3, 6) and p["stages"] in (1, 3) and p["pw"] in (4, 8, 16, 32)
+        assert p["pf"] in (3, 6) and p["stages"] in (1, 3) and p["pw"] in (4, 8, 16, 32) and p["mt"] in (8, 16)
         return p
     if p["kernel"] == 4:  # panel: one slot of C per depositing slice, two ticket words per tile
         rows, bn = 16 * p["mt"], p["bm"]
@@ -199,13 +199,14 @@ def test_dispatch_of_the_baseline_sweep(L):
     assert (p["kernel"], p["bm"], p["mt"], p["pw"], p["ksplit"]) == (4, 256, 8, 2, 1), p
     assert (g["kernel"], g["bm"], g["pw"]) == (4, 256, 2), g
     # from ~1.5 K tokens (>= 3/4 of a round of 256 x 256 tiles) the wide kernel, both modes (round 3:
-    # profiles/r03_wide_first_numbers.txt -- M=4096 556 -> 500 us per-channel, 759 -> 618 us per-group)
+    # profiles/r03_wide_*.txt -- M=4096 556 -> 478 us per-channel, 759 -> 620 us per-group)
     for m in (1536, 2048, 4096, 8192):
         for gs in (-1, 128):
             p = _lib.plan(m, N, K, gs, 16)
             assert (p["kernel"], p["ksplit"], p["pf"], p["stages"], p["pw"]) == (5, 1, 3, 1, 8), (m, gs, p)
     assert _lib.plan(4096, N, K, -1, 16, tune=dict(kernel=5, pf=6))["pf"] == 6
-    assert _lib.plan(4096, N, K, -1, 16, tune=dict(kernel=5, stages=3, pf=6))["pf"] == 3  # both deep rings together spill
+    assert _lib.plan(4096, N, K, -1, 16, tune=dict(kernel=5, stages=3))["stages"] == 1  # the uniform schedule has one staging set
+    assert _lib.plan(1024, N, K, -1, 16, tune=dict(kernel=5, mt=8))["mt"] == 8 and _lib.plan(1024, N, K, -1, 16, tune=dict(kernel=5))["mt"] == 16
     # a forced 64-column shape is honoured only where it exists (128-token m-blocks, bm = 256, prefetch depth 3 or 4)
     assert _lib.plan(300, N, K, -1, 16, tune=dict(kernel=4, bm=256, mt=8, pw=2))["pw"] == 2
     assert _lib.plan(300, N, K, -1, 16, tune=dict(kernel=4, bm=128, mt=8, pw=2))["pw"] == 1
@@ -223,5 +224,6 @@ def test_dispatch_of_the_baseline_sweep(L):
     assert p["kernel"] == 1 and p["ksplit"] == 2
     p = _lib.plan(192, 4096, 4096, -1, 16, tune=dict(kernel=1))
     assert p["ksplit"] * 3 * 32 <= 256
-    # short-K layers keep the tiled kernel at large m (per-tile fixed costs of the panel shape weigh more there)
-    assert _lib.plan(8192, 4096, 4096, -1, 16)["kernel"] == 2
+    # short-K layers at large m: the wide kernel since its uniform schedule (profiles/r03_wide_uniform_schedule.txt: 11008 x 4096,
+    # 32 K tokens 1174 vs 1429 us for the tiled kernel); the panel shapes' per-tile fixed costs weigh more there
+    assert _lib.plan(8192, 4096, 4096, -1, 16)["kernel"] == 5
