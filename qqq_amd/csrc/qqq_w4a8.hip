@@ -337,14 +337,14 @@ static hipError_t launch_tiled(const LaunchArgs& a, bool grouped, int bm, int st
                  : launch_tiled_bm<false>(a, bm, stages, ksplit, nslots, pw);
 }
 
-template <bool GROUPED, int MT, int P, int XL, int RS>
+template <bool GROUPED, int MT, int P, int RS>
 static hipError_t launch_wide_t(const LaunchArgs& a, int pw) {
   constexpr int ROWS = 16 * MT;
   constexpr int XBUF = P * ROWS * 128, EP = (MT == 16 ? 128 : 64) * (256 + 4) * 4;
   constexpr int LDS = XBUF > EP ? XBUF : EP;
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static bool attr_set[64] = {};  // per instantiation, per device
-  auto kern = qqq_wide_kernel<GROUPED, MT, P, XL, RS>;
+  auto kern = qqq_wide_kernel<GROUPED, MT, P, RS>;
   int cur = 0;
   (void)hipGetDevice(&cur);
   if (cur < 0 || cur >= 64 || !attr_set[cur]) {
@@ -358,19 +358,14 @@ static hipError_t launch_wide_t(const LaunchArgs& a, int pw) {
   return hipGetLastError();
 }
 
-// mt: 16 (256-token tiles) or 8 (128-token tiles, per-channel only in the automatic dispatch); pf: weight ring in 64-k steps
-// (3 or 6); stages: activation register lead in 128-k stages (1 or 3; 3 only with pf = 3 -- both deep rings together spill
-// inside the loop)
+// mt: 16 (256-token tiles) or 8 (128-token tiles); pf: weight ring in 64-k steps (3 or 6)
 template <bool GROUPED, int MT>
-static hipError_t launch_wide_m(const LaunchArgs& a, int pf, int stages, int pw) {
-#if !QQQ_WIDE_UNIFORM  // (the uniform slot schedule reloads its one staging register set chunk by chunk: a full stage of lead already)
-  if (stages == 3) return launch_wide_t<GROUPED, MT, 3, 3, 3>(a, pw);
-#endif
-  return pf == 3 ? launch_wide_t<GROUPED, MT, 3, 1, 3>(a, pw) : launch_wide_t<GROUPED, MT, 3, 1, 6>(a, pw);
+static hipError_t launch_wide_m(const LaunchArgs& a, int pf, int pw) {
+  return pf == 3 ? launch_wide_t<GROUPED, MT, 3, 3>(a, pw) : launch_wide_t<GROUPED, MT, 3, 6>(a, pw);
 }
-static hipError_t launch_wide(const LaunchArgs& a, bool grouped, int mt, int pf, int stages, int pw) {
-  if (mt == 8) return grouped ? launch_wide_m<true, 8>(a, pf, stages, pw) : launch_wide_m<false, 8>(a, pf, stages, pw);
-  return grouped ? launch_wide_m<true, 16>(a, pf, stages, pw) : launch_wide_m<false, 16>(a, pf, stages, pw);
+static hipError_t launch_wide(const LaunchArgs& a, bool grouped, int mt, int pf, int pw) {
+  if (mt == 8) return grouped ? launch_wide_m<true, 8>(a, pf, pw) : launch_wide_m<false, 8>(a, pf, pw);
+  return grouped ? launch_wide_m<true, 16>(a, pf, pw) : launch_wide_m<false, 16>(a, pf, pw);
 }
 
 static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -494,7 +489,7 @@ static double panel_estimate(int M, int N, int K, bool grouped, bool have_scratc
 // every CU in its prologue at once ~4 us, epilogue ~7 us) + 1.34 us per 128-k stage (per-group 1.76: the re-quantiser of a
 // lone wave is issue-bound); profiles/r03_wide_uniform_schedule.txt, r03_wide_timeline.txt
 static double wide_estimate(int M, int N, int K, bool grouped) {
-  if ((long long)N * K / 2 >= (1ll << 32)) return 1e30;  // 32-bit offsets into the packed weights
+  if ((long long)N * K / 2 >= (1ll << 32) || (K % 128) != 0) return 1e30;  // 32-bit offsets into the packed weights; whole stages
   const long long tl = (long long)((M + 255) / 256) * ((N + 255) / 256);
   const int NST = (K / 64 + 1) / 2;
   return 3.7 + (double)((tl + 255) / 256) * (12.0 + NST * (grouped ? 1.76 : 1.34));
@@ -554,6 +549,7 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
     }
   }
   if ((kernel == 3 || kernel == 4 || kernel == 5) && !column_ok) kernel = 1;
+  if (kernel == 5 && (K % 128) != 0) kernel = 4;                        // whole 128-k stages only
   if (kernel == 5 && (long long)N * K / 2 >= (1ll << 32)) kernel = 2;  // 32-bit offsets into the packed weights
   if (kernel == 2 && (K % 128) != 0) kernel = 1;
   pl.kernel = kernel;
@@ -562,8 +558,8 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
   if (kernel == 5) {
     // wide: 256 tokens x 256 columns per workgroup, 4 waves with 512 registers each, no split-K
     pl.mt = (t.mt == 8) ? 8 : 16;                         // 16-token m-tiles per workgroup: 256- or 128-token tiles
-    pl.stages = (t.stages == 3 && !QQQ_WIDE_UNIFORM) ? 3 : 1;  // activation register lead in stages (first schedule only)
-    pl.pf = (t.pf == 6 && pl.stages != 3) ? 6 : 3;        // weight ring in 64-k steps (3: measured 1-5 % faster than 6)
+    pl.stages = 1;                                        // activation lead: one staging register set, a full stage ahead
+    pl.pf = (t.pf == 6) ? 6 : 3;                          // weight ring in 64-k steps (3: measured 0-4 % faster than 6)
     pl.pw = (t.pw == 4 || t.pw == 8 || t.pw == 16 || t.pw == 32) ? t.pw : 8;
     pl.ksplit = 1;
     pl.fused = 1;
@@ -789,7 +785,7 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
     return QQQ_ERR_ARG;
   }
   if (pl.kernel == 5) {
-    e = launch_wide(a, grouped, pl.mt, pl.pf, pl.stages, pl.pw);
+    e = launch_wide(a, grouped, pl.mt, pl.pf, pl.pw);
     if (e != hipSuccess) return fail_hip(e, "qqq_wide_kernel launch");
     reduce_launch = false;
   } else if (pl.kernel == 4) {

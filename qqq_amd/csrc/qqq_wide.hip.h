@@ -13,15 +13,24 @@
 //   * unpack / re-quantise VALU per MFMA halves (per-channel 1.5 -> 0.75, per-group 5.1 -> 2.4 -- the per-group mode was
 //     VALU-issue bound at 128 tokens per weight operand: "re-quantise once, multiply many");
 //   * 256 x 256 tiles: the L2 <-> fabric traffic of the tiled kernel (2 rounds x 8 XCDs x (4 m-tiles + 8 strips)), not the
-//     128-row m-blocks' 4 rounds;
+//     128-row m-blocks' 4 rounds (741 MB per launch at M=4096 against 1137, profiles/r03_pmc_wide_m4096.txt);
 //   * no k-group meet at the end, one barrier per 128-k stage between FOUR waves.
-// The price: nothing hides a wave's own stalls (no partner on the SIMD), so the loop is software-pipelined like the panel
-// kernel's 64-column path -- weights HBM -> VGPR ring (RS = 2P steps ahead), 4x4 quad transpose in registers, operands
-// unpacked half a step ahead in place, activation fragments re-read in place right behind their last MFMA, activations
-// staged global -> VGPR -> LDS two stages ahead -- with the instruction interleave pinned by sched_group_barrier.
+// The price: nothing hides a wave's own stalls (no partner on the SIMD) and an in-order wave issues one instruction per ~4
+// cycles, i.e. a 16-cycle MFMA leaves room for at most three others.  So:
+//   * the accumulators are updated IN PLACE by inline-asm MFMAs ("+a"): with the builtin hipcc selects the untied form in the
+//     accumulation registers and, all 256 of them live, bounces accumulators through VGPRs and scratch;
+//   * the issue order is pinned slot by slot (sched_barrier): slot k of a 64-k step = the MFMA of (m-tile k / 4, column set
+//     k % 4) + its share of everything else -- the NEXT step's weights (HBM -> VGPR ring, RS steps ahead) are transposed
+//     (4 x 4 quad transpose as four 3-instruction pieces) and unpacked into a second operand set over the whole step, every
+//     activation fragment is re-read from LDS for the next step right behind its fourth MFMA, and the activations are staged
+//     global -> VGPR -> LDS one 16-byte chunk per thread every 16 slots (ds_write of stage i + 2, four slots later the reload
+//     of the same register for stage i + 3).  Everything is spread EVENLY: the four waves of a workgroup run in lock step
+//     (one barrier per stage), so anything issued in a burst hits the LDS store path / the vector-memory issue four times
+//     at once (the first version staged in a burst and ran 7-9 % slower, profiles/r03_wide_uniform_schedule.txt).
+// MT = 16: 256-token tiles; MT = 8: 128-token tiles (128 accumulators; on a par with the panel kernel's 64-column shape).
 //
 // grid = tiles_m * tiles_n (XCD-aware order as in the tiled kernel), block = 256.  No split-K: the host picks this shape
-// only when tiles >= ~1 round of the chip.
+// only when the tiles fill about a round of the chip.  K % 128 == 0 (the host sends other K to the panel kernel).
 // Addresses: wave-uniform buffer descriptors + 32-bit lane offsets + scalar step offsets (buffer_load ... v_off, s[rsrc],
 // s_off): no 64-bit per-lane address arithmetic on the issue port the MFMAs share.
 // ------------------------------------------------------------------------------------------
@@ -32,15 +41,6 @@
 #ifndef QQQ_WIDE_ABLATE
 #define QQQ_WIDE_ABLATE 0
 #endif
-// 1 (shipped): the uniform slot schedule -- the MFMAs of a step run m-tile by m-tile (all four column sets of an m-tile back
-// to back), the NEXT step's weight operands are unpacked into a second register set over the whole step, and the fragment
-// re-reads, the activation staging (ds_write + reload, chunk by chunk) and the ring refills are spread evenly over the step,
-// so the four lock-stepped waves of a workgroup never burst the LDS store path or the vector-memory issue together.
-// 0: the first version (two column halves per step, operands unpacked half a step ahead in place, staging in a burst).
-#ifndef QQQ_WIDE_UNIFORM
-#define QQQ_WIDE_UNIFORM 1
-#endif
-
 // f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>), in order: compile-time indices for hand-placed code
 template <int... S, class F>
 __device__ __forceinline__ void qqq_static_for(std::integer_sequence<int, S...>, F&& f) {
@@ -58,7 +58,7 @@ __device__ __forceinline__ v4u wide_load16(__amdgpu_buffer_rsrc_t view, const un
   return __builtin_amdgcn_raw_buffer_load_b128(view, voff, soff, 0);
 }
 
-template <bool GROUPED, int MT, int P, int XL, int RS>
+template <bool GROUPED, int MT, int P, int RS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void qqq_wide_kernel(
     const int8_t* __restrict__ A, const unsigned char* __restrict__ B, _Float16* __restrict__ D,
     const float* __restrict__ s1, const float* __restrict__ s2, const _Float16* __restrict__ s3,
@@ -72,7 +72,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   constexpr int XPT = XB / 16 / NT;      // 16-byte chunks per thread and stage (8 / 4)
   static_assert((2 * P) % RS == 0, "weight ring (in 64-k steps) must divide the unroll period");
   constexpr int LA = 2;                  // stage i + LA is written to LDS during stage i (its buffer was last read in i - 1)
-  static_assert(P == 3 && (P % XL) == 0, "ring periods");
+  static_assert(P == 3, "LDS stage buffers = unroll period in stages");
+  constexpr int XL = 1;                  // one staging register set, reloaded chunk by chunk: a full stage of lead
   constexpr int EPR = (MT == 16) ? 128 : 64;  // rows per epilogue pass (int32 image: EPR x 260 x 4 B = 130 / 65 KiB of LDS)
   constexpr int EP_STRIDE = BN + 4;
 
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const unsigned rowbytes = (unsigned)N * 8u;
 
   const int KS = K >> 6;                 // 64-k steps
-  const int NST = (KS + 1) >> 1;         // 128-k stages (a trailing half stage when K % 128 == 64)
+  const int NST = K >> 7;                // 128-k stages (K % 128 == 0)
 
   // ---- per-lane sources ----
   const int h = lane >> 4, cq = (lane >> 2) & 3, q4 = lane & 3;  // q4: kq as a load lane, jt as an MFMA lane
@@ -128,21 +129,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     xoff[q] = (unsigned)row * (unsigned)K + (unsigned)(xpos * 16);
   }
   const unsigned xdst = (unsigned)(xr0 * 128 + ((xpos ^ ((xr0 >> 1) & 7)) << 4));  // + q * 4096 (rows 32 apart: same swizzle)
-  const bool k_tail = (KS & 1) != 0;
-  const unsigned xtail = xpos >= 4 ? 64u : 0u;  // the upper 64 k of a trailing half stage lie outside the row
+  unsigned xdst_b[P];                    // ... per LDS buffer, as registers (the ds_write offset field stops at 64 KiB)
+#pragma unroll
+  for (int b = 0; b < P; ++b) xdst_b[b] = xdst + (unsigned)(b * XB);
 
   // stage / step indices past the end are redirected to the last one (loaded, never used): the loop stays branch-free
   auto load_x = [&](const int st_rel, v4u (&r)[XPT]) {
     const int st = st_rel < NST ? st_rel : NST - 1;
-    // ... fetch the lower half again instead (never used: the weights of that step are zeroed)
-    const unsigned adj = (k_tail && st == NST - 1) ? xtail : 0u;
     const unsigned so = (unsigned)st * 128u;
 #pragma unroll
-    for (int q = 0; q < XPT; ++q) r[q] = wide_load16(xview, xoff[q] - adj, so);
+    for (int q = 0; q < XPT; ++q) r[q] = wide_load16(xview, xoff[q], so);
   };
   auto store_x = [&](const int buf, const v4u (&r)[XPT]) {
 #pragma unroll
-    for (int q = 0; q < XPT; ++q) *reinterpret_cast<v4u*>(smem + buf * XB + xdst + q * 4096) = r[q];
+    for (int q = 0; q < XPT; ++q) *reinterpret_cast<v4u*>(smem + xdst_b[buf] + q * 4096) = r[q];
   };
   auto load_w = [&](const int step_rel, v4u (&dst)[2]) {
     const int s = step_rel < KS ? step_rel : KS - 1;
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   v4u xr[XL][XPT];
   h2 scr[GROUPED ? P : 1][2];
   v4i x[MT];     // activation fragments of the current step; x[mt] is re-read for the next step right behind its last MFMA
-  v4i aop[2][4]; // weight operands [set][2 * hf + b]: the current step's and (uniform schedule) the next step's
+  v4i aop[2][4]; // weight operands [set][2 * hf + b]: the current step's and the next step's
   const unsigned xrd = (unsigned)((lane & 15) * 128);  // + mt * 2048; chunk = (4 * t + h) ^ ((row >> 1) & 7), row = 16 * mt + j
   const int xsw = ((lane & 15) >> 1) & 7;
   const unsigned xrd_t[2] = {xrd + (unsigned)(((0 + h) ^ xsw) << 4), xrd + (unsigned)(((4 + h) ^ xsw) << 4)};
@@ -208,68 +208,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                    : "=&v"(y[2]), "=&v"(y[3]) : "v"(z[0]), "v"(z[1]), "v"(z[2]), "v"(z[3]), "s"(kmc) : "vcc");
   };
   // per-channel: 12 VALU (and | shift, and per packed word); per-group: 8 x dequant_group4 in 4 two-instruction parts
-  unsigned nmask = 0;          // per-channel: nibble mask of the half being unpacked (0 for a step past the end of K)
-  h2 sb[2];                    // per-group: the half's two group scales, broadcast (0 for a step past the end of K)
-  unsigned gt0 = 0, gt1 = 0;   // per-group: one re-quantisation in flight
-  h2 gha, ghb;
+  const unsigned nmask = QQQ_NIB_MASK;
+  h2 sb[2];                    // per-group: the half's two group scales, broadcast
+  unsigned gt0[2] = {0, 0}, gt1[2] = {0, 0};  // per-group: the two re-quantisations (b = 0, 1) of a packed word in flight
+  h2 gha[2], ghb[2];
   constexpr int UPARTS = GROUPED ? 32 : 12;
-  auto un_setup = [&](const h2 sc, const bool valid) {
+  auto un_setup = [&](const h2 sc) {
     if constexpr (GROUPED) {
-      const h2 zero = {(_Float16)0, (_Float16)0};
-      const h2 sv = valid ? sc : zero;  // scale 0 re-quantises every nibble to 0
-      sb[0] = (h2){sv[0], sv[0]};
-      sb[1] = (h2){sv[1], sv[1]};
-    } else {
-      nmask = valid ? QQQ_NIB_MASK : 0u;
+      sb[0] = (h2){sc[0], sc[0]};
+      sb[1] = (h2){sc[1], sc[1]};
     }
   };
   auto un_part = [&](auto pc, auto hfc, v4i (&a)[4]) {
     constexpr int pi = decltype(pc)::value, hf = decltype(hfc)::value;
     if constexpr (GROUPED) {
-      constexpr int it = pi / 4, part = pi % 4, kq = it / 2, b = it % 2;
+      // the two re-quantisations of a packed word (b = 0, 1) run in lock step: part p of b = 0, then part p of b = 1 -- a
+      // v_pk_fma_f16's consumer (v_perm_b32) must not be the next VALU instruction (one wait state, which hipcc fills with an
+      // s_nop: it does not count the inline-asm MFMA in between), and the sibling's part sits there for free
+      constexpr int kq = pi / 8, part = (pi % 8) / 2, b = pi % 2;
       if constexpr (part == 0) {
         const unsigned qv = b ? (y[kq] >> 8) : y[kq];
         const unsigned magic = qqq_fp16_1024x2();
-        gt0 = (qv & 0x000f000fu) | magic;  // {1024+p0, 1024+p4}
-        gt1 = (qv & 0x00f000f0u) | magic;  // {1024+16*p1, 1024+16*p5}
+        gt0[b] = (qv & 0x000f000fu) | magic;  // {1024+p0, 1024+p4}
+        gt1[b] = (qv & 0x00f000f0u) | magic;  // {1024+16*p1, 1024+16*p5}
       } else if constexpr (part == 1) {
         const h2 c_sub = {(_Float16)-1032.0f, (_Float16)-1032.0f};
         const h2 c_mul = {(_Float16)0.0625f, (_Float16)0.0625f};
         const h2 c_add = {(_Float16)-72.0f, (_Float16)-72.0f};
-        gha = __builtin_bit_cast(h2, gt0) + c_sub;                                    // exact
-        ghb = __builtin_elementwise_fma(__builtin_bit_cast(h2, gt1), c_mul, c_add);  // exact
+        gha[b] = __builtin_bit_cast(h2, gt0[b]) + c_sub;                                    // exact
+        ghb[b] = __builtin_elementwise_fma(__builtin_bit_cast(h2, gt1[b]), c_mul, c_add);  // exact
       } else if constexpr (part == 2) {
         const h2 c_mag = {(_Float16)1152.0f, (_Float16)1152.0f};
-        gha = __builtin_elementwise_fma(gha, sb[b], c_mag);
-        ghb = __builtin_elementwise_fma(ghb, sb[b], c_mag);
+        gha[b] = __builtin_elementwise_fma(gha[b], sb[b], c_mag);
+        ghb[b] = __builtin_elementwise_fma(ghb[b], sb[b], c_mag);
       } else {
-        a[2 * hf + b][kq] = (int)(__builtin_amdgcn_perm(__builtin_bit_cast(unsigned, ghb), __builtin_bit_cast(unsigned, gha), 0x06040200u) ^ 0x80808080u);
+        a[2 * hf + b][kq] = (int)(__builtin_amdgcn_perm(__builtin_bit_cast(unsigned, ghb[b]), __builtin_bit_cast(unsigned, gha[b]), 0x06040200u) ^ 0x80808080u);
       }
     } else {
       constexpr int kq = pi / 3, part = pi % 3;
       if constexpr (part == 0) a[2 * hf][kq] = (int)(y[kq] & nmask);         // odd nibbles  -> 16*w4 of column n      (b = 0)
-      else if constexpr (part == 1) gt0 = y[kq] << 4;
-      else a[2 * hf + 1][kq] = (int)(gt0 & nmask);                           // even nibbles -> 16*w4 of column n + 8  (b = 1)
-    }
-  };
-  // unpack piece of issue slot s (0 .. 2 MT - 1) of a half-step: slots 0..3 the transpose pieces (+ the scale / mask set-up
-  // in slot 0), the remaining NSL slots share the UPARTS unpack parts evenly
-  constexpr int NSL = 2 * MT - 4;
-  auto un_slot = [&](auto sc_, auto hfc, const v4u& w, const h2 sc, const bool valid) {
-    v4i (&a)[4] = aop[0];
-    constexpr int s_ = decltype(sc_)::value;
-    if constexpr ((QQQ_WIDE_ABLATE & 4) != 0) {
-      if constexpr (s_ == 0) { a[0] = a[1] = a[2] = a[3] = (v4i){(int)w[0], (int)w[1], (int)w[2], (int)w[3]}; }
-    } else if constexpr (s_ < 4) {
-      if constexpr (s_ == 0) un_setup(sc, valid);
-      tr_piece(sc_, w);
-    } else {
-      constexpr int lo = ((s_ - 4) * UPARTS + NSL - 1) / NSL;
-      constexpr int hi = ((s_ - 3) * UPARTS + NSL - 1) / NSL;
-      qqq_static_for<(hi > lo ? hi - lo : 0)>([&](auto pc) {
-        constexpr int pi = lo + decltype(pc)::value;
-        if constexpr (pi < UPARTS) un_part(std::integral_constant<int, pi>{}, hfc, a);
-      });
+      else if constexpr (part == 1) gt0[0] = y[kq] << 4;
+      else a[2 * hf + 1][kq] = (int)(gt0[0] & nmask);                           // even nibbles -> 16*w4 of column n + 8  (b = 1)
     }
   };
   auto mfma = [&](v4i& c, const v4i& wa, const v4i& xb) {
@@ -278,74 +257,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+a"(c) : "v"(wa), "v"(xb));
   };
 
-  // One 64-k step (stage i, half t of it; u = i % P and t compile-time at every call site).  While the matrix pipe works on
-  // column half 0 the wave unpacks THIS step's half 1; while it works on half 1, the NEXT step's half 0 -- refills the ring
-  // slot just emptied, and re-reads every activation fragment for the next step right behind its last MFMA.  The issue
-  // order is pinned slot by slot (sched_barrier): one MFMA (16 cycles of the matrix pipe = 4 issue slots of a lone wave)
-  // followed by at most three other instructions.  The stage's activation traffic goes into the first step: LDS image of
-  // stage i + LA out of the staging registers behind the unpack of half 0, loads of stage i + LA + XL behind that of half 1.
-  auto step = [&](const int i, auto uc, auto tc) __attribute__((always_inline)) {
-    constexpr int t = decltype(tc)::value, u = decltype(uc)::value;
-    const int sl = (2 * u + t) % RS;            // ring slot of this step
-    const int sn = (sl + 1) % RS;               // ... of the next one
-    const int step_abs = 2 * i + t;
-    const int xs = (u + LA) % XL;
-    const int su0 = GROUPED ? u : 0, su1 = GROUPED ? ((t == 1) ? (u + 1) % P : u) : 0;
-    // ---- column half 0 ----
-    auto half0 = [&](auto mc) __attribute__((always_inline)) {
-      constexpr int mt = decltype(mc)::value;
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        mfma(acc[mt][e], aop[0][e], x[mt]);
-        if (e == 0) un_slot(std::integral_constant<int, 2 * mt>{}, std::integral_constant<int, 1>{}, wr[sl][1], scr[su0][1], step_abs < KS);
-        else un_slot(std::integral_constant<int, 2 * mt + 1>{}, std::integral_constant<int, 1>{}, wr[sl][1], scr[su0][1], step_abs < KS);
-        if constexpr (t == 0 && mt >= MT - XPT / 2 && !(QQQ_WIDE_ABLATE & 2)) {  // activation staging: XPT x ds_write_b128 in the last slots
-          const int q = 2 * (mt - (MT - XPT / 2)) + e;
-          *reinterpret_cast<v4u*>(smem + ((i + LA) % P) * XB + xdst + q * 4096) = xr[xs][q];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    };
-    qqq_static_for<MT>(half0);
-    // ---- column half 1 ----
-    const int st_x = i + LA + XL < NST ? i + LA + XL : NST - 1;
-    const unsigned xadj = (k_tail && st_x == NST - 1) ? xtail : 0u;
-    const unsigned xso = (unsigned)st_x * 128u;
-    auto half1 = [&](auto mc) __attribute__((always_inline)) {
-      constexpr int mt = decltype(mc)::value;
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        mfma(acc[mt][2 + e], aop[0][2 + e], x[mt]);
-        if (e == 0) un_slot(std::integral_constant<int, 2 * mt>{}, std::integral_constant<int, 0>{}, wr[sn][0], scr[su1][0], step_abs + 1 < KS);
-        else un_slot(std::integral_constant<int, 2 * mt + 1>{}, std::integral_constant<int, 0>{}, wr[sn][0], scr[su1][0], step_abs + 1 < KS);
-        if constexpr (!(QQQ_WIDE_ABLATE & 16))
-          if (e == 1) read_x(t == 0 ? (i % P) : ((i + 1) % P), t == 0 ? 1 : 0, mt);  // the next step's fragment, in place
-        if constexpr (t == 0 && mt >= MT - XPT && !(QQQ_WIDE_ABLATE & 2))
-          if (e == 0) xr[xs][mt - (MT - XPT)] = wide_load16(xview, xoff[mt - (MT - XPT)] - xadj, xso);  // activation staging
-        if constexpr (!(QQQ_WIDE_ABLATE & 8))
-          if (e == 1 && mt == MT / 2) load_w(step_abs + RS, wr[sl]);  // ring refill (both halves of this slot are consumed)
-        if constexpr (GROUPED)
-          if (t == 1 && e == 1 && mt == MT / 2 + 2) load_sc(i + P, scr[u]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    };
-    qqq_static_for<MT>(half1);
-  };
-
-  // The uniform slot schedule (QQQ_WIDE_UNIFORM): slot k of a step = MFMA (m-tile k / 4, column set k % 4) + its share of
+  // One 64-k step (stage i, half t of it; u = i % P and t compile-time).  Slot k of a step = MFMA (m-tile k / 4, column set k % 4) + its share of
   // everything else.  Step s unpacks step s + 1 into the other operand set (2 x (4 transpose pieces + UPARTS parts), evenly
   // over the 4 MT slots), re-reads fragment x[mt] for step s + 1 right behind its fourth MFMA, refills ring slot s % RS (read by
   // the unpack that ran during step s - 1) with step s + RS, and moves one 16-byte chunk per thread of the activation stage
   // every 16 slots: ds_write of stage i + LA, four slots later the reload of the same register for stage i + LA + 1.
-  auto step_u = [&](const int i, auto uc, auto tc) __attribute__((always_inline)) {
+  auto step = [&](const int i, auto uc, auto tc) __attribute__((always_inline)) {
     constexpr int t = decltype(tc)::value, u = decltype(uc)::value;
     constexpr int cur = t, nxt = 1 - t;         // 2 P steps per trip: the step's parity is its t
     constexpr int sl = (2 * u + t) % RS, sn = (sl + 1) % RS;
     const int step_abs = 2 * i + t;
     constexpr int su = GROUPED ? ((t == 1) ? (u + 1) % P : u) : 0;  // scales of the NEXT step's stage
-    const bool nvalid = step_abs + 1 < KS;
     const int st_x = i + LA + 1 < NST ? i + LA + 1 : NST - 1;
-    const unsigned xadj = (k_tail && st_x == NST - 1) ? xtail : 0u;
     const unsigned xso = (unsigned)st_x * 128u;
     constexpr int NSLOT = 4 * MT, NI = 2 * (4 + UPARTS);
     auto slot = [&](auto kc) __attribute__((always_inline)) {
@@ -357,7 +280,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           constexpr int it = lo + decltype(jc)::value;
           constexpr int hf = it / (4 + UPARTS), w_ = it % (4 + UPARTS);
           if constexpr (w_ < 4) {
-            if constexpr (w_ == 0) un_setup(scr[su][hf], nvalid);
+            if constexpr (w_ == 0) un_setup(scr[su][hf]);
             tr_piece(std::integral_constant<int, w_>{}, wr[sn][hf]);
           } else {
             un_part(std::integral_constant<int, w_ - 4>{}, std::integral_constant<int, hf>{}, aop[nxt]);
@@ -367,11 +290,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         aop[nxt][0] = aop[nxt][1] = (v4i){(int)wr[sn][0][0], (int)wr[sn][0][1], (int)wr[sn][0][2], (int)wr[sn][0][3]};
         aop[nxt][2] = aop[nxt][3] = (v4i){(int)wr[sn][1][0], (int)wr[sn][1][1], (int)wr[sn][1][2], (int)wr[sn][1][3]};
       }
-      if constexpr (q == 3 && !(QQQ_WIDE_ABLATE & 16)) read_x(t == 0 ? (i % P) : ((i + 1) % P), t == 0 ? 1 : 0, mt);
+      if constexpr (q == 3 && !(QQQ_WIDE_ABLATE & 16)) read_x(t == 0 ? (u % P) : ((u + 1) % P), t == 0 ? 1 : 0, mt);
       if constexpr (!(QQQ_WIDE_ABLATE & 2)) {
         constexpr int qi = (XPT / 2) * t + k / 16;  // this thread's chunk of the stage
-        if constexpr (k % 16 == 5) *reinterpret_cast<v4u*>(smem + ((i + LA) % P) * XB + xdst + qi * 4096) = xr[0][qi];
-        if constexpr (k % 16 == 9) xr[0][qi] = wide_load16(xview, xoff[qi] - xadj, xso);
+        if constexpr (k % 16 == 5) *reinterpret_cast<v4u*>(smem + xdst_b[(u + LA) % P] + qi * 4096) = xr[0][qi];
+        if constexpr (k % 16 == 9) xr[0][qi] = wide_load16(xview, xoff[qi], xso);
       }
       if constexpr (k == 2 && !(QQQ_WIDE_ABLATE & 8)) load_w(step_abs + RS, wr[sl]);
       if constexpr (GROUPED && t == 1 && k == 6) load_sc(i + P, scr[u]);
@@ -414,34 +337,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   __syncthreads();
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) read_x(0, 0, mt);
-  if constexpr (QQQ_WIDE_UNIFORM) {  // both halves of step 0 into operand set 0
-    static_assert(!QQQ_WIDE_UNIFORM || XL == 1, "uniform schedule: one staging register set, reloaded chunk by chunk");
-    qqq_static_for<2>([&](auto hfc) {
-      constexpr int hf = decltype(hfc)::value;
-      un_setup(scr[0][hf], 0 < KS);
-      qqq_static_for<4>([&](auto pc) { tr_piece(pc, wr[0][hf]); __builtin_amdgcn_sched_barrier(0); });
-      qqq_static_for<UPARTS>([&](auto pc) { un_part(pc, hfc, aop[0]); });
-    });
-  } else {
-    const std::integral_constant<int, 0> hf0;
-    un_slot(std::integral_constant<int, 0>{}, hf0, wr[0][0], scr[0][0], 0 < KS);
-    un_slot(std::integral_constant<int, 1>{}, hf0, wr[0][0], scr[0][0], 0 < KS);
-    __builtin_amdgcn_sched_barrier(0);
-    un_slot(std::integral_constant<int, 2>{}, hf0, wr[0][0], scr[0][0], 0 < KS);
-    un_slot(std::integral_constant<int, 3>{}, hf0, wr[0][0], scr[0][0], 0 < KS);
-    __builtin_amdgcn_sched_barrier(0);
-    qqq_static_for<NSL>([&](auto sc_) { un_slot(std::integral_constant<int, decltype(sc_)::value + 4>{}, hf0, wr[0][0], scr[0][0], 0 < KS); });
-  }
+  qqq_static_for<2>([&](auto hfc) {  // both halves of step 0 into operand set 0
+    constexpr int hf = decltype(hfc)::value;
+    un_setup(scr[0][hf]);
+    qqq_static_for<4>([&](auto pc) { tr_piece(pc, wr[0][hf]); __builtin_amdgcn_sched_barrier(0); });
+    qqq_static_for<UPARTS>([&](auto pc) { un_part(pc, hfc, aop[0]); });
+  });
   __builtin_amdgcn_sched_barrier(0);
 
   auto do_stage = [&](const int i, auto uc) __attribute__((always_inline)) {  // one 128-k stage: two steps and the barrier that publishes stage i + LA
-    if constexpr (QQQ_WIDE_UNIFORM) {
-      step_u(i, uc, std::integral_constant<int, 0>{});
-      step_u(i, uc, std::integral_constant<int, 1>{});
-    } else {
-      step(i, uc, std::integral_constant<int, 0>{});
-      step(i, uc, std::integral_constant<int, 1>{});
-    }
+    step(i, uc, std::integral_constant<int, 0>{});
+    step(i, uc, std::integral_constant<int, 1>{});
     if constexpr (!(QQQ_WIDE_ABLATE & 1)) __syncthreads();  // stage i + LA is in LDS for everybody; buffer (i % P) is free
   };
   QQQ_TR(1);

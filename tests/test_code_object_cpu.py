@@ -104,14 +104,15 @@ def test_steady_state_loops(table):
     # the wide kernel (large m since round 3): 3 stages x 2 steps x 64 in-place MFMAs per trip, one barrier per stage, no
     # scratch inside the loop, counted waits, and the issue budget of a LONE wave: at most 4 instructions per MFMA
     # (16 matrix-pipe cycles = 4 issue slots) in the per-channel mode
-    for name, grouped in (("qqq_wide_kernel<false,16,3,1,3>", False), ("qqq_wide_kernel<true,16,3,1,3>", True)):
+    for name, grouped in (("qqq_wide_kernel<false,16,3,3>", False), ("qqq_wide_kernel<true,16,3,3>", True)):
         mix, waits = _loop(name)
         assert mix["v_mfma_i32_16x16x64_i8"] == 384 and mix["s_barrier"] == 3, name
         assert _count(mix, "scratch") == 0 and not any("vmcnt(0)" in w for w in waits), (name, waits)
         assert mix["ds_read_b128"] == 96 and mix["ds_write_b128"] == 24 and mix["buffer_load_dwordx4"] == 36, name
         assert _count(mix, "v_accvgpr") == 0, name  # accumulators never leave the accumulation registers
         total = sum(mix.values())
-        assert total <= (5.0 if grouped else 3.0) * 384, (name, total)
+        assert total <= (4.4 if grouped else 2.6) * 384, (name, total)
+        assert mix.get("s_nop", 0) <= 32, (name, mix.get("s_nop"))  # hazard fillers: the paired re-quantisations keep them out
     # decode and a-few-tokens kernels: counted waits only, no LDS in the loop, no scratch
     for name in ("qqq_column_kernel<1,false,8,3>", "qqq_column_kernel<1,true,8,3>", "qqq_stream_kernel<1,false,4,3>"):
         mix, waits = _loop(name)
