@@ -338,9 +338,9 @@ static hipError_t launch_tiled(const LaunchArgs& a, bool grouped, int bm, int st
 }
 
 template <bool GROUPED, int MT, int P, int RS>
-static hipError_t launch_wide_t(const LaunchArgs& a, int pw) {
+static hipError_t launch_wide_t(const LaunchArgs& a, int pw, int ksplit) {
   constexpr int ROWS = 16 * MT;
-  constexpr int XBUF = P * ROWS * 128, EP = (MT == 16 ? 128 : 64) * (256 + 4) * 4;
+  constexpr int XBUF = P * ROWS * 128, EP = (MT == 16 ? 128 : 64) * (256 + 4) * 4 + 16;  // + the ticket exchange word
   constexpr int LDS = XBUF > EP ? XBUF : EP;
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static bool attr_set[64] = {};  // per instantiation, per device
@@ -353,19 +353,19 @@ static hipError_t launch_wide_t(const LaunchArgs& a, int pw) {
     if (cur >= 0 && cur < 64) attr_set[cur] = true;
   }
   const int tiles_m = (a.M + ROWS - 1) / ROWS, tiles_n = (a.N + 255) / 256;
-  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), LDS, a.stream, a.A, a.B, a.D, a.s1, a.s2, a.s3, a.acc_out,
-                     a.bias, a.M, a.N, a.K, tiles_m, tiles_n, pw);
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n * ksplit), dim3(256), LDS, a.stream, a.A, a.B, a.C, a.D, a.s1, a.s2, a.s3,
+                     a.acc_out, a.tickets, a.bias, a.M, a.N, a.K, tiles_m, tiles_n, pw, ksplit);
   return hipGetLastError();
 }
 
 // mt: 16 (256-token tiles) or 8 (128-token tiles); pf: weight ring in 64-k steps (3 or 6)
 template <bool GROUPED, int MT>
-static hipError_t launch_wide_m(const LaunchArgs& a, int pf, int pw) {
-  return pf == 3 ? launch_wide_t<GROUPED, MT, 3, 3>(a, pw) : launch_wide_t<GROUPED, MT, 3, 6>(a, pw);
+static hipError_t launch_wide_m(const LaunchArgs& a, int pf, int pw, int ksplit) {
+  return pf == 3 ? launch_wide_t<GROUPED, MT, 3, 3>(a, pw, ksplit) : launch_wide_t<GROUPED, MT, 3, 6>(a, pw, ksplit);
 }
-static hipError_t launch_wide(const LaunchArgs& a, bool grouped, int mt, int pf, int pw) {
-  if (mt == 8) return grouped ? launch_wide_m<true, 8>(a, pf, pw) : launch_wide_m<false, 8>(a, pf, pw);
-  return grouped ? launch_wide_m<true, 16>(a, pf, pw) : launch_wide_m<false, 16>(a, pf, pw);
+static hipError_t launch_wide(const LaunchArgs& a, bool grouped, int mt, int pf, int pw, int ksplit) {
+  if (mt == 8) return grouped ? launch_wide_m<true, 8>(a, pf, pw, ksplit) : launch_wide_m<false, 8>(a, pf, pw, ksplit);
+  return grouped ? launch_wide_m<true, 16>(a, pf, pw, ksplit) : launch_wide_m<false, 16>(a, pf, pw, ksplit);
 }
 
 static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -488,11 +488,38 @@ static double panel_estimate(int M, int N, int K, bool grouped, bool have_scratc
 // wide: 256 x 256 tiles, one per CU and round, no split-K: ~12 us per tile round of fixed cost (first operands from HBM with
 // every CU in its prologue at once ~4 us, epilogue ~7 us) + 1.34 us per 128-k stage (per-group 1.76: the re-quantiser of a
 // lone wave is issue-bound); profiles/r03_wide_uniform_schedule.txt, r03_wide_timeline.txt
-static double wide_estimate(int M, int N, int K, bool grouped) {
+static double wide_estimate(int M, int N, int K, bool grouped, bool have_scratch, long long cap_rows, long long cap_tickets, int* ks_out,
+                            int* mt_out) {
+  *ks_out = 1;
+  *mt_out = 16;
   if ((long long)N * K / 2 >= (1ll << 32) || (K % 128) != 0) return 1e30;  // 32-bit offsets into the packed weights; whole stages
-  const long long tl = (long long)((M + 255) / 256) * ((N + 255) / 256);
-  const int NST = (K / 64 + 1) / 2;
-  return 3.7 + (double)((tl + 255) / 256) * (12.0 + NST * (grouped ? 1.76 : 1.34));
+  const long long strips = (N + 255) / 256;
+  const int NST = K / 128;
+  double best = 1e30;
+  for (int mt = 16; mt >= 8; mt -= 8) {
+    // 128-token tiles (mt = 8): half the accumulators, twice the unpack work per MFMA -- 0.775 us per stage (per-group 1.24),
+    // ~8 us fixed; on a par with the panel kernel's 64-column shape, a few % ahead per-channel (profiles/r03_wide_splitk.txt)
+    const int rows = 16 * mt;
+    const long long tl = (long long)((M + rows - 1) / rows) * strips;
+    const double t_stage = (mt == 16) ? (grouped ? 1.76 : 1.34) : (grouped ? 1.24 : 0.775);
+    const double fixed = (mt == 16) ? 12.0 : 8.0;
+    for (int ks = 1; ks <= (mt == 16 ? 2 : 1); ++ks) {
+      // one slot of rows x 256 ints per tile and depositing slice inside C, two ticket words per tile; hand-off (256 KiB deposit
+      // written through + its fold by the last arrival)
+      if (ks > 1 && (!have_scratch || 2 * tl > cap_tickets || tl * rows * 256 * (ks - 1) > cap_rows * (long long)N || ks > NST / 4)) break;
+      // rounds: workgroups of later rounds start as CUs free up, but the XCDs' queues drain unevenly -- between the exact
+      // ratio and its ceiling (344 tiles measured 1.7 rounds, 688 tiles 2.8; profiles/r03_dispatch_check_wide2.txt)
+      const double x = (double)(tl * ks) / 256.0;
+      const double rounds = x <= 1.0 ? 1.0 : 0.5 * (x + (double)((tl * ks + 255) / 256));
+      const double us = 3.7 + rounds * (fixed + (ks > 1 ? 20.0 : 0.0) + ((double)NST / ks) * t_stage);
+      if (us < best) {
+        best = us;
+        *ks_out = ks;
+        *mt_out = mt;
+      }
+    }
+  }
+  return best;
 }
 
 // The dispatch decision of one call, as plain data (pure host logic: also exported as qqq_w4a8_plan so
@@ -535,9 +562,12 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
       const double e_panel = ((long long)(M + 127) / 128 <= 65535) ? panel_estimate(M, N, K, grouped, have_scratch && have_ws, cap_rows, cap_tk, &pbn, &pks, &pcw) : 1e30;
       const double e_stream = (M <= 256) ? stream_estimate(M, N, K, grouped) : 1e30;
       const double e_tiled = ((K % 128) == 0 && M > 64) ? tiled_estimate(M, N, K, grouped, have_scratch, cap_rows, cap_tk, false, &tbm, &tks) : 1e30;
-      const double e_wide = (M > 256) ? wide_estimate(M, N, K, grouped) : 1e30;
+      int wks = 1, wmt = 16;
+      const double e_wide = (M > 256) ? wide_estimate(M, N, K, grouped, have_scratch && have_ws, cap_rows, cap_tk, &wks, &wmt) : 1e30;
       if (e_wide < e_panel && e_wide < e_stream && e_wide < e_tiled) {
         kernel = 5;
+        if (t.ksplit <= 0) t.ksplit = wks;
+        if (t.mt == 0) t.mt = wmt;
       } else if (e_panel <= e_stream && e_panel <= e_tiled) {
         kernel = 4;
         if (t.bm == 0 && t.pw == 0 && t.mt == 0 && pcw == 2) t.pw = 2;
@@ -556,12 +586,21 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
   int ksplit = 1;
 
   if (kernel == 5) {
-    // wide: 256 tokens x 256 columns per workgroup, 4 waves with 512 registers each, no split-K
+    // wide: 256 (mt = 8: 128) tokens x 256 columns per workgroup, 4 waves with 512 registers each; in-launch split-K with
+    // one slot of C per depositing slice (row-major partial tiles) and two ticket words per tile
     pl.mt = (t.mt == 8) ? 8 : 16;                         // 16-token m-tiles per workgroup: 256- or 128-token tiles
     pl.stages = 1;                                        // activation lead: one staging register set, a full stage ahead
     pl.pf = (t.pf == 6) ? 6 : 3;                          // weight ring in 64-k steps (3: measured 0-4 % faster than 6)
     pl.pw = (t.pw == 4 || t.pw == 8 || t.pw == 16 || t.pw == 32) ? t.pw : 8;
-    pl.ksplit = 1;
+    const int rows = 16 * pl.mt;
+    const long long tl = (long long)((M + rows - 1) / rows) * ((N + 255) / 256);
+    ksplit = t.ksplit > 0 ? t.ksplit : 1;
+    ksplit = clampi(ksplit, 1, (K / 128) / 4 > 0 ? (K / 128) / 4 : 1);
+    if (!have_scratch || workspace == nullptr) ksplit = 1;
+    const long long cap_tk = (long long)(N / 128) * (max_par > 0 ? max_par : 0);
+    if (2 * tl > cap_tk) ksplit = 1;
+    while (ksplit > 1 && tl * rows * 256 * (ksplit - 1) > cap_rows * (long long)N) --ksplit;
+    pl.ksplit = ksplit;
     pl.fused = 1;
     return pl;
   }
@@ -785,7 +824,7 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
     return QQQ_ERR_ARG;
   }
   if (pl.kernel == 5) {
-    e = launch_wide(a, grouped, pl.mt, pl.pf, pl.pw);
+    e = launch_wide(a, grouped, pl.mt, pl.pf, pl.pw, pl.ksplit);
     if (e != hipSuccess) return fail_hip(e, "qqq_wide_kernel launch");
     reduce_launch = false;
   } else if (pl.kernel == 4) {

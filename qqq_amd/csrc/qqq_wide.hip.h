@@ -60,10 +60,10 @@ __device__ __forceinline__ v4u wide_load16(__amdgpu_buffer_rsrc_t view, const un
 
 template <bool GROUPED, int MT, int P, int RS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void qqq_wide_kernel(
-    const int8_t* __restrict__ A, const unsigned char* __restrict__ B, _Float16* __restrict__ D,
+    const int8_t* __restrict__ A, const unsigned char* __restrict__ B, int32_t* __restrict__ C, _Float16* __restrict__ D,
     const float* __restrict__ s1, const float* __restrict__ s2, const _Float16* __restrict__ s3,
-    int32_t* __restrict__ acc_out, const _Float16* __restrict__ bias, const int M, const int N, const int K,
-    const int tiles_m, const int tiles_n, const int PW) {
+    int32_t* __restrict__ acc_out, int* __restrict__ tickets, const _Float16* __restrict__ bias, const int M, const int N,
+    const int K, const int tiles_m, const int tiles_n, const int PW, const int ksplit) {
   static_assert(MT == 16 || MT == 8, "m-tiles of 16 tokens per wave (= per workgroup): 256 or 128 tokens");
   constexpr int ROWS = 16 * MT;
   constexpr int BN = 256;                // 4 waves x 64 columns
@@ -85,13 +85,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   QQQ_TR(0);  // (measurement builds only, -DQQQ_PANEL_TRACE: see qqq_panel.hip.h; grid is 1-D here)
 
   // ---- XCD-aware tile order (speed only): block b runs on XCD b % 8; an XCD walks panels of PW strips x all m-tiles ----
-  int tile_m, tile_n;
+  int tile_m, tile_n, tile_lin, sp;  // tile coordinates, tile index, K slice
   {
-    const int ntiles = tiles_m * tiles_n;
+    // (with a K split the slices of a tile take consecutive positions of the XCD's run: resident together, on one XCD)
+    const int ntot = tiles_m * tiles_n * ksplit;
     const int bid = blockIdx.x;
-    const int q = ntiles >> 3, rr = ntiles & 7;
+    const int q = ntot >> 3, rr = ntot & 7;
     const int xcd = bid & 7, idx = bid >> 3;
-    const int lin = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+    const int lin2 = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+    const int lin = lin2 / ksplit;
+    sp = lin2 - lin * ksplit;
+    tile_lin = lin;
     const int full = (tiles_n / PW) * PW * tiles_m;
     if (lin < full) {
       const int panel = lin / (PW * tiles_m), within = lin % (PW * tiles_m);
@@ -109,8 +113,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   if (ng >= ngroups) ng = ngroups - 1;   // N % 256 != 0: surplus waves of the last strip compute on clamped columns, store nothing
   const unsigned rowbytes = (unsigned)N * 8u;
 
-  const int KS = K >> 6;                 // 64-k steps
-  const int NST = K >> 7;                // 128-k stages (K % 128 == 0)
+  // K slice [st0, st0 + NST) in 128-k stages (K % 128 == 0); steps and stages below are relative to it
+  const int st0 = (int)(((long long)(K >> 7) * sp) / ksplit);
+  const int NST = (int)(((long long)(K >> 7) * (sp + 1)) / ksplit) - st0;
+  const int KS = 2 * NST;                // 64-k steps
 
   // ---- per-lane sources ----
   const int h = lane >> 4, cq = (lane >> 2) & 3, q4 = lane & 3;  // q4: kq as a load lane, jt as an MFMA lane
@@ -136,7 +142,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // stage / step indices past the end are redirected to the last one (loaded, never used): the loop stays branch-free
   auto load_x = [&](const int st_rel, v4u (&r)[XPT]) {
     const int st = st_rel < NST ? st_rel : NST - 1;
-    const unsigned so = (unsigned)st * 128u;
+    const unsigned so = (unsigned)(st0 + st) * 128u;
 #pragma unroll
     for (int q = 0; q < XPT; ++q) r[q] = wide_load16(xview, xoff[q], so);
   };
@@ -146,13 +152,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   };
   auto load_w = [&](const int step_rel, v4u (&dst)[2]) {
     const int s = step_rel < KS ? step_rel : KS - 1;
-    const unsigned so = (unsigned)(4 * s) * rowbytes;
+    const unsigned so = (unsigned)(4 * (2 * st0 + s)) * rowbytes;
     dst[0] = wide_load16(wview, woff, so);
     dst[1] = wide_load16(wview, woff + 256u, so);
   };
   auto load_sc = [&](const int st_rel, h2 (&dst)[2]) {
     const int st = st_rel < NST ? st_rel : NST - 1;
-    const unsigned so = (unsigned)st * (unsigned)N * 2u;
+    const unsigned so = (unsigned)(st0 + st) * (unsigned)N * 2u;
     dst[0] = __builtin_bit_cast(h2, __builtin_amdgcn_raw_buffer_load_b32(sview, soff_l, so, 0));
     dst[1] = __builtin_bit_cast(h2, __builtin_amdgcn_raw_buffer_load_b32(sview, soff_l + 64u, so, 0));
   };
@@ -269,7 +275,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int step_abs = 2 * i + t;
     constexpr int su = GROUPED ? ((t == 1) ? (u + 1) % P : u) : 0;  // scales of the NEXT step's stage
     const int st_x = i + LA + 1 < NST ? i + LA + 1 : NST - 1;
-    const unsigned xso = (unsigned)st_x * 128u;
+    const unsigned xso = (unsigned)(st0 + st_x) * 128u;
     constexpr int NSLOT = 4 * MT, NI = 2 * (4 + UPARTS);
     auto slot = [&](auto kc) __attribute__((always_inline)) {
       constexpr int k = decltype(kc)::value, mt = k / 4, q = k % 4;
@@ -372,6 +378,53 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   int* ep = reinterpret_cast<int*>(smem);
   const int ej = lane & 15, ecp = lane >> 4;
   constexpr int EP_ITEMS = EPR * (BN / 8), EP_PASSES = EP_ITEMS / NT;  // 16 rows per thread and pass
+  auto image = [&](const int pass) {  // this wave's accumulators of EPR rows -> the row-major LDS image
+#pragma unroll
+    for (int jm = 0; jm < EPR / 16; ++jm)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          ep[(16 * jm + ej) * EP_STRIDE + 64 * wn + 16 * r + 8 * (q & 1) + 4 * (q >> 1) + ecp] = acc[pass * (EPR / 16) + jm][q][r];
+  };
+
+  // ---- in-launch split-K (ksplit > 1): arrival-order tickets as in the panel kernel.  A depositor sends its partial tile
+  // through the SAME LDS transposition as the epilogue and writes it row-major ([ROWS][256] int32, full 1 KiB rows,
+  // write-through) into slot `arrival` of the tile in the caller's reduce buffer C; the last arrival adds the slots to its
+  // own image rows (agent-scope sc1 loads) on the way to the fp16 conversion.  Two ticket words per tile in `workspace`
+  // (arrivals, completed deposits), zero again on exit. ----
+  int arrival = 0;
+  if (ksplit > 1) {
+    int* tk = tickets + 2 * (size_t)tile_lin;
+    int* xch = ep + EPR * EP_STRIDE;  // one word behind the image (a second __shared__ object would de-pipeline the main loop)
+    if (tid == 0) *xch = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    arrival = __builtin_amdgcn_readfirstlane(*xch);
+    const size_t slot_ints = (size_t)ROWS * BN;
+    if (arrival < ksplit - 1) {
+      const __amdgpu_buffer_rsrc_t sv = wide_view(C + ((size_t)tile_lin * (ksplit - 1) + arrival) * slot_ints);
+#pragma unroll
+      for (int pass = 0; pass < ROWS / EPR; ++pass) {
+        __syncthreads();
+        image(pass);
+        __syncthreads();
+#pragma unroll
+        for (int ps = 0; ps < EP_PASSES; ++ps) {
+          const int row = er0 + 8 * ps;
+          const unsigned off = (unsigned)(((pass * EPR + row) * BN + c8 * 8) * 4);
+          const v4i lo = *reinterpret_cast<const v4i*>(ep + row * EP_STRIDE + c8 * 8);
+          const v4i hi4 = *reinterpret_cast<const v4i*>(ep + row * EP_STRIDE + c8 * 8 + 4);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, lo), sv, off, 0, /*sc0 sc1*/ 17);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, hi4), sv, off + 16, 0, /*sc0 sc1*/ 17);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // every wave's part of the deposit has reached memory
+      if (tid == 0) __hip_atomic_fetch_add(tk + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+  }
+
   // every token scale this thread needs, fetched up front (pass by pass each batch paid its own round trip) and pinned here:
   // left alone hipcc sinks every load to its use inside the guarded store below, one exposed round trip per row
   float a_s[ROWS / EPR][EP_PASSES];
@@ -384,45 +437,90 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
   // interior tiles without the test hook: branch-free stores (a guard per row makes hipcc drain the memory queue per row)
   const bool interior = (mbase + ROWS <= M) && (tile_n * BN + BN <= N) && acc_out == nullptr;
-  auto out_row = [&](const int pass, const int ps, const bool guarded) {
-    const int row = er0 + 8 * ps;
-    const int m = mbase + pass * EPR + row;
-    if (guarded && !(m < M && n < N)) return;
-    const v4i lo = *reinterpret_cast<const v4i*>(ep + row * EP_STRIDE + c8 * 8);
-    const v4i hi4 = *reinterpret_cast<const v4i*>(ep + row * EP_STRIDE + c8 * 8 + 4);
-    const h4 o0 = epilogue_vals4(lo[0], lo[1], lo[2], lo[3], a_s[pass][ps], s2v[0], s2v[1]);
-    const h4 o1 = epilogue_vals4(hi4[0], hi4[1], hi4[2], hi4[3], a_s[pass][ps], s2v[2], s2v[3]);
-    h8 o = {o0[0], o0[1], o0[2], o0[3], o1[0], o1[1], o1[2], o1[3]};
-    o = o + bv;  // fp16 add after the fp16 round; without a bias bv = -0.0: x + (-0.0) == x bit for bit for every x, +-0 included
-    *reinterpret_cast<h8*>(D + (size_t)m * N + n) = o;
-    if (guarded && acc_out) {
-      *reinterpret_cast<v4i*>(acc_out + (size_t)m * N + n) = lo;
-      *reinterpret_cast<v4i*>(acc_out + (size_t)m * N + n + 4) = hi4;
+  const bool fold = ksplit > 1;
+  const int32_t* slots = C + (size_t)tile_lin * (size_t)(ksplit - 1) * ((size_t)ROWS * BN);
+  // EP_PASSES / 4 rows at a time: the loads (image rows from LDS, and with a K split the deposits' rows from C) of all of
+  // them are issued before the first conversion, branch-free; only the stores sit behind the edge guard
+  constexpr int RB = EP_PASSES / 4;  // (a deeper batch spills in the fold path: 16 registers per row and slot in flight)
+  auto out_rows = [&](const int pass, const int half, const bool guarded, const bool folding) {
+    v4i lo[RB], hi4[RB];
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+      const int row = er0 + 8 * (half * RB + j);
+      lo[j] = *reinterpret_cast<const v4i*>(ep + row * EP_STRIDE + c8 * 8);
+      hi4[j] = *reinterpret_cast<const v4i*>(ep + row * EP_STRIDE + c8 * 8 + 4);
+    }
+    if (folding) {
+      for (int sl = 0; sl < ksplit - 1; ++sl) {
+        const __amdgpu_buffer_rsrc_t sv = agent_view(slots + (size_t)sl * ((size_t)ROWS * BN));
+        v4i d0[RB], d1[RB];
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+          const unsigned off = (unsigned)(((pass * EPR + er0 + 8 * (half * RB + j)) * BN + c8 * 8) * 4);
+          d0[j] = load16_agent(sv, off);
+          d1[j] = load16_agent(sv, off + 16);
+        }
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+          lo[j] += d0[j];
+          hi4[j] += d1[j];
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+      const int ps = half * RB + j;
+      const int m = mbase + pass * EPR + er0 + 8 * ps;
+      const h4 o0 = epilogue_vals4(lo[j][0], lo[j][1], lo[j][2], lo[j][3], a_s[pass][ps], s2v[0], s2v[1]);
+      const h4 o1 = epilogue_vals4(hi4[j][0], hi4[j][1], hi4[j][2], hi4[j][3], a_s[pass][ps], s2v[2], s2v[3]);
+      h8 o = {o0[0], o0[1], o0[2], o0[3], o1[0], o1[1], o1[2], o1[3]};
+      o = o + bv;  // fp16 add after the fp16 round; without a bias bv = -0.0: x + (-0.0) == x bit for bit for every x, +-0 included
+      if (!guarded || (m < M && n < N)) {
+        *reinterpret_cast<h8*>(D + (size_t)m * N + n) = o;
+        if (guarded && acc_out) {
+          *reinterpret_cast<v4i*>(acc_out + (size_t)m * N + n) = lo[j];
+          *reinterpret_cast<v4i*>(acc_out + (size_t)m * N + n + 4) = hi4[j];
+        }
+      }
     }
   };
 #pragma unroll
   for (int pass = 0; pass < ROWS / EPR; ++pass) {
-    if (pass) __syncthreads();
-#pragma unroll
-    for (int jm = 0; jm < EPR / 16; ++jm)
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          ep[(16 * jm + ej) * EP_STRIDE + 64 * wn + 16 * r + 8 * (q & 1) + 4 * (q >> 1) + ecp] = acc[pass * (EPR / 16) + jm][q][r];
     __syncthreads();
+    image(pass);
+    if (pass == 0 && fold) {
+      // the last arrival: everybody it waits for has arrived already (is depositing) -- short, and bounded as a matter of
+      // principle: a depositor that never completes must not end in a silently wrong D (the launch is aborted instead)
+      if (tid == 0) {
+        int* tk = tickets + 2 * (size_t)tile_lin;
+        int spin = 0;
+        while (__hip_atomic_load(tk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ksplit - 1) {
+          if (++spin > QQQ_SPIN_LIMIT) __builtin_trap();
+          __builtin_amdgcn_s_sleep(2);
+        }
+        __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // workspace zero on return
+        __hip_atomic_store(tk + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    __syncthreads();
+#ifdef QQQ_HANDOFF_ACQUIRE_FENCE  // debugging switch: the formal agent-scope acquire in front of the fold
+    if (pass == 0 && fold) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
     if (pass == 0) {  // (the pin: behind the first image's LDS writes, which cover the loads' round trip)
 #pragma unroll
       for (int p2 = 0; p2 < ROWS / EPR; ++p2)
 #pragma unroll
         for (int ps = 0; ps < EP_PASSES; ++ps) asm volatile("" : "+v"(a_s[p2][ps]));
     }
-    if (interior) {
+    if (interior && !fold) {
 #pragma unroll
-      for (int ps = 0; ps < EP_PASSES; ++ps) out_row(pass, ps, false);
+      for (int hb = 0; hb < EP_PASSES / RB; ++hb) out_rows(pass, hb, false, false);
+    } else if (interior) {
+#pragma unroll
+      for (int hb = 0; hb < EP_PASSES / RB; ++hb) out_rows(pass, hb, false, true);
     } else {
 #pragma unroll
-      for (int ps = 0; ps < EP_PASSES; ++ps) out_row(pass, ps, true);
+      for (int hb = 0; hb < EP_PASSES / RB; ++hb) out_rows(pass, hb, true, fold);
     }
   }
 #ifdef QQQ_PANEL_TRACE

@@ -110,9 +110,14 @@ def _check_plan(m, n, k, grouped, max_par):
     p = _lib.plan(m, n, k, gs, max_par)
     assert p["kernel"] in (1, 2, 3, 4, 5) and p["ksplit"] >= 1
     cap_rows, cap_tk = max_par * 64, (n // 128) * max_par
-    if p["kernel"] == 5:  # wide: 256 x 256 tiles, no split-K, no scratch at all; 32-bit offsets into the packed weights
-        assert m > 256 and n % 64 == 0 and k % 64 == 0 and p["ksplit"] == 1 and n * k // 2 < 2**32
-        assert p["pf"] in (3, 6) and p["stages"] in (1, 3) and p["pw"] in (4, 8, 16, 32) and p["mt"] in (8, 16)
+    if p["kernel"] == 5:  # wide: 256 x 256 tiles; 32-bit offsets into the packed weights; one slot of C per depositing slice
+        assert m > 256 and n % 64 == 0 and k % 128 == 0 and n * k // 2 < 2**32
+        assert p["pf"] in (3, 6) and p["stages"] == 1 and p["pw"] in (4, 8, 16, 32) and p["mt"] in (8, 16)
+        rows = 16 * p["mt"]
+        tiles = -(-m // rows) * -(-n // 256)
+        if p["ksplit"] > 1:
+            assert tiles * rows * 256 * (p["ksplit"] - 1) <= cap_rows * n and 2 * tiles <= cap_tk and p["ksplit"] <= (k // 128) // 4
+        assert _lib.plan(m, n, k, gs, max_par, have_scratch=False)["ksplit"] == 1
         return p
     if p["kernel"] == 4:  # panel: one slot of C per depositing slice, two ticket words per tile
         rows, bn = 16 * p["mt"], p["bm"]
@@ -194,13 +199,17 @@ def test_dispatch_of_the_baseline_sweep(L):
     assert _lib.plan(16, N, K, -1, 16)["kernel"] == 1
     p = _lib.plan(128, N, K, -1, 16)
     assert (p["kernel"], p["mt"], p["ksplit"]) == (4, 8, 4)
-    # 1024 tokens (one round of 128 x 256 tiles): the panel kernel with 64 columns per wave, both modes
-    p, g = _lib.plan(1024, N, K, -1, 16), _lib.plan(1024, N, K, 128, 16)
+    # 640 - 1024 tokens: per-channel the wide kernel's 128-token tiles (one round of 128 x 256 tiles, no split); per-group its
+    # 256-token tiles with two K slices (128 tiles x 2 slices = one round: the re-quantiser wants 256 tokens per weight operand)
+    for m in (640, 768, 1024):
+        p, g = _lib.plan(m, N, K, -1, 16), _lib.plan(m, N, K, 128, 16)
+        assert (p["kernel"], p["mt"], p["ksplit"]) == (5, 8, 1), (m, p)
+        assert (g["kernel"], g["mt"], g["ksplit"]) == (5, 16, 2), (m, g)
+    p = _lib.plan(1024, N, K, -1, 16, tune=dict(kernel=4, bm=256, mt=8, pw=2))  # the round-2 choice stays available
     assert (p["kernel"], p["bm"], p["mt"], p["pw"], p["ksplit"]) == (4, 256, 8, 2, 1), p
-    assert (g["kernel"], g["bm"], g["pw"]) == (4, 256, 2), g
     # from ~1.5 K tokens (>= 3/4 of a round of 256 x 256 tiles) the wide kernel, both modes (round 3:
     # profiles/r03_wide_*.txt -- M=4096 556 -> 478 us per-channel, 759 -> 620 us per-group)
-    for m in (1536, 2048, 4096, 8192):
+    for m in (1280, 1536, 2048, 4096, 8192):
         for gs in (-1, 128):
             p = _lib.plan(m, N, K, gs, 16)
             assert (p["kernel"], p["ksplit"], p["pf"], p["stages"], p["pw"]) == (5, 1, 3, 1, 8), (m, gs, p)

@@ -433,6 +433,53 @@ def test_panel_inlaunch_splitk_stress_two_streams(dev):
         assert int(h.ws.abs().sum().item()) == 0
 
 
+def test_wide_inlaunch_splitk_stress_two_streams(dev):
+    """The wide kernel's ticket / slot hand-off under load (row-major partial tiles written through to C, folded by the last
+    arrival with agent-scope loads, no acquire fence): two layers with their own scratch hammered from two streams, both tile
+    heights, 2-3 K slices, ragged m; every result equal to the unsplit stream kernel's bit for bit, workspaces all-zero after."""
+    from qqq_amd import pack as P
+
+    g = torch.Generator(device="cpu").manual_seed(321)
+    N, K = 2048, 4096
+    layers = []
+    for i in range(2):
+        grouped = i == 1
+        codes = torch.randint(0 if grouped else -7, 16 if grouped else 8, (K, N), generator=g, dtype=torch.int8)
+        B = P.pack_codes(codes.to(dev), grouped)
+        s2 = (torch.rand((1, N), generator=g) * 2e-4 + 1e-5).to(torch.float32)
+        s3 = (torch.rand((K // 128, N), generator=g) * 15.0 + 0.5).to(torch.float16) if grouped else None
+        layers.append(GemmHarness(B, s2, s3, dev))
+    Ms = [129, 256, 300, 512, 700, 1024]
+    toks, want = {}, {}
+    for M in Ms:
+        A = torch.randint(-128, 128, (M, K), generator=g, dtype=torch.int8).to(dev)
+        s1 = (torch.rand((M, 1), generator=g) * 0.05 + 0.001).to(torch.float32).to(dev)
+        toks[M] = (A, s1)
+        for li, h in enumerate(layers):
+            D = torch.empty((M, N), dtype=torch.float16, device=dev)
+            ops.qqq_gemm_ex(A, h.B, h.C, D, s1, h.s2, h.s3, h.ws, -1, -1, -1, 16, tune=dict(kernel=1, ksplit=1))
+            want[(li, M)] = D
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    for trial in range(3):
+        outs = []
+        for it in range(100):
+            for li, h in enumerate(layers):
+                M = Ms[(it + 2 * li) % len(Ms)]
+                A, s1 = toks[M]
+                tune = [dict(kernel=5, ksplit=2), dict(kernel=5, mt=8, ksplit=2), dict(kernel=5, ksplit=3), dict(kernel=5, mt=8, ksplit=3, pf=6),
+                        dict(kernel=5, ksplit=2, pw=4)][it % 5]
+                D = torch.empty((M, N), dtype=torch.float16, device=dev)
+                with torch.cuda.stream(streams[li]):
+                    ops.qqq_gemm_ex(A, h.B, h.C, D, s1, h.s2, h.s3, h.ws, -1, -1, -1, 16, tune=tune)
+                outs.append((li, M, D, tune))
+        torch.cuda.synchronize()
+        for li, M, D, tune in outs:
+            assert torch.equal(D.view(torch.int16), want[(li, M)].view(torch.int16)), (trial, li, M, tune)
+    for h in layers:
+        assert int(h.ws.abs().sum().item()) == 0
+
+
 def test_panel_two_workgroups_per_cu(dev):
     """More panel workgroups than CUs, light enough (64-token m-blocks) for two to share a CU: the waves of a workgroup
     then drift apart behind a barrier.  Regression for a race of the two-buffer activation ring (the first step's fragment
