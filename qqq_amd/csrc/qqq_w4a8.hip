@@ -507,11 +507,14 @@ static double wide_estimate(int M, int N, int K, bool grouped, bool have_scratch
       // one slot of rows x 256 ints per tile and depositing slice inside C, two ticket words per tile; hand-off (256 KiB deposit
       // written through + its fold by the last arrival)
       if (ks > 1 && (!have_scratch || 2 * tl > cap_tickets || tl * rows * 256 * (ks - 1) > cap_rows * (long long)N || ks > NST / 4)) break;
-      // rounds: workgroups of later rounds start as CUs free up, but the XCDs' queues drain unevenly -- between the exact
-      // ratio and its ceiling (344 tiles measured 1.7 rounds, 688 tiles 2.8; profiles/r03_dispatch_check_wide2.txt)
+      // rounds: workgroups of later rounds start as CUs free up, but the XCDs' queues drain unevenly -- close to the ceiling of
+      // the ratio (288-344 tiles measured 1.7-1.8 rounds, 688 tiles 2.8-3; profiles/r03_dispatch_check_wide2.txt).  A partly
+      // filled single round runs each tile faster: the part is power-limited (160 of 256 CUs busy: 1.10 us per stage, not 1.34)
       const double x = (double)(tl * ks) / 256.0;
-      const double rounds = x <= 1.0 ? 1.0 : 0.5 * (x + (double)((tl * ks + 255) / 256));
-      const double us = 3.7 + rounds * (fixed + (ks > 1 ? 20.0 : 0.0) + ((double)NST / ks) * t_stage);
+      const double cx = (double)((tl * ks + 255) / 256);
+      const double rounds = x <= 1.0 ? 1.0 : cx - 0.3 * (cx - x);
+      const double load = x <= 1.0 ? 0.6 + 0.4 * x : 1.0;
+      const double us = 3.7 + rounds * (fixed + (ks > 1 ? 20.0 : 0.0) + ((double)NST / ks) * t_stage * load);
       if (us < best) {
         best = us;
         *ks_out = ks;
