@@ -2,6 +2,7 @@
 
     qqq_amd/libqqq_amd.so      the operator (include/qqq_amd.h)      <- csrc/qqq_w4a8.hip (+ csrc/*.hip.h)
     qqq_amd/libqqq_amd_dev.so  test / tuning companion (include/qqq_amd_dev.h) <- csrc/qqq_dev.hip
+    qqq_amd/_torch_ext*.so     compiled torch binding (pybind + TORCH_LIBRARY) of the operator library <- csrc/qqq_torch.cpp
 
 The .so files are git-ignored but travel to the GPU box with the repo snapshot.
 """
@@ -65,6 +66,44 @@ def build_dev(force: bool = False, verbose: bool = False) -> str:
     return _compile(DEV_SRC, DEV_LIB, verbose)
 
 
+TORCH_SRC = os.path.join(_HERE, "csrc", "qqq_torch.cpp")
+
+
+def torch_ext_path() -> str:
+    import sysconfig
+
+    return os.path.join(_HERE, "_torch_ext" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+
+
+def build_torch_ext(force: bool = False, verbose: bool = False) -> str:
+    """g++ against torch's own headers (a ROCm torch ships c10/hip/*.h): no kernel code, no hipify -- the module only forwards
+    data_ptr()s and the current HIP stream to libqqq_amd.so, which it finds next to itself ($ORIGIN)."""
+    import sysconfig
+
+    import torch
+    from torch.utils import cpp_extension as ce
+
+    out = torch_ext_path()
+    default_lib = os.path.join(_HERE, "libqqq_amd.so")
+    if not os.path.exists(default_lib):
+        raise RuntimeError("build the operator library first (qqq_amd.build.build())")
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(TORCH_SRC), os.path.getmtime(HDR)):
+        return out
+    tdir = os.path.dirname(torch.__file__)
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", "-DTORCH_EXTENSION_NAME=_torch_ext",
+           "-DTORCH_API_INCLUDE_EXTENSION_H", "-Wno-deprecated-declarations"]
+    cmd += [f"-I{p}" for p in ce.include_paths()] + [f"-I{sysconfig.get_paths()['include']}", "-I/opt/rocm/include"]
+    cmd += [TORCH_SRC, "-o", out + ".tmp", f"-L{tdir}/lib", "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch", "-ltorch_python",
+            f"-L{_HERE}", "-lqqq_amd", "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{tdir}/lib"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(out + ".tmp", out)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))
     print(build_dev(force=True, verbose=True))
+    print(build_torch_ext(force=True, verbose=True))

@@ -236,3 +236,39 @@ def test_dispatch_of_the_baseline_sweep(L):
     # short-K layers at large m: the wide kernel since its uniform schedule (profiles/r03_wide_uniform_schedule.txt: 11008 x 4096,
     # 32 K tokens 1174 vs 1429 us for the tiled kernel); the panel shapes' per-tile fixed costs weigh more there
     assert _lib.plan(8192, 4096, 4096, -1, 16)["kernel"] == 5
+
+
+def test_compiled_torch_binding_imports_and_keeps_the_error_contract():
+    """csrc/qqq_torch.cpp -> qqq_amd/_torch_ext*.so (the reference binds through pybind, csrc/pybind.cpp:3-5): built by
+    __graft_entry__.build(), imports without a GPU, registers the qqq_amd_native ops, and raises the SAME messages as the ctypes
+    path for the same bad calls (there is no CPU path in either)."""
+    import torch
+
+    from qqq_amd import build as kb, ops
+
+    kb.build()
+    kb.build_torch_ext()
+    E = ops._ext()
+    assert E is not None and E.abi_version() == 2
+    assert hasattr(torch.ops.qqq_amd_native, "qqq_gemm") and hasattr(torch.ops.qqq_amd_native, "dynamic_quant")
+    A = torch.zeros((4, 128), dtype=torch.int8)
+    B = torch.zeros((8, 256), dtype=torch.int32)
+    C = torch.zeros((1024, 128), dtype=torch.int32)
+    D = torch.zeros((4, 128), dtype=torch.float16)
+    s1, s2, s3 = torch.zeros((4, 1)), torch.zeros((1, 128)), torch.zeros(0, dtype=torch.float16)
+    ws = torch.zeros(16, dtype=torch.int32)
+    cases = [
+        (dict(), "must live on the same GPU as A"),
+        (dict(s1=s1.double()), "s1 dtype must be float32, but got"),
+        (dict(ws=torch.zeros(3, dtype=torch.int32)), "workspace must be of size at least 16."),
+        (dict(s3=torch.zeros((3, 128), dtype=torch.float16)), "k=128 not compatible with 3 groups."),
+    ]
+    for kw, msg in cases:
+        args = dict(A=A, B=B, C=C, D=D, s1=s1, s2=s2, s3=s3, ws=ws)
+        args.update(kw)
+        for fn in (E.qqq_gemm, ops._qqq_gemm_impl):
+            with pytest.raises(RuntimeError) as ei:
+                fn(args["A"], args["B"], args["C"], args["D"], args["s1"], args["s2"], args["s3"], args["ws"], -1, -1, -1, 16)
+            assert msg in str(ei.value), (fn, msg, str(ei.value)[:200])
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        E.dynamic_quant(torch.zeros((2, 64), dtype=torch.float16))

@@ -22,8 +22,14 @@ def loop(fn, n=2000):
     return (t1 - t0) / n * 1e6, (t2 - t0) / n * 1e6
 f_op = lambda: ops.qqq_gemm(A, layer.Bs[0], layer.C, D, s1, layer.s2, layer.s3, layer.ws, -1, -1, -1, 16)
 f_direct = lambda: ops._qqq_gemm_impl(A, layer.Bs[0], layer.C, D, s1, layer.s2, layer.s3, layer.ws, -1, -1, -1, 16)
-print("custom op  : enqueue %.1f us/call, wall %.1f us/call" % loop(f_op))
-print("direct     : enqueue %.1f us/call, wall %.1f us/call" % loop(f_direct))
+f_disp = lambda: ops._qqq_gemm_op(A, layer.Bs[0], layer.C, D, s1, layer.s2, layer.s3, layer.ws, -1, -1, -1, 16)
+f_native = lambda: torch.ops.qqq_amd_native.qqq_gemm(A, layer.Bs[0], layer.C, D, s1, layer.s2, layer.s3, layer.ws, -1, -1, -1, 16)
+print("compiled torch binding present:", ops._ext() is not None)
+print("qqq_gemm (eager: compiled binding if present)   : enqueue %.1f us/call, wall %.1f us/call" % loop(f_op))
+print("ctypes binding (_qqq_gemm_impl)                 : enqueue %.1f us/call, wall %.1f us/call" % loop(f_direct))
+print("python custom op through the dispatcher         : enqueue %.1f us/call, wall %.1f us/call" % loop(f_disp))
+if ops._ext() is not None:
+    print("TORCH_LIBRARY op qqq_amd_native::qqq_gemm       : enqueue %.1f us/call, wall %.1f us/call" % loop(f_native))
 import numpy as np
 print("native loop: %.1f us/call (HIP events)" % float(np.mean(layer.time_calls(A, s1, D, 200)) * 1e3))
 x = torch.randn((1, 4096), device=dev, dtype=torch.float16)
