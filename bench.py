@@ -474,6 +474,36 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # N > 1: where the step's time goes at the sharded points: GEMM-only, all-gather-only, overlapped total;
+    # event-timed on the launch stream after the timed region, max over ranks
+    multi = None
+    if world > 1:
+        multi = {}
+        for j, M in enumerate(SWEEP_M):
+            if M not in sharded:
+                continue
+            sg, a_loc, s1_loc = sharded[M]
+            res = {}
+            for name, kw in (("gemm_only_us", dict(do_gather=False)), ("allgather_only_us", dict(do_gemm=False)), ("overlapped_us", {})):
+                for _ in range(2):
+                    sg(a_loc, s1_loc, M, N_FULL, Dfull[M], local=True, **kw)
+                barrier()
+                reps = 8
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    sg(a_loc, s1_loc, M, N_FULL, Dfull[M], local=True, **kw)
+                e1.record()
+                torch.cuda.synchronize()
+                t = torch.tensor([e0.elapsed_time(e1) * 1e3 / reps], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                res[name] = float(t.item())
+            from qqq_amd.parallel import pick_chunks
+
+            res["chunks"] = pick_chunks(M, N_FULL, world, K_FULL)
+            res["rows_per_rank"] = -(-M // world)
+            multi[str(M)] = res
+
     if args.check and world > 1:
         for j, M in enumerate(SWEEP_M):
             if M in sharded:
@@ -508,6 +538,8 @@ def main():
         },
     }
 
+    if multi:
+        result["multi_gpu"] = multi
     if step_us:
         result["step_us"] = {"min": float(np.min(step_us)), "median": float(np.median(step_us)), "max": float(np.max(step_us)),
                              "n": len(step_us), "note": "event-timed replays after the timed region"}

@@ -102,7 +102,10 @@ class ShardedGemm:
         return row_spans(M_total, world, dist.get_rank(self.group), chunks)
 
     def __call__(self, A: torch.Tensor, s1: torch.Tensor, M_total: int, N: int,
-                 D_full: Optional[torch.Tensor] = None, local: bool = False) -> torch.Tensor:
+                 D_full: Optional[torch.Tensor] = None, local: bool = False, do_gemm: bool = True,
+                 do_gather: bool = True) -> torch.Tensor:
+        """do_gemm / do_gather = False leave out one half of the pipeline (bench.py times GEMM-only and all-gather-only next
+        to the overlapped total); the result is only meaningful with both."""
         world = dist.get_world_size(self.group)
         rank = dist.get_rank(self.group)
         chunks = self.chunks if self.chunks else pick_chunks(M_total, N, world)
@@ -142,8 +145,11 @@ class ShardedGemm:
                 slab = self._tail
             piece = slab[rank * w : (rank + 1) * w]  # in-place all-gather: this rank's piece inside the output slab
             if e > s:
-                self.gemm_fn(A_local[off : off + (e - s)], s1_local[off : off + (e - s)], piece[: e - s])
+                if do_gemm:
+                    self.gemm_fn(A_local[off : off + (e - s)], s1_local[off : off + (e - s)], piece[: e - s])
                 off += e - s
+            if not do_gather:
+                continue
             if use_streams:
                 comm.wait_stream(torch.cuda.current_stream(dev))
                 with torch.cuda.stream(comm):

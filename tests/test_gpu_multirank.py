@@ -28,6 +28,10 @@ def test_bench_two_ranks_one_gpu_gloo(dev):
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0
+    # GEMM-only, all-gather-only and overlapped totals of the sharded points; the M=4096 point is pipelined
+    mg = out["multi_gpu"]["4096"]
+    assert mg["chunks"] >= 2 and mg["rows_per_rank"] == 2048
+    assert all(mg[k] > 0 for k in ("gemm_only_us", "allgather_only_us", "overlapped_us"))
 
 
 def test_bench_two_ranks_rccl_when_two_gpus():
