@@ -19,15 +19,22 @@ Parity status ("what pins this oracle"):
                                               CUDA/ROCm torch semantics differ in
                                               one documented place, see below).
   * int32 accumulators + fp16 epilogue     -- restated from csrc/qqq_gemm.cu (the
-                                              CUDA kernel cannot be built or run
-                                              anywhere in this project: no nvcc, PTX
-                                              inline asm).  The reference ships NO
-                                              tests / golden vectors for it.  It is
-                                              cross-checked against the fake-quant
-                                              float path the reference defines
-                                              (D ~= (xq*s1) @ W_fq.T) with an absolute
-                                              tolerance.  => "parity partially
-                                              unpinned" for the GEMM arithmetic.
+                                              CUDA kernel cannot be built or run anywhere
+                                              in this project: no nvcc, PTX inline asm; the
+                                              reference ships NO tests / golden vectors for
+                                              it).  PINNED two ways since round 3:
+                                              (1) tests/marlin_model.py follows Marlin<>
+                                              thread by thread (its own index expressions,
+                                              ldmatrix / mma.m16n8k16 fragment layouts,
+                                              reduce and write-out) on reference-packed
+                                              operands and reproduces this oracle's
+                                              accumulators and outputs bit for bit
+                                              (tests/test_marlin_model_cpu.py);
+                                              (2) cross-checked against the fake-quant float
+                                              path the reference defines (D ~= (xq*s1) @
+                                              W_fq.T) with an absolute tolerance.  What is
+                                              taken from the PTX ISA rather than from a run:
+                                              the semantics of the instructions themselves.
 """
 from __future__ import annotations
 

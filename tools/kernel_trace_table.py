@@ -12,6 +12,10 @@ for f in glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursi
             continue
         name = name[5:] if name.startswith("void ") else name
         name = name.split("(")[0]
+        if name.startswith("_Z"):  # rocprofv3 leaves some template instances mangled
+            sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+            from code_object import _demangle
+            name = _demangle(name)
         grid = (int(r["Grid_Size_X"]), int(r["Grid_Size_Y"]), int(r["Grid_Size_Z"]))
         wg = (int(r["Workgroup_Size_X"]), int(r["Workgroup_Size_Y"]), int(r["Workgroup_Size_Z"]))
         wgs = tuple(g // max(w, 1) for g, w in zip(grid, wg))

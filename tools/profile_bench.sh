@@ -3,15 +3,15 @@
 # roofline kernels; everything under gpurun_out/prof_bench/, summaries are copied to profiles/ by hand.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; R=$PWD; O=$R/gpurun_out/prof_bench; rm -rf $O; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- python $R/bench.py --no-cpu --no-fp16 --no-pmc --steps 20 --warmup 5 > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- python $R/bench.py --no-cpu --no-fp16 --no-pmc --steps 40 --warmup 5 > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
 python $R/tools/kernel_trace_table.py $O/trace > $O/bench_kernels_by_shape.csv
 cat $O/bench_kernels_by_shape.csv | cut -c1-220
 cd $R
-bash tools/pmc_kernel.sh panel_m4096 4096 pc '{}' > /dev/null 2>&1
-bash tools/pmc_kernel.sh tiled_m4096 4096 pc '{"kernel": 2}' > /dev/null 2>&1
-bash tools/pmc_kernel.sh panel_m1024 1024 pc '{}' > /dev/null 2>&1
+bash tools/pmc_kernel.sh wide_m4096 4096 pc '{}' > /dev/null 2>&1
+bash tools/pmc_kernel.sh wide_m1024 1024 pc '{}' > /dev/null 2>&1
 bash tools/pmc_kernel.sh panel_m128 128 pc '{}' > /dev/null 2>&1
 bash tools/pmc_kernel.sh stream_m16 16 pc '{}' > /dev/null 2>&1
 bash tools/pmc_kernel.sh column_m1 1 pc '{}' > /dev/null 2>&1
-bash tools/pmc_kernel.sh tiled_m4096_g128 4096 g128 '{}' > /dev/null 2>&1
-for t in panel_m4096 tiled_m4096 panel_m1024 panel_m128 stream_m16 column_m1 tiled_m4096_g128; do echo "#### $t"; grep -v "^   [A-Z]" gpurun_out/pmc_$t/summary.txt; done
+bash tools/pmc_kernel.sh wide_m4096_g128 4096 g128 '{}' > /dev/null 2>&1
+bash tools/pmc_kernel.sh wide_m1024_g128 1024 g128 '{}' > /dev/null 2>&1
+for t in wide_m4096 wide_m1024 panel_m128 stream_m16 column_m1 wide_m4096_g128 wide_m1024_g128; do echo "#### $t"; cat gpurun_out/pmc_$t/summary.txt; done
