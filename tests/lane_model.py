@@ -438,3 +438,112 @@ def panel_kernel_model(A, B, s3, M, N, K, MT, WN, KG, HW, ksplit, grouped):
                     if w > 0:
                         out[m, n0 : n0 + w] += tile[row, :w]
     return out
+
+
+def wide_tile_order(tiles_m, tiles_n, ksplit, PW):
+    """(tile_m, tile_n, slice) of every block id of the wide kernel's 1-D grid: block b runs on XCD b % 8; an XCD walks a
+    contiguous run of the panel-major sequence (panels of PW strips x all m-tiles), the slices of a tile take consecutive
+    positions of the run (qqq_wide.hip.h: "XCD-aware tile order")."""
+    ntot = tiles_m * tiles_n * ksplit
+    q, rr = ntot >> 3, ntot & 7
+    out = []
+    for bid in range(ntot):
+        xcd, idx = bid & 7, bid >> 3
+        lin2 = (xcd * (q + 1) if xcd < rr else rr * (q + 1) + (xcd - rr) * q) + idx
+        lin, sp = lin2 // ksplit, lin2 % ksplit
+        full = (tiles_n // PW) * PW * tiles_m
+        if lin < full:
+            panel, within = lin // (PW * tiles_m), lin % (PW * tiles_m)
+            tm, tn = within // PW, panel * PW + within % PW
+        else:
+            rem, pw = lin - full, tiles_n % PW
+            tm, tn = rem // pw, (tiles_n // PW) * PW + rem % pw
+        out.append((tm, tn, sp, lin))
+    return out
+
+
+def wide_kernel_model(A, B, s3, M, N, K, MT, ksplit, grouped, PW=8):
+    """qqq_wide_kernel: a workgroup = 16*MT tokens x 256 columns x one K slice, four waves; wave wn owns the 64-column group
+    tile_n*4 + wn (both halves) and all m-tiles.  Weights: buffer loads at lane offset h*rowbytes + cq*64 + q4*16 (+256 per
+    half) over the descriptor base B + ng*512, scalar offset 4*(2*st0 + s)*rowbytes, quad transpose; activations: chunk
+    (row (tid >> 3) + 32 q, piece tid & 7) of a stage to LDS at row*128 + ((pos ^ ((row >> 1) & 7)) << 4) (+ q*4096), scalar
+    offset (st0 + st)*128 over the base A + mbase*K; fragments as in the panel kernel; epilogue / split-K slot image
+    row-major [ROWS][256] with column 64*wn + 16*r + 8*b + 4*hf + c'.  Returns (acc [M,N], the list of slot images)."""
+    assert K % 128 == 0
+    Bb = np.ascontiguousarray(B).view(np.uint8).reshape(-1)
+    Ab = np.ascontiguousarray(A).view(np.uint8).reshape(-1)
+    s3h = None if not grouped else np.ascontiguousarray(s3).reshape(-1)
+    rowbytes = N * 8
+    ROWS, BN = 16 * MT, 256
+    XPT = ROWS * 128 // 16 // 256
+    ngroups = N >> 6
+    tiles_m, tiles_n = -(-M // ROWS), -(-N // BN)
+    lane = np.arange(64)
+    h, cq, q4 = lane >> 4, (lane >> 2) & 3, lane & 3
+    tid = np.arange(256)
+    xr0, xpos = tid >> 3, tid & 7
+    out = np.zeros((M, N), np.int64)
+    seen = set()
+    partial = {}
+    for (tile_m, tile_n, sp, lin) in wide_tile_order(tiles_m, tiles_n, ksplit, PW):
+        assert (tile_m, tile_n, sp) not in seen and tile_m < tiles_m and tile_n < tiles_n
+        seen.add((tile_m, tile_n, sp))
+        mbase = tile_m * ROWS
+        st0 = ((K >> 7) * sp) // ksplit
+        nst = ((K >> 7) * (sp + 1)) // ksplit - st0
+        image = np.zeros((ROWS, BN), np.int64)  # this slice's partial tile as the LDS transposition lays it out
+        # activation stage images, built chunk by chunk as the threads store them
+        imgs = []
+        for st in range(nst):
+            img = np.zeros(ROWS * 128, np.uint8)
+            for q in range(XPT):
+                row = np.minimum(xr0 + 32 * q, M - 1 - mbase)          # rows past M: the last row again
+                voff = row * K + xpos * 16                              # 32-bit lane offset over the base A + mbase*K
+                src = mbase * K + voff + (st0 + st) * 128
+                dst = xr0 * 128 + ((xpos ^ ((xr0 >> 1) & 7)) << 4) + q * 4096
+                for t_ in range(256):
+                    img[dst[t_] : dst[t_] + 16] = Ab[src[t_] : src[t_] + 16]
+            imgs.append(img)
+        for wn in range(4):
+            ng = min(tile_n * 4 + wn, ngroups - 1)
+            woff = h * rowbytes + cq * 64 + q4 * 16
+            acc = np.zeros((MT, 4, 64, 4), np.int64)
+            for st in range(nst):
+                for t in range(2):
+                    s = 2 * st + t
+                    ops = []
+                    for hf in range(2):
+                        src = ng * 512 + woff + 256 * hf + 4 * (2 * st0 + s) * rowbytes
+                        w = Bb[src[:, None] + np.arange(16)[None, :]].reshape(64, 4, 4)
+                        w = (w.astype(np.uint32) << (8 * np.arange(4, dtype=np.uint32))).sum(-1).astype(np.uint32)
+                        y = _quad_transpose4(w)
+                        if grouped:
+                            so = ng * 64 + cq * 8 + 2 * q4 + 32 * hf + (st0 + st) * N   # halves: lane offset + 64 B per half + stage
+                            w0, w1 = unpack_pair(y, True, s3h[so][:, None], s3h[so + 1][:, None])
+                        else:
+                            w0, w1 = y & MASK, (y << np.uint32(4)) & MASK
+                        ops += [_bytes_to_i8(w0), _bytes_to_i8(w1)]  # q = 2*hf + b
+                    for mt in range(MT):
+                        ad = panel_fragment_addr(mt, t)
+                        x = imgs[st][ad[:, None] + np.arange(16)[None, :]].view(np.int8)
+                        for q in range(4):
+                            acc[mt, q] += mfma_16x16x64(ops[q], x)
+            j, cp = lane & 15, lane >> 4
+            for mt in range(MT):
+                for q in range(4):
+                    for r in range(4):
+                        col = 64 * wn + 16 * r + 8 * (q & 1) + 4 * (q >> 1) + cp
+                        np.add.at(image, (16 * mt + j, col), acc[mt, q, :, r])
+        partial.setdefault((tile_m, tile_n), []).append(image)
+    assert len(seen) == tiles_m * tiles_n * ksplit
+    slots = []
+    for (tile_m, tile_n), parts in partial.items():
+        tile = sum(parts)                       # arrival order is irrelevant: integer adds
+        slots += parts[:-1]                     # every slice but the last arrival deposits its image, row-major
+        for row in range(ROWS):
+            m = tile_m * ROWS + row
+            if m < M:
+                n0 = tile_n * BN
+                w = min(BN, N - n0)
+                out[m, n0 : n0 + w] += tile[row, :w]
+    return out, slots

@@ -107,3 +107,34 @@ def test_panel_split_k_slot_and_fragment_layout():
                     for d in range(4):
                         banks.setdefault(((addr[l] // 4) + d) % 64, set()).add(int(addr[l]) + 4 * d)
                 assert max(len(v) for v in banks.values()) == 1, (mt, tk)
+
+
+@pytest.mark.parametrize("grouped", [False, True])
+def test_wide_kernel_model(grouped):
+    """the wide kernel's address arithmetic (round 3): buffer-descriptor offsets of the weight / scale / activation loads, the
+    chunk-by-chunk LDS stage image, fragment reads, the row-major epilogue / split-K slot image, K slices, ragged m and n,
+    both tile heights, and the XCD-aware 1-D tile order with the slices of a tile side by side"""
+    rng = np.random.default_rng(17)
+    K = 512
+    A, B, s3, acc = _case(rng, 300, 320, K, grouped)       # N % 256 == 64, m not a multiple of either tile height
+    kw = dict(grouped=grouped)
+    got, _ = LM.wide_kernel_model(A, B, s3, 300, 320, K, MT=16, ksplit=1, **kw)
+    assert np.array_equal(got, acc)
+    got, slots = LM.wide_kernel_model(A, B, s3, 300, 320, K, MT=8, ksplit=2, PW=4, **kw)
+    assert np.array_equal(got, acc) and len(slots) == 3 * 2 * 1 and all(sl.shape == (128, 256) for sl in slots)
+    A, B, s3, acc = _case(rng, 70, 512, 1024, grouped)
+    got, slots = LM.wide_kernel_model(A, B, s3, 70, 512, 1024, MT=16, ksplit=3, **kw)
+    assert np.array_equal(got, acc) and len(slots) == 2 * 2
+
+
+def test_wide_tile_order_is_a_bijection_and_keeps_slices_together():
+    for (tm, tn, ks, pw) in ((16, 32, 1, 8), (4, 32, 2, 8), (5, 43, 1, 8), (3, 7, 3, 4), (1, 1, 2, 8), (8, 16, 1, 16)):
+        order = LM.wide_tile_order(tm, tn, ks, pw)
+        assert sorted((a, b, c) for a, b, c, _ in order) == [(a, b, c) for a in range(tm) for b in range(tn) for c in range(ks)]
+        # the slices of a tile sit at consecutive positions of one XCD's run: block ids 8 apart (same XCD) or the run's edge
+        pos = {}
+        for bid, (a, b, c, lin) in enumerate(order):
+            pos.setdefault((a, b), []).append(bid)
+        if ks > 1:  # only a tile that straddles the edge between two XCDs' runs is split: at most 7 of them
+            split = sum(len({p % 8 for p in v}) > 1 for v in pos.values())
+            assert split <= 7, (tm, tn, ks, split, len(pos))
