@@ -60,8 +60,9 @@ typedef struct qqq_tune {
                   3 = "column" (decode: 32 columns x all of K per workgroup, no split-K),
                   4 = "panel" (m-blocks of up to 128 tokens: all tokens of an m-block x bm columns x a K slice per
                       workgroup, weights straight to VGPRs, activations shared through LDS, in-launch split-K),
-                  5 = "wide" (256 tokens x 256 columns per workgroup, four waves with 512 registers each -- 256 int32
-                      accumulators per lane --, weights straight to VGPRs, activations through LDS, no split-K: large m) */
+                  5 = "wide" (256 -- mt = 8: 128 -- tokens x 256 columns per workgroup, four waves with 512 registers each, 256
+                      int32 accumulators per lane, weights straight to VGPRs, activations through LDS, in-launch split-K
+                      through row-major slots of C: from ~640 tokens up) */
   int ksplit;  /* 0 auto, else number of K slices (partials go through C)                   */
   int waves;   /* stream: waves per workgroup (4, 8 or 16); panel (bm = 128): 4 or 8 (two k-groups); 0 auto */
   int fused;   /* split-K finish; 0 auto.  stream: 1 = last-arriving workgroup reduces in-launch (tickets in
@@ -74,8 +75,8 @@ typedef struct qqq_tune {
                   (2..12); panel: weight ring depth in 128-k stages (2, 3, 4; 8 for mt <= 4); wide: weight ring depth in
                   64-k steps (3, 6); 0 auto                                                                  */
   int stages;  /* tiled + LDS-DMA: ring depth 2..7 (0 auto); panel: activation lead in stages -- with pf = 4 it is 2
-                  unless 4 is asked for, otherwise it equals pf; wide: activation register lead in stages (1, 3) */
-  int mt;      /* stream: 16-token tiles per workgroup (1..4); column: 1..2; panel: 1, 2, 4, 8; 0 auto  */
+                  unless 4 is asked for, otherwise it equals pf */
+  int mt;      /* stream: 16-token tiles per workgroup (1..4); column: 1..2; panel: 1, 2, 4, 8; wide: 16, 8; 0 auto */
   int pw;      /* tiled, wide: weight strips per XCD panel of the tile order (4, 8, 16, 32); panel (bm = 256, mt = 8):
                   32-column sets per wave (1, or 2 = 4 waves x 64 columns x 2 k-groups); 0 auto            */
   int nslots;  /* out (qqq_w4a8_plan only): tile-sized slots of C used by the tiled in-launch split-K  */
