@@ -58,6 +58,21 @@ __device__ __forceinline__ v4u wide_load16(__amdgpu_buffer_rsrc_t view, const un
   return __builtin_amdgcn_raw_buffer_load_b128(view, voff, soff, 0);
 }
 
+// Measurement / tuning: QQQ_WIDE_SLOTMAP=1 keeps the unpack items of the per-channel 256-token shape out of the slots that
+// already carry a memory instruction (fragment re-read, staging write / reload, ring refill): a memory instruction takes
+// more than one issue slot, and with a VALU item behind it the slot overruns its MFMA's 16 cycles.
+#ifndef QQQ_WIDE_SLOTMAP
+#define QQQ_WIDE_SLOTMAP 1  // bit 0: per-channel, bit 1: per-group
+#endif
+__host__ __device__ constexpr bool wide_item_slot(int k) {  // slots of a 64-slot step that take an unpack item
+  return (k % 4 == 0) || (k % 4 == 2 && k != 2 && k != 6) || (k % 8 == 5 && k % 16 != 5);
+}
+__host__ __device__ constexpr int wide_item_slots_before(int k) {  // number of item slots in [0, k)
+  int n = 0;
+  for (int j = 0; j < k; ++j) n += wide_item_slot(j) ? 1 : 0;
+  return n;
+}
+
 template <bool GROUPED, int MT, int P, int RS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void qqq_wide_kernel(
     const int8_t* __restrict__ A, const unsigned char* __restrict__ B, int32_t* __restrict__ C, _Float16* __restrict__ D,
@@ -281,7 +296,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       constexpr int k = decltype(kc)::value, mt = k / 4, q = k % 4;
       mfma(acc[mt][q], aop[cur][q], x[mt]);
       if constexpr (!(QQQ_WIDE_ABLATE & 4)) {
-        constexpr int lo = (k * NI) / NSLOT, hi = ((k + 1) * NI) / NSLOT;
+        // MT == 16: the NI items go to the NE = 34 memory-free slots of the step (per-channel one each, per-group 2-3 each)
+        constexpr bool MAPPED = (QQQ_WIDE_SLOTMAP & (GROUPED ? 2 : 1)) != 0 && MT == 16;
+        constexpr int NE = wide_item_slots_before(64), e = wide_item_slots_before(k);
+        constexpr bool here = wide_item_slot(k);
+        constexpr int lo = MAPPED ? (here ? (e * NI) / NE : 0) : (k * NI) / NSLOT;
+        constexpr int hi = MAPPED ? (here ? ((e + 1) * NI) / NE : 0) : ((k + 1) * NI) / NSLOT;
         qqq_static_for<(hi - lo)>([&](auto jc) {
           constexpr int it = lo + decltype(jc)::value;
           constexpr int hf = it / (4 + UPARTS), w_ = it % (4 + UPARTS);
@@ -302,8 +322,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if constexpr (k % 16 == 5) *reinterpret_cast<v4u*>(smem + xdst_b[(u + LA) % P] + qi * 4096) = xr[0][qi];
         if constexpr (k % 16 == 9) xr[0][qi] = wide_load16(xview, xoff[qi], xso);
       }
-      if constexpr (k == 2 && !(QQQ_WIDE_ABLATE & 8)) load_w(step_abs + RS, wr[sl]);
-      if constexpr (GROUPED && t == 1 && k == 6) load_sc(i + P, scr[u]);
+      if constexpr (!(QQQ_WIDE_ABLATE & 8)) {  // ring refill, one 16-byte load per slot
+        const int sw = step_abs + RS < KS ? step_abs + RS : KS - 1;
+        const unsigned swo = (unsigned)(4 * (2 * st0 + sw)) * rowbytes;
+        if constexpr (k == 2) wr[sl][0] = wide_load16(wview, woff, swo);
+        if constexpr (k == 6) wr[sl][1] = wide_load16(wview, woff + 256u, swo);
+      }
+      if constexpr (GROUPED && t == 1 && k == 1) load_sc(i + P, scr[u]);
       __builtin_amdgcn_sched_barrier(0);
     };
     qqq_static_for<NSLOT>(slot);
