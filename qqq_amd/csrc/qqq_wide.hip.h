@@ -62,7 +62,7 @@ __device__ __forceinline__ v4u wide_load16(__amdgpu_buffer_rsrc_t view, const un
 // already carry a memory instruction (fragment re-read, staging write / reload, ring refill): a memory instruction takes
 // more than one issue slot, and with a VALU item behind it the slot overruns its MFMA's 16 cycles.
 #ifndef QQQ_WIDE_SLOTMAP
-#define QQQ_WIDE_SLOTMAP 1  // bit 0: per-channel, bit 1: per-group
+#define QQQ_WIDE_SLOTMAP 5  // bit 0: per-channel, bit 1: per-group, bit 2: the 128-token shape too
 #endif
 __host__ __device__ constexpr bool wide_item_slot(int k) {  // slots of a 64-slot step that take an unpack item
   return (k % 4 == 0) || (k % 4 == 2 && k != 2 && k != 6) || (k % 8 == 5 && k % 16 != 5);
@@ -297,8 +297,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       mfma(acc[mt][q], aop[cur][q], x[mt]);
       if constexpr (!(QQQ_WIDE_ABLATE & 4)) {
         // MT == 16: the NI items go to the NE = 34 memory-free slots of the step (per-channel one each, per-group 2-3 each)
-        constexpr bool MAPPED = (QQQ_WIDE_SLOTMAP & (GROUPED ? 2 : 1)) != 0 && MT == 16;
-        constexpr int NE = wide_item_slots_before(64), e = wide_item_slots_before(k);
+        constexpr bool MAPPED = (QQQ_WIDE_SLOTMAP & (GROUPED ? 2 : 1)) != 0 && (MT == 16 || (QQQ_WIDE_SLOTMAP & 4) != 0);
+        constexpr int NE = wide_item_slots_before(NSLOT), e = wide_item_slots_before(k);
         constexpr bool here = wide_item_slot(k);
         constexpr int lo = MAPPED ? (here ? (e * NI) / NE : 0) : (k * NI) / NSLOT;
         constexpr int hi = MAPPED ? (here ? ((e + 1) * NI) / NE : 0) : ((k + 1) * NI) / NSLOT;
