@@ -358,10 +358,10 @@ static hipError_t launch_wide_t(const LaunchArgs& a, int pw, int ksplit) {
   return hipGetLastError();
 }
 
-// mt: 16 (256-token tiles) or 8 (128-token tiles); pf: weight ring in 64-k steps (3 or 6)
+// mt: 16 (256-token tiles) or 8 (128-token tiles); pf: weight ring in 64-k steps (4 or 8); four LDS stage buffers
 template <bool GROUPED, int MT>
 static hipError_t launch_wide_m(const LaunchArgs& a, int pf, int pw, int ksplit) {
-  return pf == 3 ? launch_wide_t<GROUPED, MT, 3, 3>(a, pw, ksplit) : launch_wide_t<GROUPED, MT, 3, 6>(a, pw, ksplit);
+  return pf == 4 ? launch_wide_t<GROUPED, MT, 4, 4>(a, pw, ksplit) : launch_wide_t<GROUPED, MT, 4, 8>(a, pw, ksplit);
 }
 static hipError_t launch_wide(const LaunchArgs& a, bool grouped, int mt, int pf, int pw, int ksplit) {
   if (mt == 8) return grouped ? launch_wide_m<true, 8>(a, pf, pw, ksplit) : launch_wide_m<false, 8>(a, pf, pw, ksplit);
@@ -592,8 +592,8 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
     // wide: 256 (mt = 8: 128) tokens x 256 columns per workgroup, 4 waves with 512 registers each; in-launch split-K with
     // one slot of C per depositing slice (row-major partial tiles) and two ticket words per tile
     pl.mt = (t.mt == 8) ? 8 : 16;                         // 16-token m-tiles per workgroup: 256- or 128-token tiles
-    pl.stages = 1;                                        // activation lead: one staging register set, a full stage ahead
-    pl.pf = (t.pf == 6) ? 6 : 3;                          // weight ring in 64-k steps (3: measured 0-4 % faster than 6)
+    pl.stages = 1;                                        // activation lead: the LDS-DMA of a stage is issued a full stage ahead
+    pl.pf = (t.pf == 8 || t.pf == 4) ? t.pf : (grouped ? 8 : 4);  // weight ring in 64-k steps (per-group: 8 measured 1.5 % ahead)
     pl.pw = (t.pw == 4 || t.pw == 8 || t.pw == 16 || t.pw == 32) ? t.pw : 8;
     const int rows = 16 * pl.mt;
     const long long tl = (long long)((M + rows - 1) / rows) * ((N + 255) / 256);

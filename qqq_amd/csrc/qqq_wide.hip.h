@@ -65,12 +65,42 @@ __device__ __forceinline__ v4u wide_load16(__amdgpu_buffer_rsrc_t view, const un
 #define QQQ_WIDE_SLOTMAP 5  // bit 0: per-channel, bit 1: per-group, bit 2: the 128-token shape too
 #endif
 __host__ __device__ constexpr bool wide_item_slot(int k) {  // slots of a 64-slot step that take an unpack item
-  return (k % 4 == 0) || (k % 4 == 2 && k != 2 && k != 6) || (k % 8 == 5 && k % 16 != 5);
+  return (k % 4 == 0) || (k % 4 == 2 && k != 2 && k != 6) || (k % 8 == 5);
 }
 __host__ __device__ constexpr int wide_item_slots_before(int k) {  // number of item slots in [0, k)
   int n = 0;
   for (int j = 0; j < k; ++j) n += wide_item_slot(j) ? 1 : 0;
   return n;
+}
+
+// LDS-DMA staging (QQQ_WIDE_DMA, default): the activations go global -> LDS directly (buffer_load_dwordx4 ... lds, one
+// 16-byte chunk per lane and instruction, lane-linear destination M0 + 16 * lane; the row swizzle is applied on the SOURCE
+// side).  The second ablation (profiles/r03_wide_ablation2.txt) put 10 % of the loop on the staging's reload + ds_write pair
+// -- their issue cost, not their latency.  An LDS-DMA is invisible to hipcc's wait-count bookkeeping, and its counted waits
+// for the VISIBLE loads would then over-wait (vmcnt counts every load in flight), so EVERY vector-memory load of the loop is
+// inline asm and the waits are placed by hand from the static schedule below: loads complete in issue order, so "the load I
+// need is done" == "at most <number of loads issued after it> are outstanding".
+#ifndef QQQ_WIDE_DMA
+#define QQQ_WIDE_DMA 1
+#endif
+// Vector-memory loads slot k of a step (parity t = second step of its stage) issues, in the order the slot issues them.
+__host__ __device__ constexpr int wide_loads_in_slot(bool grouped, int t, int k) {
+  int n = 0;
+  if (grouped && t == 1 && k == 1 && !(QQQ_WIDE_ABLATE & 8)) n += 2;  // the group scales of stage i + P
+  if ((k == 2 || k == 6) && !(QQQ_WIDE_ABLATE & 8)) n += 1;            // weight-ring refill, one half each
+  if (k % 16 == 9 && !(QQQ_WIDE_ABLATE & 2)) n += 1;                   // one activation chunk per lane every 16 slots
+  return n;
+}
+__host__ __device__ constexpr int wide_loads_in_step(bool grouped, int nslot, int t, int from, int to) {  // slots [from, to)
+  int n = 0;
+  for (int k = from; k < to && k < nslot; ++k) n += wide_loads_in_slot(grouped, t, k);
+  return n;
+}
+// Loads issued after slot k0 of a step with parity t0 and before slot k1 of the step `steps` later (>= 1).
+__host__ __device__ constexpr int wide_loads_between(bool grouped, int nslot, int t0, int k0, int steps, int k1) {
+  int n = wide_loads_in_step(grouped, nslot, t0, k0 + 1, nslot);
+  for (int j = 1; j < steps; ++j) n += wide_loads_in_step(grouped, nslot, (t0 + j) & 1, 0, nslot);
+  return n + wide_loads_in_step(grouped, nslot, (t0 + steps) & 1, 0, k1);
 }
 
 template <bool GROUPED, int MT, int P, int RS>
@@ -86,9 +116,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   constexpr int XB = ROWS * 128;         // bytes of one activation stage (128 k)
   constexpr int XPT = XB / 16 / NT;      // 16-byte chunks per thread and stage (8 / 4)
   static_assert((2 * P) % RS == 0, "weight ring (in 64-k steps) must divide the unroll period");
-  constexpr int LA = 2;                  // stage i + LA is written to LDS during stage i (its buffer was last read in i - 1)
-  static_assert(P == 3, "LDS stage buffers = unroll period in stages");
-  constexpr int XL = 1;                  // one staging register set, reloaded chunk by chunk: a full stage of lead
+  // P LDS stage buffers = unroll period in stages.  The LDS-DMA of stage i + LA is ISSUED during stage i (its buffer was last
+  // read in stage i - 1), is waited for at the end of stage i + 1 (a full stage of lead) and published by that stage's barrier:
+  // the fragment reads of stage i + LA begin in the last step of stage i + LA - 1 = i + 2.
+  static_assert(P == 4, "four LDS stage buffers: one being read, one complete, two in flight");
+  constexpr int LA = P - 1;
+  constexpr int NSLOT = 4 * MT;          // issue slots (= MFMAs) of a 64-k step
   constexpr int EPR = (MT == 16) ? 128 : 64;  // rows per epilogue pass (int32 image: EPR x 260 x 4 B = 130 / 65 KiB of LDS)
   constexpr int EP_STRIDE = BN + 4;
 
@@ -135,47 +168,67 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
   // ---- per-lane sources ----
   const int h = lane >> 4, cq = (lane >> 2) & 3, q4 = lane & 3;  // q4: kq as a load lane, jt as an MFMA lane
-  const __amdgpu_buffer_rsrc_t wview = wide_view(B + (size_t)ng * 512);
+  // Every vector-memory load from here to the end of the main loop is inline asm (see QQQ_WIDE_DMA above): descriptors as plain
+  // SGPR quads (base, stride 0, no bound, raw-buffer flags), 32-bit lane offset, scalar step / stage offset.
+  auto descriptor = [](const void* base_uniform) {
+    const unsigned long long a = (unsigned long long)base_uniform;
+    return (v4u){(unsigned)a, (unsigned)(a >> 32), 0xffffffffu, 0x00020000u};
+  };
+  const v4u wdesc = descriptor(B + (size_t)ng * 512);
   const unsigned woff = (unsigned)h * rowbytes + (unsigned)(cq * 64 + q4 * 16);   // + step * 4 * rowbytes (scalar) + 256 * hf
-  const __amdgpu_buffer_rsrc_t sview = wide_view(GROUPED ? (const void*)(s3 + (size_t)ng * 64) : (const void*)B);
+  const v4u sdesc = descriptor(GROUPED ? (const void*)(s3 + (size_t)ng * 64) : (const void*)B);
   const unsigned soff_l = (unsigned)((cq * 8 + 2 * q4) * 2);                      // + stage * N * 2 (scalar) + 64 * hf
-  // activation staging: chunk ci = tid + q * NT of the stage image = (row ci >> 3 = (tid >> 3) + 32 q, 16-byte piece tid & 7)
-  const __amdgpu_buffer_rsrc_t xview = wide_view(A + (size_t)mbase * K);
-  const int xr0 = tid >> 3, xpos = tid & 7;
+  // Activation staging by LDS-DMA: instruction q of wave wn fills the 1 KiB [rows 8 wn + 32 q .. + 8) x 128 bytes of the stage
+  // image, lane l -> byte 16 l of it = (row l >> 3, slot l & 7).  The image keeps the XOR swizzle of the fragment reads
+  // (16-byte piece p of a row sits in slot p ^ ((row >> 1) & 7)), so the lane FETCHES piece slot ^ ((row >> 1) & 7).
+  const v4u xdesc = descriptor(A + (size_t)mbase * K);
+  const int xr0 = tid >> 3, xslot = tid & 7;
   unsigned xoff[XPT];
 #pragma unroll
   for (int q = 0; q < XPT; ++q) {
     int row = xr0 + 32 * q;
     if (mbase + row >= M) row = M - 1 - mbase;  // rows past M: re-read the last row (computed, never stored)
-    xoff[q] = (unsigned)row * (unsigned)K + (unsigned)(xpos * 16);
+    xoff[q] = (unsigned)row * (unsigned)K + (unsigned)((xslot ^ ((xr0 >> 1) & 7)) * 16);  // (rows 32 apart: same swizzle)
   }
-  const unsigned xdst = (unsigned)(xr0 * 128 + ((xpos ^ ((xr0 >> 1) & 7)) << 4));  // + q * 4096 (rows 32 apart: same swizzle)
-  unsigned xdst_b[P];                    // ... per LDS buffer, as registers (the ds_write offset field stops at 64 KiB)
-#pragma unroll
-  for (int b = 0; b < P; ++b) xdst_b[b] = xdst + (unsigned)(b * XB);
+  const unsigned lds_wave = (unsigned)wn * 1024u;  // + buffer * XB + q * 4096: the LDS-DMA's M0
 
   // stage / step indices past the end are redirected to the last one (loaded, never used): the loop stays branch-free
-  auto load_x = [&](const int st_rel, v4u (&r)[XPT]) {
+  // (M0 is reserved: hipcc never allocates it, and nothing else in this kernel uses it.  A write of M0 needs one wait state in
+  // front of the LDS-DMA that reads it: in the loop the write sits one issue slot earlier, dma_m0 / dma_go.)
+  auto dma_m0 = [&](auto bufc, auto qc) __attribute__((always_inline)) {
+    constexpr unsigned dst = (unsigned)(decltype(bufc)::value * XB + decltype(qc)::value * 4096);
+    (void)lds_wave;  // (odr-use: clang does not capture what only an asm operand of a generic lambda names)
+    asm volatile("s_add_u32 m0, %0, %1" : : "s"(lds_wave), "n"(dst) : "scc");
+  };
+  auto dma_go = [&](auto qc, const unsigned so) __attribute__((always_inline)) {
+    (void)xoff[0], (void)xdesc;
+    asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(xoff[decltype(qc)::value]), "s"(xdesc), "s"(so) : "memory");
+  };
+  auto dma_x = [&](auto bufc, auto qc, const unsigned so) __attribute__((always_inline)) {  // chunk q of a stage -> LDS buffer buf
+    dma_m0(bufc, qc);
+    asm volatile("s_nop 0");
+    dma_go(qc, so);
+  };
+  auto dma_stage = [&](auto bufc, const int st_rel) __attribute__((always_inline)) {
     const int st = st_rel < NST ? st_rel : NST - 1;
     const unsigned so = (unsigned)(st0 + st) * 128u;
-#pragma unroll
-    for (int q = 0; q < XPT; ++q) r[q] = wide_load16(xview, xoff[q], so);
+    qqq_static_for<XPT>([&](auto qc) { dma_x(bufc, qc, so); });
   };
-  auto store_x = [&](const int buf, const v4u (&r)[XPT]) {
-#pragma unroll
-    for (int q = 0; q < XPT; ++q) *reinterpret_cast<v4u*>(smem + xdst_b[buf] + q * 4096) = r[q];
+  auto asm_load_w = [&](v4u& dst, auto hfc, const unsigned so) __attribute__((always_inline)) {
+    (void)woff, (void)wdesc;
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=v"(dst) : "v"(woff), "s"(wdesc), "s"(so), "n"(256 * decltype(hfc)::value));
   };
-  auto load_w = [&](const int step_rel, v4u (&dst)[2]) {
+  auto load_w = [&](const int step_rel, v4u (&dst)[2]) __attribute__((always_inline)) {
     const int s = step_rel < KS ? step_rel : KS - 1;
     const unsigned so = (unsigned)(4 * (2 * st0 + s)) * rowbytes;
-    dst[0] = wide_load16(wview, woff, so);
-    dst[1] = wide_load16(wview, woff + 256u, so);
+    asm_load_w(dst[0], std::integral_constant<int, 0>{}, so);
+    asm_load_w(dst[1], std::integral_constant<int, 1>{}, so);
   };
-  auto load_sc = [&](const int st_rel, h2 (&dst)[2]) {
+  auto load_sc = [&](const int st_rel, unsigned (&dst)[2]) __attribute__((always_inline)) {  // (raw words: an h2 copy behind the asm would read early)
     const int st = st_rel < NST ? st_rel : NST - 1;
     const unsigned so = (unsigned)(st0 + st) * (unsigned)N * 2u;
-    dst[0] = __builtin_bit_cast(h2, __builtin_amdgcn_raw_buffer_load_b32(sview, soff_l, so, 0));
-    dst[1] = __builtin_bit_cast(h2, __builtin_amdgcn_raw_buffer_load_b32(sview, soff_l + 64u, so, 0));
+    asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(dst[0]) : "v"(soff_l), "s"(sdesc), "s"(so));
+    asm volatile("buffer_load_dword %0, %1, %2, %3 offen offset:64" : "=v"(dst[1]) : "v"(soff_l), "s"(sdesc), "s"(so));
   };
 
   v4i acc[MT][4];  // [mt][2 * hf + b]
@@ -185,8 +238,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int q = 0; q < 4; ++q) acc[mt][q] = (v4i){0, 0, 0, 0};
 
   v4u wr[RS][2];
-  v4u xr[XL][XPT];
-  h2 scr[GROUPED ? P : 1][2];
+  unsigned scr[GROUPED ? P : 1][2];  // group scales (two fp16 each) of P stages, as loaded
   v4i x[MT];     // activation fragments of the current step; x[mt] is re-read for the next step right behind its last MFMA
   v4i aop[2][4]; // weight operands [set][2 * hf + b]: the current step's and the next step's
   const unsigned xrd = (unsigned)((lane & 15) * 128);  // + mt * 2048; chunk = (4 * t + h) ^ ((row >> 1) & 7), row = 16 * mt + j
@@ -281,17 +333,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // One 64-k step (stage i, half t of it; u = i % P and t compile-time).  Slot k of a step = MFMA (m-tile k / 4, column set k % 4) + its share of
   // everything else.  Step s unpacks step s + 1 into the other operand set (2 x (4 transpose pieces + UPARTS parts), evenly
   // over the 4 MT slots), re-reads fragment x[mt] for step s + 1 right behind its fourth MFMA, refills ring slot s % RS (read by
-  // the unpack that ran during step s - 1) with step s + RS, and moves one 16-byte chunk per thread of the activation stage
-  // every 16 slots: ds_write of stage i + LA, four slots later the reload of the same register for stage i + LA + 1.
+  // the unpack that ran during step s - 1) with step s + RS, and issues the LDS-DMA of one 16-byte chunk per lane of activation
+  // stage i + LA every 16 slots.  The waits are hand-counted from the static schedule (wide_loads_between).
   auto step = [&](const int i, auto uc, auto tc) __attribute__((always_inline)) {
     constexpr int t = decltype(tc)::value, u = decltype(uc)::value;
     constexpr int cur = t, nxt = 1 - t;         // 2 P steps per trip: the step's parity is its t
     constexpr int sl = (2 * u + t) % RS, sn = (sl + 1) % RS;
     const int step_abs = 2 * i + t;
     constexpr int su = GROUPED ? ((t == 1) ? (u + 1) % P : u) : 0;  // scales of the NEXT step's stage
-    const int st_x = i + LA + 1 < NST ? i + LA + 1 : NST - 1;
+    const int st_x = i + LA < NST ? i + LA : NST - 1;
     const unsigned xso = (unsigned)(st0 + st_x) * 128u;
-    constexpr int NSLOT = 4 * MT, NI = 2 * (4 + UPARTS);
+    constexpr int NI = 2 * (4 + UPARTS);
     auto slot = [&](auto kc) __attribute__((always_inline)) {
       constexpr int k = decltype(kc)::value, mt = k / 4, q = k % 4;
       mfma(acc[mt][q], aop[cur][q], x[mt]);
@@ -306,7 +358,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           constexpr int it = lo + decltype(jc)::value;
           constexpr int hf = it / (4 + UPARTS), w_ = it % (4 + UPARTS);
           if constexpr (w_ < 4) {
-            if constexpr (w_ == 0) un_setup(scr[su][hf]);
+            if constexpr (w_ == 0) {
+              // ring slot sn, half hf: loaded RS - 1 steps ago at slot 2 + 4 hf; everything older (the group scales of this
+              // stage among it) has landed once at most the loads issued since are outstanding
+              constexpr int younger = wide_loads_between(GROUPED, NSLOT, (t + RS - 1) & 1, 2 + 4 * hf, RS - 1, k);
+              static_assert(younger < 64, "vmcnt is a 6-bit counter");
+              if constexpr (GROUPED) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(wr[sn][hf]), "+v"(scr[su][hf]) : "n"(younger));
+              else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(wr[sn][hf]) : "n"(younger));
+              un_setup(__builtin_bit_cast(h2, scr[su][hf]));
+            }
             tr_piece(std::integral_constant<int, w_>{}, wr[sn][hf]);
           } else {
             un_part(std::integral_constant<int, w_ - 4>{}, std::integral_constant<int, hf>{}, aop[nxt]);
@@ -317,18 +377,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         aop[nxt][2] = aop[nxt][3] = (v4i){(int)wr[sn][1][0], (int)wr[sn][1][1], (int)wr[sn][1][2], (int)wr[sn][1][3]};
       }
       if constexpr (q == 3 && !(QQQ_WIDE_ABLATE & 16)) read_x(t == 0 ? (u % P) : ((u + 1) % P), t == 0 ? 1 : 0, mt);
-      if constexpr (!(QQQ_WIDE_ABLATE & 2)) {
-        constexpr int qi = (XPT / 2) * t + k / 16;  // this thread's chunk of the stage
-        if constexpr (k % 16 == 5) *reinterpret_cast<v4u*>(smem + xdst_b[(u + LA) % P] + qi * 4096) = xr[0][qi];
-        if constexpr (k % 16 == 9) xr[0][qi] = wide_load16(xview, xoff[qi], xso);
-      }
+      // (the order of the loads inside a slot is the order wide_loads_in_slot counts them in)
+      if constexpr (GROUPED && t == 1 && k == 1 && !(QQQ_WIDE_ABLATE & 8)) load_sc(i + P, scr[u]);
       if constexpr (!(QQQ_WIDE_ABLATE & 8)) {  // ring refill, one 16-byte load per slot
         const int sw = step_abs + RS < KS ? step_abs + RS : KS - 1;
         const unsigned swo = (unsigned)(4 * (2 * st0 + sw)) * rowbytes;
-        if constexpr (k == 2) wr[sl][0] = wide_load16(wview, woff, swo);
-        if constexpr (k == 6) wr[sl][1] = wide_load16(wview, woff + 256u, swo);
+        if constexpr (k == 2) asm_load_w(wr[sl][0], std::integral_constant<int, 0>{}, swo);
+        if constexpr (k == 6) asm_load_w(wr[sl][1], std::integral_constant<int, 1>{}, swo);
       }
-      if constexpr (GROUPED && t == 1 && k == 1) load_sc(i + P, scr[u]);
+      if constexpr (k % 16 == 8 && !(QQQ_WIDE_ABLATE & 2))  // chunk (XPT / 2) t + k / 16 of stage i + LA: M0, then the DMA
+        dma_m0(std::integral_constant<int, (u + LA) % P>{}, std::integral_constant<int, (XPT / 2) * t + k / 16>{});
+      if constexpr (k % 16 == 9 && !(QQQ_WIDE_ABLATE & 2)) dma_go(std::integral_constant<int, (XPT / 2) * t + k / 16>{}, xso);
       __builtin_amdgcn_sched_barrier(0);
     };
     qqq_static_for<NSLOT>(slot);
@@ -349,28 +408,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     if (bias) bv = *reinterpret_cast<const h8*>(bias + n);
   }
 
-  // ---- prologue: stages 0 and 1 go straight into LDS; the weight ring and the scales are issued before the wait for them ----
-  load_x(0, xr[0]);
-  __builtin_amdgcn_sched_barrier(0);
+  // ---- prologue: stages 0 .. LA - 1 by LDS-DMA, the weight ring, the scales; then EVERYTHING has landed (the loop's hand-counted
+  // waits presuppose that nothing older than its own loads is in flight) ----
+  qqq_static_for<LA>([&](auto jc) { dma_stage(jc, decltype(jc)::value); });
 #pragma unroll
   for (int j = 0; j < RS; ++j) load_w(j, wr[j]);
   if constexpr (GROUPED) {
 #pragma unroll
     for (int j = 0; j < P; ++j) load_sc(j, scr[j]);
   }
-  __builtin_amdgcn_sched_barrier(0);
-  store_x(0, xr[0]);
-  load_x(1, xr[0]);
-  __builtin_amdgcn_sched_barrier(0);
-  store_x(1 % P, xr[0]);
-#pragma unroll
-  for (int j = 0; j < XL; ++j) load_x(LA + j, xr[(LA + j) % XL]);
+  qqq_static_for<RS>([&](auto jc) {  // (the asm loads' results are tied to the wait: nothing may read them before it)
+    constexpr int j = decltype(jc)::value;
+    (void)wr[0];
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(wr[j][0]), "+v"(wr[j][1]));
+  });
+  if constexpr (GROUPED) {
+    qqq_static_for<P>([&](auto jc) {
+      (void)scr[0];
+      asm volatile("" : "+v"(scr[decltype(jc)::value][0]), "+v"(scr[decltype(jc)::value][1]));
+    });
+  }
   __syncthreads();
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) read_x(0, 0, mt);
   qqq_static_for<2>([&](auto hfc) {  // both halves of step 0 into operand set 0
     constexpr int hf = decltype(hfc)::value;
-    un_setup(scr[0][hf]);
+    un_setup(__builtin_bit_cast(h2, scr[0][hf]));
     qqq_static_for<4>([&](auto pc) { tr_piece(pc, wr[0][hf]); __builtin_amdgcn_sched_barrier(0); });
     qqq_static_for<UPARTS>([&](auto pc) { un_part(pc, hfc, aop[0]); });
   });
@@ -379,7 +442,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   auto do_stage = [&](const int i, auto uc) __attribute__((always_inline)) {  // one 128-k stage: two steps and the barrier that publishes stage i + LA
     step(i, uc, std::integral_constant<int, 0>{});
     step(i, uc, std::integral_constant<int, 1>{});
-    if constexpr (!(QQQ_WIDE_ABLATE & 1)) __syncthreads();  // stage i + LA is in LDS for everybody; buffer (i % P) is free
+    // the LDS-DMA of stage i + LA - 1, issued during stage i - 1: done when at most the loads issued since its last chunk
+    // (slot NSLOT - 7 of that stage's second step) are outstanding, i.e. this stage's
+    constexpr int since = wide_loads_between(GROUPED, NSLOT, 1, NSLOT - 7, 2, NSLOT);
+    static_assert(since < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(since) : "memory");
+    if constexpr (!(QQQ_WIDE_ABLATE & 1)) __syncthreads();  // stage i + LA - 1 is in LDS for everybody; buffer (i % P) is free
   };
   QQQ_TR(1);
   // ---- steady state: P stages per iteration (ring slots and LDS buffers are compile-time), branch-free ----
@@ -394,6 +462,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     if (i0 + decltype(uc)::value < NST) do_stage(i0 + decltype(uc)::value, uc);
   });
 
+  // the clamped LDS-DMAs of the last stages are still writing stage buffers: the epilogue image below lives in the same LDS.
+  // The ring / scale registers are USED behind the wait: the last steps' refills are never consumed, and hipcc would hand the
+  // destination of a dead asm load to the next value -- which the load then overwrites when it lands (seen: the transposed words of
+  // column half 0 in the ragged tail).
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  qqq_static_for<RS>([&](auto jc) {
+    (void)wr[0];
+    asm volatile("" : : "v"(wr[decltype(jc)::value][0]), "v"(wr[decltype(jc)::value][1]));
+  });
+  if constexpr (GROUPED) {
+    qqq_static_for<P>([&](auto jc) {
+      (void)scr[0];
+      asm volatile("" : : "v"(scr[decltype(jc)::value][0]), "v"(scr[decltype(jc)::value][1]));
+    });
+  }
   // ---- epilogue: EPR rows at a time: int32 -> LDS (row-major, skewed rows) -> 8 consecutive n per thread -> 16-byte stores ----
   // D lane ln of the MFMA holds token j = ln & 15, rows 4 * (ln >> 4) + r -> c' = ln >> 4, jt = r:
   //   column inside the strip  nl = 64 * wn + 16 * jt + 8 * b + 4 * hf + c'

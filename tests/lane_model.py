@@ -465,8 +465,9 @@ def wide_tile_order(tiles_m, tiles_n, ksplit, PW):
 def wide_kernel_model(A, B, s3, M, N, K, MT, ksplit, grouped, PW=8):
     """qqq_wide_kernel: a workgroup = 16*MT tokens x 256 columns x one K slice, four waves; wave wn owns the 64-column group
     tile_n*4 + wn (both halves) and all m-tiles.  Weights: buffer loads at lane offset h*rowbytes + cq*64 + q4*16 (+256 per
-    half) over the descriptor base B + ng*512, scalar offset 4*(2*st0 + s)*rowbytes, quad transpose; activations: chunk
-    (row (tid >> 3) + 32 q, piece tid & 7) of a stage to LDS at row*128 + ((pos ^ ((row >> 1) & 7)) << 4) (+ q*4096), scalar
+    half) over the descriptor base B + ng*512, scalar offset 4*(2*st0 + s)*rowbytes, quad transpose; activations by LDS-DMA: instruction
+    q of wave wn fills the lane-linear 1 KiB at q*4096 + wn*1024 of the stage image (lane l -> byte 16 l: row (tid >> 3) + 32 q,
+    slot tid & 7) and FETCHES piece slot ^ ((row >> 1) & 7) of that row (the swizzle is on the source side), scalar
     offset (st0 + st)*128 over the base A + mbase*K; fragments as in the panel kernel; epilogue / split-K slot image
     row-major [ROWS][256] with column 64*wn + 16*r + 8*b + 4*hf + c'.  Returns (acc [M,N], the list of slot images)."""
     assert K % 128 == 0
@@ -481,7 +482,7 @@ def wide_kernel_model(A, B, s3, M, N, K, MT, ksplit, grouped, PW=8):
     lane = np.arange(64)
     h, cq, q4 = lane >> 4, (lane >> 2) & 3, lane & 3
     tid = np.arange(256)
-    xr0, xpos = tid >> 3, tid & 7
+    xr0, xslot = tid >> 3, tid & 7
     out = np.zeros((M, N), np.int64)
     seen = set()
     partial = {}
@@ -498,9 +499,9 @@ def wide_kernel_model(A, B, s3, M, N, K, MT, ksplit, grouped, PW=8):
             img = np.zeros(ROWS * 128, np.uint8)
             for q in range(XPT):
                 row = np.minimum(xr0 + 32 * q, M - 1 - mbase)          # rows past M: the last row again
-                voff = row * K + xpos * 16                              # 32-bit lane offset over the base A + mbase*K
+                voff = row * K + (xslot ^ ((xr0 >> 1) & 7)) * 16        # 32-bit lane offset over the base A + mbase*K
                 src = mbase * K + voff + (st0 + st) * 128
-                dst = xr0 * 128 + ((xpos ^ ((xr0 >> 1) & 7)) << 4) + q * 4096
+                dst = q * 4096 + tid * 16                                # M0 = q*4096 + wn*1024 (+ buffer), + 16 * lane
                 for t_ in range(256):
                     img[dst[t_] : dst[t_] + 16] = Ab[src[t_] : src[t_] + 16]
             imgs.append(img)

@@ -112,7 +112,7 @@ def _check_plan(m, n, k, grouped, max_par):
     cap_rows, cap_tk = max_par * 64, (n // 128) * max_par
     if p["kernel"] == 5:  # wide: 256 x 256 tiles; 32-bit offsets into the packed weights; one slot of C per depositing slice
         assert m > 256 and n % 64 == 0 and k % 128 == 0 and n * k // 2 < 2**32
-        assert p["pf"] in (3, 6) and p["stages"] == 1 and p["pw"] in (4, 8, 16, 32) and p["mt"] in (8, 16)
+        assert p["pf"] in (4, 8) and p["stages"] == 1 and p["pw"] in (4, 8, 16, 32) and p["mt"] in (8, 16)
         rows = 16 * p["mt"]
         tiles = -(-m // rows) * -(-n // 256)
         if p["ksplit"] > 1:
@@ -212,9 +212,9 @@ def test_dispatch_of_the_baseline_sweep(L):
     for m in (1280, 1536, 2048, 4096, 8192):
         for gs in (-1, 128):
             p = _lib.plan(m, N, K, gs, 16)
-            assert (p["kernel"], p["ksplit"], p["pf"], p["stages"], p["pw"]) == (5, 1, 3, 1, 8), (m, gs, p)
-    assert _lib.plan(4096, N, K, -1, 16, tune=dict(kernel=5, pf=6))["pf"] == 6
-    assert _lib.plan(4096, N, K, -1, 16, tune=dict(kernel=5, stages=3))["stages"] == 1  # the uniform schedule has one staging set
+            assert (p["kernel"], p["ksplit"], p["pf"], p["stages"], p["pw"]) == (5, 1, 4 if gs < 0 else 8, 1, 8), (m, gs, p)
+    assert _lib.plan(4096, N, K, -1, 16, tune=dict(kernel=5, pf=8))["pf"] == 8 and _lib.plan(4096, N, K, 128, 16, tune=dict(kernel=5, pf=4))["pf"] == 4
+    assert _lib.plan(4096, N, K, -1, 16, tune=dict(kernel=5, stages=3))["stages"] == 1  # LDS-DMA staging: one lead, a full stage
     assert _lib.plan(1024, N, K, -1, 16, tune=dict(kernel=5, mt=8))["mt"] == 8 and _lib.plan(1024, N, K, -1, 16, tune=dict(kernel=5))["mt"] == 16
     # a forced 64-column shape is honoured only where it exists (128-token m-blocks, bm = 256, prefetch depth 3 or 4)
     assert _lib.plan(300, N, K, -1, 16, tune=dict(kernel=4, bm=256, mt=8, pw=2))["pw"] == 2

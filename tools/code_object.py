@@ -63,6 +63,39 @@ def kernels(lib):
     return out
 
 
+def disassemble(lib, symbol):
+    """Disassembly of kernel `symbol` (mangled) as compiler-style text: one instruction per line, `.LBB0_<n>:` labels at the
+    branch targets and the branches rewritten to name them (what tools/check_waits.py walks)."""
+    lib = os.path.abspath(lib)
+    with tempfile.TemporaryDirectory() as td:
+        link = os.path.join(td, "lib.so")
+        os.symlink(lib, link)
+        subprocess.run([f"{LLVM}/llvm-objdump", "--offloading", link], cwd=td, check=True, capture_output=True)
+        co = [f for f in os.listdir(td) if "gfx950" in f][0]
+        dis = subprocess.run([f"{LLVM}/llvm-objdump", "-d", f"--disassemble-symbols={symbol}", os.path.join(td, co)],
+                             check=True, capture_output=True, text=True).stdout
+    ins = []
+    for line in dis.split("\n"):
+        m = re.match(r"\s+(\S+)\s*(.*?)\s*//\s*([0-9A-Fa-f]+):(.*)", line)
+        if m:
+            ins.append((int(m.group(3), 16), m.group(1), m.group(2), m.group(4)))
+    if not ins:
+        raise RuntimeError(f"{symbol} not found in {lib}")
+    base = ins[0][0]
+    targets = {}
+    for addr, op, args, tail in ins:
+        m = re.search(r"\+0x([0-9a-fA-F]+)>", tail) if op.startswith(("s_cbranch", "s_branch")) else None
+        if m:
+            targets.setdefault(base + int(m.group(1), 16), len(targets))
+    out = []
+    for addr, op, args, tail in ins:
+        if addr in targets:
+            out.append(f".LBB0_{targets[addr]}:")
+        m = re.search(r"\+0x([0-9a-fA-F]+)>", tail) if op.startswith(("s_cbranch", "s_branch")) else None
+        out.append(f"\t{op} .LBB0_{targets[base + int(m.group(1), 16)]}" if m else f"\t{op} {args}")
+    return "\n".join(out)
+
+
 def hottest_loop(lib, symbol):
     """Instruction mix of the loop with the most MFMAs in kernel `symbol` (mangled name) of `lib`: {opcode: count} over the
     instructions between a backward branch and its target, plus "waits" = the s_waitcnt operands seen inside.  The loop is
