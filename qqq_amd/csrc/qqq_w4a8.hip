@@ -337,14 +337,14 @@ static hipError_t launch_tiled(const LaunchArgs& a, bool grouped, int bm, int st
                  : launch_tiled_bm<false>(a, bm, stages, ksplit, nslots, pw);
 }
 
-template <bool GROUPED, int MT, int P, int RS>
+template <bool GROUPED, int MT, int P, int RS, int HW>
 static hipError_t launch_wide_t(const LaunchArgs& a, int pw, int ksplit) {
-  constexpr int ROWS = 16 * MT;
-  constexpr int XBUF = P * ROWS * 128, EP = (MT == 16 ? 128 : 64) * (256 + 4) * 4 + 16;  // + the ticket exchange word
+  constexpr int ROWS = 16 * MT, BN = 128 * HW;
+  constexpr int XBUF = P * ROWS * 128, EP = (MT == 16 ? (HW == 2 ? 128 : 256) : 64) * (BN + 4) * 4 + 16;  // + the ticket exchange word
   constexpr int LDS = XBUF > EP ? XBUF : EP;
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static bool attr_set[64] = {};  // per instantiation, per device
-  auto kern = qqq_wide_kernel<GROUPED, MT, P, RS>;
+  auto kern = qqq_wide_kernel<GROUPED, MT, P, RS, HW>;
   int cur = 0;
   (void)hipGetDevice(&cur);
   if (cur < 0 || cur >= 64 || !attr_set[cur]) {
@@ -352,18 +352,23 @@ static hipError_t launch_wide_t(const LaunchArgs& a, int pw, int ksplit) {
     if (e != hipSuccess) return e;
     if (cur >= 0 && cur < 64) attr_set[cur] = true;
   }
-  const int tiles_m = (a.M + ROWS - 1) / ROWS, tiles_n = (a.N + 255) / 256;
+  const int tiles_m = (a.M + ROWS - 1) / ROWS, tiles_n = (a.N + BN - 1) / BN;
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n * ksplit), dim3(256), LDS, a.stream, a.A, a.B, a.C, a.D, a.s1, a.s2, a.s3,
                      a.acc_out, a.tickets, a.bias, a.M, a.N, a.K, tiles_m, tiles_n, pw, ksplit);
   return hipGetLastError();
 }
 
-// mt: 16 (256-token tiles) or 8 (128-token tiles); pf: weight ring in 64-k steps (4 or 8); four LDS stage buffers
+// mt: 16 (256-token tiles) or 8 (128-token tiles); pf: weight ring in 64-k steps (4 or 8); four LDS stage buffers;
+// bn: 256 columns per workgroup, or (mt = 16 only) 128: 32 columns per wave
 template <bool GROUPED, int MT>
 static hipError_t launch_wide_m(const LaunchArgs& a, int pf, int pw, int ksplit) {
-  return pf == 4 ? launch_wide_t<GROUPED, MT, 4, 4>(a, pw, ksplit) : launch_wide_t<GROUPED, MT, 4, 8>(a, pw, ksplit);
+  return pf == 4 ? launch_wide_t<GROUPED, MT, 4, 4, 2>(a, pw, ksplit) : launch_wide_t<GROUPED, MT, 4, 8, 2>(a, pw, ksplit);
 }
-static hipError_t launch_wide(const LaunchArgs& a, bool grouped, int mt, int pf, int pw, int ksplit) {
+static hipError_t launch_wide(const LaunchArgs& a, bool grouped, int mt, int bn, int pf, int pw, int ksplit) {
+  if (bn == 128) {
+    if (grouped) return pf == 4 ? launch_wide_t<true, 16, 4, 4, 1>(a, pw, ksplit) : launch_wide_t<true, 16, 4, 8, 1>(a, pw, ksplit);
+    return pf == 4 ? launch_wide_t<false, 16, 4, 4, 1>(a, pw, ksplit) : launch_wide_t<false, 16, 4, 8, 1>(a, pw, ksplit);
+  }
   if (mt == 8) return grouped ? launch_wide_m<true, 8>(a, pf, pw, ksplit) : launch_wide_m<false, 8>(a, pf, pw, ksplit);
   return grouped ? launch_wide_m<true, 16>(a, pf, pw, ksplit) : launch_wide_m<false, 16>(a, pf, pw, ksplit);
 }
@@ -485,40 +490,46 @@ static double panel_estimate(int M, int N, int K, bool grouped, bool have_scratc
   return best;
 }
 
-// wide: 256 x 256 tiles, one per CU and round, no split-K: ~12 us per tile round of fixed cost (first operands from HBM with
-// every CU in its prologue at once ~4 us, epilogue ~7 us) + 1.34 us per 128-k stage (per-group 1.76: the re-quantiser of a
-// lone wave is issue-bound); profiles/r03_wide_uniform_schedule.txt, r03_wide_timeline.txt
+// wide: three tile shapes, one tile per CU and round.  Fitted on one box after the LDS-DMA staging
+// (profiles/r03_dispatch_check_wide3.txt): time = 3.7 + rounds * (fixed + hand-off + stages * t_stage * load), with
+//   256 x 256 (mt 16, bn 256): fixed 12 us (first operands from HBM with every CU in its prologue at once ~4, epilogue ~7),
+//                              1.25 us per 128-k stage (per-group 1.635: the re-quantiser of a lone wave is issue-bound);
+//   256 x 128 (mt 16, bn 128): fixed 7, 0.72 (0.96) per stage: a weight operand still feeds 256 tokens, twice the LDS traffic
+//                              per MFMA -- the shape that fills the chip from ~600 tokens, and per-group on 4096-wide layers;
+//   128 x 256 (mt 8,  bn 256): fixed 7, 0.71 (1.17): twice the unpack / re-quantise work per MFMA.
+// Two K slices (256-token tiles): hand-off 20 us per 256 KiB of partial tile (written through, folded by the last arrival).
 static double wide_estimate(int M, int N, int K, bool grouped, bool have_scratch, long long cap_rows, long long cap_tickets, int* ks_out,
-                            int* mt_out) {
+                            int* mt_out, int* bn_out) {
   *ks_out = 1;
   *mt_out = 16;
+  *bn_out = 256;
   if ((long long)N * K / 2 >= (1ll << 32) || (K % 128) != 0) return 1e30;  // 32-bit offsets into the packed weights; whole stages
-  const long long strips = (N + 255) / 256;
   const int NST = K / 128;
   double best = 1e30;
-  for (int mt = 16; mt >= 8; mt -= 8) {
-    // 128-token tiles (mt = 8): half the accumulators, twice the unpack work per MFMA -- 0.775 us per stage (per-group 1.24),
-    // ~8 us fixed; on a par with the panel kernel's 64-column shape, a few % ahead per-channel (profiles/r03_wide_splitk.txt)
+  for (int shape = 0; shape < 3; ++shape) {
+    const int mt = shape == 2 ? 8 : 16, bn = shape == 1 ? 128 : 256;
     const int rows = 16 * mt;
-    const long long tl = (long long)((M + rows - 1) / rows) * strips;
-    const double t_stage = (mt == 16) ? (grouped ? 1.76 : 1.34) : (grouped ? 1.24 : 0.775);
-    const double fixed = (mt == 16) ? 12.0 : 8.0;
+    const long long tl = (long long)((M + rows - 1) / rows) * ((N + bn - 1) / bn);
+    const double t_stage = shape == 0 ? (grouped ? 1.635 : 1.25) : shape == 1 ? (grouped ? 0.96 : 0.72) : (grouped ? 1.17 : 0.71);
+    const double fixed = shape == 0 ? 12.0 : 7.0;
     for (int ks = 1; ks <= (mt == 16 ? 2 : 1); ++ks) {
-      // one slot of rows x 256 ints per tile and depositing slice inside C, two ticket words per tile; hand-off (256 KiB deposit
-      // written through + its fold by the last arrival)
-      if (ks > 1 && (!have_scratch || 2 * tl > cap_tickets || tl * rows * 256 * (ks - 1) > cap_rows * (long long)N || ks > NST / 4)) break;
+      // one slot of rows x bn ints per tile and depositing slice inside C, two ticket words per tile
+      if (ks > 1 && (!have_scratch || 2 * tl > cap_tickets || tl * rows * bn * (ks - 1) > cap_rows * (long long)N || ks > NST / 4)) break;
       // rounds: workgroups of later rounds start as CUs free up, but the XCDs' queues drain unevenly -- close to the ceiling of
-      // the ratio (288-344 tiles measured 1.7-1.8 rounds, 688 tiles 2.8-3; profiles/r03_dispatch_check_wide2.txt).  A partly
-      // filled single round runs each tile faster: the part is power-limited (160 of 256 CUs busy: 1.10 us per stage, not 1.34)
+      // the ratio (288-344 tiles measured 1.7-1.8 rounds, 688 tiles 2.8-3).  A partly filled single round runs each tile
+      // faster: the part is power-limited (half the CUs busy: 0.8 of the full-chip stage time, 0.85 per-group; then quadratic)
       const double x = (double)(tl * ks) / 256.0;
       const double cx = (double)((tl * ks + 255) / 256);
       const double rounds = x <= 1.0 ? 1.0 : cx - 0.3 * (cx - x);
-      const double load = x <= 1.0 ? 0.6 + 0.4 * x : 1.0;
-      const double us = 3.7 + rounds * (fixed + (ks > 1 ? 20.0 : 0.0) + ((double)NST / ks) * t_stage * load);
+      const double lo = grouped ? 0.85 : 0.80, rel = x <= 0.5 ? 0.0 : (x - 0.5) / 0.5;
+      const double load = x <= 1.0 ? lo + (1.0 - lo) * rel * rel : 1.0;
+      const double handoff = ks > 1 ? 20.0 * (double)(rows * bn) / 65536.0 : 0.0;
+      const double us = 3.7 + rounds * (fixed + handoff + ((double)NST / ks) * t_stage * load);
       if (us < best) {
         best = us;
         *ks_out = ks;
         *mt_out = mt;
+        *bn_out = bn;
       }
     }
   }
@@ -565,12 +576,15 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
       const double e_panel = ((long long)(M + 127) / 128 <= 65535) ? panel_estimate(M, N, K, grouped, have_scratch && have_ws, cap_rows, cap_tk, &pbn, &pks, &pcw) : 1e30;
       const double e_stream = (M <= 256) ? stream_estimate(M, N, K, grouped) : 1e30;
       const double e_tiled = ((K % 128) == 0 && M > 64) ? tiled_estimate(M, N, K, grouped, have_scratch, cap_rows, cap_tk, false, &tbm, &tks) : 1e30;
-      int wks = 1, wmt = 16;
-      const double e_wide = (M > 256) ? wide_estimate(M, N, K, grouped, have_scratch && have_ws, cap_rows, cap_tk, &wks, &wmt) : 1e30;
+      int wks = 1, wmt = 16, wbn = 256;
+      const double e_wide = (M > 256) ? wide_estimate(M, N, K, grouped, have_scratch && have_ws, cap_rows, cap_tk, &wks, &wmt, &wbn) : 1e30;
       if (e_wide < e_panel && e_wide < e_stream && e_wide < e_tiled) {
         kernel = 5;
         if (t.ksplit <= 0) t.ksplit = wks;
-        if (t.mt == 0) t.mt = wmt;
+        if (t.mt == 0 && t.bm == 0) {
+          t.mt = wmt;
+          t.bm = wbn;
+        }
       } else if (e_panel <= e_stream && e_panel <= e_tiled) {
         kernel = 4;
         if (t.bm == 0 && t.pw == 0 && t.mt == 0 && pcw == 2) t.pw = 2;
@@ -592,17 +606,18 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
     // wide: 256 (mt = 8: 128) tokens x 256 columns per workgroup, 4 waves with 512 registers each; in-launch split-K with
     // one slot of C per depositing slice (row-major partial tiles) and two ticket words per tile
     pl.mt = (t.mt == 8) ? 8 : 16;                         // 16-token m-tiles per workgroup: 256- or 128-token tiles
+    pl.bm = (t.bm == 128 && pl.mt == 16) ? 128 : 256;     // columns per workgroup: 64 or (256-token tiles only) 32 per wave
     pl.stages = 1;                                        // activation lead: the LDS-DMA of a stage is issued a full stage ahead
     pl.pf = (t.pf == 8 || t.pf == 4) ? t.pf : (grouped ? 8 : 4);  // weight ring in 64-k steps (per-group: 8 measured 1.5 % ahead)
     pl.pw = (t.pw == 4 || t.pw == 8 || t.pw == 16 || t.pw == 32) ? t.pw : 8;
     const int rows = 16 * pl.mt;
-    const long long tl = (long long)((M + rows - 1) / rows) * ((N + 255) / 256);
+    const long long tl = (long long)((M + rows - 1) / rows) * ((N + pl.bm - 1) / pl.bm);
     ksplit = t.ksplit > 0 ? t.ksplit : 1;
     ksplit = clampi(ksplit, 1, (K / 128) / 4 > 0 ? (K / 128) / 4 : 1);
     if (!have_scratch || workspace == nullptr) ksplit = 1;
     const long long cap_tk = (long long)(N / 128) * (max_par > 0 ? max_par : 0);
     if (2 * tl > cap_tk) ksplit = 1;
-    while (ksplit > 1 && tl * rows * 256 * (ksplit - 1) > cap_rows * (long long)N) --ksplit;
+    while (ksplit > 1 && tl * rows * pl.bm * (ksplit - 1) > cap_rows * (long long)N) --ksplit;
     pl.ksplit = ksplit;
     pl.fused = 1;
     return pl;
@@ -827,7 +842,7 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
     return QQQ_ERR_ARG;
   }
   if (pl.kernel == 5) {
-    e = launch_wide(a, grouped, pl.mt, pl.pf, pl.pw, pl.ksplit);
+    e = launch_wide(a, grouped, pl.mt, pl.bm, pl.pf, pl.pw, pl.ksplit);
     if (e != hipSuccess) return fail_hip(e, "qqq_wide_kernel launch");
     reduce_launch = false;
   } else if (pl.kernel == 4) {

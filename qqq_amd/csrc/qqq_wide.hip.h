@@ -64,12 +64,23 @@ __device__ __forceinline__ v4u wide_load16(__amdgpu_buffer_rsrc_t view, const un
 #ifndef QQQ_WIDE_SLOTMAP
 #define QQQ_WIDE_SLOTMAP 5  // bit 0: per-channel, bit 1: per-group, bit 2: the 128-token shape too
 #endif
-__host__ __device__ constexpr bool wide_item_slot(int k) {  // slots of a 64-slot step that take an unpack item
+// The static roles of the NSLOT = 2 * HW * MT issue slots of a 64-k step (slot k: m-tile k / (2 HW), column set k % (2 HW)).
+// HW = 2 (64 columns per wave): fragment re-read behind every fourth MFMA, ring refill in slots 2 and 6, the LDS-DMA's M0 in
+// slot 8 and the DMA itself in slot 9 of every 16, group scales in slot 1 of a stage's second step; unpack items in the rest.
+// HW = 1 (32 columns per wave, 256 x 128 tiles): every ODD slot re-reads a fragment, so everything else sits in even ones.
+__host__ __device__ constexpr bool wide_frag_slot(int hw, int k) { return k % (2 * hw) == 2 * hw - 1; }
+__host__ __device__ constexpr bool wide_refill_slot(int hw, int k, int hf) { return hf < hw && k == 2 + 4 * hf; }
+__host__ __device__ constexpr int wide_dma_period(int mt, int hw) { return (2 * hw * mt) / (mt / 4); }  // slots per DMA chunk: 16 / 8
+__host__ __device__ constexpr bool wide_m0_slot(int mt, int hw, int k) { return k % wide_dma_period(mt, hw) == (hw == 2 ? 8 : 4); }
+__host__ __device__ constexpr bool wide_dma_slot(int mt, int hw, int k) { return k % wide_dma_period(mt, hw) == (hw == 2 ? 9 : 6); }
+__host__ __device__ constexpr int wide_scale_slot(int hw) { return hw == 2 ? 1 : 0; }
+__host__ __device__ constexpr bool wide_item_slot(int hw, int k) {  // slots of a step that take an unpack item
+  if (hw == 1) return k % 2 == 0 && k != 2 && k % 8 != 6;
   return (k % 4 == 0) || (k % 4 == 2 && k != 2 && k != 6) || (k % 8 == 5);
 }
-__host__ __device__ constexpr int wide_item_slots_before(int k) {  // number of item slots in [0, k)
+__host__ __device__ constexpr int wide_item_slots_before(int hw, int k) {  // number of item slots in [0, k)
   int n = 0;
-  for (int j = 0; j < k; ++j) n += wide_item_slot(j) ? 1 : 0;
+  for (int j = 0; j < k; ++j) n += wide_item_slot(hw, j) ? 1 : 0;
   return n;
 }
 
@@ -84,34 +95,41 @@ __host__ __device__ constexpr int wide_item_slots_before(int k) {  // number of 
 #define QQQ_WIDE_DMA 1
 #endif
 // Vector-memory loads slot k of a step (parity t = second step of its stage) issues, in the order the slot issues them.
-__host__ __device__ constexpr int wide_loads_in_slot(bool grouped, int t, int k) {
+__host__ __device__ constexpr int wide_loads_in_slot(bool grouped, int mt, int hw, int t, int k) {
   int n = 0;
-  if (grouped && t == 1 && k == 1 && !(QQQ_WIDE_ABLATE & 8)) n += 2;  // the group scales of stage i + P
-  if ((k == 2 || k == 6) && !(QQQ_WIDE_ABLATE & 8)) n += 1;            // weight-ring refill, one half each
-  if (k % 16 == 9 && !(QQQ_WIDE_ABLATE & 2)) n += 1;                   // one activation chunk per lane every 16 slots
+  if (grouped && t == 1 && k == wide_scale_slot(hw) && !(QQQ_WIDE_ABLATE & 8)) n += 2;            // the group scales of stage i + P
+  if ((wide_refill_slot(hw, k, 0) || wide_refill_slot(hw, k, 1)) && !(QQQ_WIDE_ABLATE & 8)) n += 1;  // weight-ring refill
+  if (wide_dma_slot(mt, hw, k) && !(QQQ_WIDE_ABLATE & 2)) n += 1;                                  // one activation chunk per lane
   return n;
 }
-__host__ __device__ constexpr int wide_loads_in_step(bool grouped, int nslot, int t, int from, int to) {  // slots [from, to)
+__host__ __device__ constexpr int wide_loads_in_step(bool grouped, int mt, int hw, int t, int from, int to) {  // slots [from, to)
   int n = 0;
-  for (int k = from; k < to && k < nslot; ++k) n += wide_loads_in_slot(grouped, t, k);
+  for (int k = from; k < to && k < 2 * hw * mt; ++k) n += wide_loads_in_slot(grouped, mt, hw, t, k);
   return n;
 }
 // Loads issued after slot k0 of a step with parity t0 and before slot k1 of the step `steps` later (>= 1).
-__host__ __device__ constexpr int wide_loads_between(bool grouped, int nslot, int t0, int k0, int steps, int k1) {
-  int n = wide_loads_in_step(grouped, nslot, t0, k0 + 1, nslot);
-  for (int j = 1; j < steps; ++j) n += wide_loads_in_step(grouped, nslot, (t0 + j) & 1, 0, nslot);
-  return n + wide_loads_in_step(grouped, nslot, (t0 + steps) & 1, 0, k1);
+__host__ __device__ constexpr int wide_loads_between(bool grouped, int mt, int hw, int t0, int k0, int steps, int k1) {
+  int n = wide_loads_in_step(grouped, mt, hw, t0, k0 + 1, 2 * hw * mt);
+  for (int j = 1; j < steps; ++j) n += wide_loads_in_step(grouped, mt, hw, (t0 + j) & 1, 0, 2 * hw * mt);
+  return n + wide_loads_in_step(grouped, mt, hw, (t0 + steps) & 1, 0, k1);
+}
+__host__ __device__ constexpr int wide_last_dma_slot(int mt, int hw) {
+  int last = 0;
+  for (int k = 0; k < 2 * hw * mt; ++k) last = wide_dma_slot(mt, hw, k) ? k : last;
+  return last;
 }
 
-template <bool GROUPED, int MT, int P, int RS>
+template <bool GROUPED, int MT, int P, int RS, int HW>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void qqq_wide_kernel(
     const int8_t* __restrict__ A, const unsigned char* __restrict__ B, int32_t* __restrict__ C, _Float16* __restrict__ D,
     const float* __restrict__ s1, const float* __restrict__ s2, const _Float16* __restrict__ s3,
     int32_t* __restrict__ acc_out, int* __restrict__ tickets, const _Float16* __restrict__ bias, const int M, const int N,
     const int K, const int tiles_m, const int tiles_n, const int PW, const int ksplit) {
   static_assert(MT == 16 || MT == 8, "m-tiles of 16 tokens per wave (= per workgroup): 256 or 128 tokens");
+  static_assert(HW == 2 || (HW == 1 && MT == 16), "a wave owns both 32-column halves of a 64-column group, or (256 x 128 tiles) one");
   constexpr int ROWS = 16 * MT;
-  constexpr int BN = 256;                // 4 waves x 64 columns
+  constexpr int NQ = 2 * HW;             // column sets (of 16) per wave
+  constexpr int BN = 128 * HW;           // 4 waves x 32 HW columns
   constexpr int NT = 256;
   constexpr int XB = ROWS * 128;         // bytes of one activation stage (128 k)
   constexpr int XPT = XB / 16 / NT;      // 16-byte chunks per thread and stage (8 / 4)
@@ -121,8 +139,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // the fragment reads of stage i + LA begin in the last step of stage i + LA - 1 = i + 2.
   static_assert(P == 4, "four LDS stage buffers: one being read, one complete, two in flight");
   constexpr int LA = P - 1;
-  constexpr int NSLOT = 4 * MT;          // issue slots (= MFMAs) of a 64-k step
-  constexpr int EPR = (MT == 16) ? 128 : 64;  // rows per epilogue pass (int32 image: EPR x 260 x 4 B = 130 / 65 KiB of LDS)
+  constexpr int NSLOT = NQ * MT;         // issue slots (= MFMAs) of a 64-k step
+  constexpr int EPR = (MT == 16) ? (HW == 2 ? 128 : 256) : 64;  // rows per epilogue pass (int32 image: EPR x (BN + 4) x 4 B = 130 / 132 / 65 KiB)
   constexpr int EP_STRIDE = BN + 4;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -157,8 +175,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
   const int mbase = tile_m * ROWS;
   const int ngroups = N >> 6;
-  int ng = tile_n * 4 + wn;
-  if (ng >= ngroups) ng = ngroups - 1;   // N % 256 != 0: surplus waves of the last strip compute on clamped columns, store nothing
+  const int cb = tile_n * 4 + wn;        // this wave's block of 32 HW columns: a 64-column group, or (HW = 1) half cb & 1 of group cb >> 1
+  int ng = HW == 2 ? cb : cb >> 1;
+  const int whalf = HW == 2 ? 0 : (cb & 1);
+  if (ng >= ngroups) ng = ngroups - 1;   // N % BN != 0: surplus waves of the last strip compute on clamped columns, store nothing
   const unsigned rowbytes = (unsigned)N * 8u;
 
   // K slice [st0, st0 + NST) in 128-k stages (K % 128 == 0); steps and stages below are relative to it
@@ -175,9 +195,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     return (v4u){(unsigned)a, (unsigned)(a >> 32), 0xffffffffu, 0x00020000u};
   };
   const v4u wdesc = descriptor(B + (size_t)ng * 512);
-  const unsigned woff = (unsigned)h * rowbytes + (unsigned)(cq * 64 + q4 * 16);   // + step * 4 * rowbytes (scalar) + 256 * hf
+  const unsigned woff = (unsigned)h * rowbytes + (unsigned)(cq * 64 + q4 * 16 + 256 * whalf);   // + step * 4 * rowbytes (scalar) + 256 * hf
   const v4u sdesc = descriptor(GROUPED ? (const void*)(s3 + (size_t)ng * 64) : (const void*)B);
-  const unsigned soff_l = (unsigned)((cq * 8 + 2 * q4) * 2);                      // + stage * N * 2 (scalar) + 64 * hf
+  const unsigned soff_l = (unsigned)((cq * 8 + 2 * q4) * 2 + 64 * whalf);         // + stage * N * 2 (scalar) + 64 * hf
   // Activation staging by LDS-DMA: instruction q of wave wn fills the 1 KiB [rows 8 wn + 32 q .. + 8) x 128 bytes of the stage
   // image, lane l -> byte 16 l of it = (row l >> 3, slot l & 7).  The image keeps the XOR swizzle of the fragment reads
   // (16-byte piece p of a row sits in slot p ^ ((row >> 1) & 7)), so the lane FETCHES piece slot ^ ((row >> 1) & 7).
@@ -218,29 +238,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     (void)woff, (void)wdesc;
     asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=v"(dst) : "v"(woff), "s"(wdesc), "s"(so), "n"(256 * decltype(hfc)::value));
   };
-  auto load_w = [&](const int step_rel, v4u (&dst)[2]) __attribute__((always_inline)) {
+  auto load_w = [&](const int step_rel, v4u (&dst)[HW]) __attribute__((always_inline)) {
     const int s = step_rel < KS ? step_rel : KS - 1;
     const unsigned so = (unsigned)(4 * (2 * st0 + s)) * rowbytes;
-    asm_load_w(dst[0], std::integral_constant<int, 0>{}, so);
-    asm_load_w(dst[1], std::integral_constant<int, 1>{}, so);
+    qqq_static_for<HW>([&](auto hfc) { asm_load_w(dst[decltype(hfc)::value], hfc, so); });
   };
+  // (the scales of a stage are always fetched as two words -- HW = 1 needs only the first -- so that the load counts of the
+  // static schedule do not depend on HW)
   auto load_sc = [&](const int st_rel, unsigned (&dst)[2]) __attribute__((always_inline)) {  // (raw words: an h2 copy behind the asm would read early)
     const int st = st_rel < NST ? st_rel : NST - 1;
     const unsigned so = (unsigned)(st0 + st) * (unsigned)N * 2u;
     asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(dst[0]) : "v"(soff_l), "s"(sdesc), "s"(so));
-    asm volatile("buffer_load_dword %0, %1, %2, %3 offen offset:64" : "=v"(dst[1]) : "v"(soff_l), "s"(sdesc), "s"(so));
+    asm volatile("buffer_load_dword %0, %1, %2, %3 offen offset:%4" : "=v"(dst[1]) : "v"(soff_l), "s"(sdesc), "s"(so), "n"(HW == 2 ? 64 : 0));
   };
 
-  v4i acc[MT][4];  // [mt][2 * hf + b]
+  v4i acc[MT][NQ];  // [mt][2 * hf + b]
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) acc[mt][q] = (v4i){0, 0, 0, 0};
+    for (int q = 0; q < NQ; ++q) acc[mt][q] = (v4i){0, 0, 0, 0};
 
-  v4u wr[RS][2];
+  v4u wr[RS][HW];
   unsigned scr[GROUPED ? P : 1][2];  // group scales (two fp16 each) of P stages, as loaded
   v4i x[MT];     // activation fragments of the current step; x[mt] is re-read for the next step right behind its last MFMA
-  v4i aop[2][4]; // weight operands [set][2 * hf + b]: the current step's and the next step's
+  v4i aop[2][NQ]; // weight operands [set][2 * hf + b]: the current step's and the next step's
   const unsigned xrd = (unsigned)((lane & 15) * 128);  // + mt * 2048; chunk = (4 * t + h) ^ ((row >> 1) & 7), row = 16 * mt + j
   const int xsw = ((lane & 15) >> 1) & 7;
   const unsigned xrd_t[2] = {xrd + (unsigned)(((0 + h) ^ xsw) << 4), xrd + (unsigned)(((4 + h) ^ xsw) << 4)};
@@ -292,7 +313,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       sb[1] = (h2){sc[1], sc[1]};
     }
   };
-  auto un_part = [&](auto pc, auto hfc, v4i (&a)[4]) {
+  auto un_part = [&](auto pc, auto hfc, v4i (&a)[NQ]) {
     constexpr int pi = decltype(pc)::value, hf = decltype(hfc)::value;
     if constexpr (GROUPED) {
       // the two re-quantisations of a packed word (b = 0, 1) run in lock step: part p of b = 0, then part p of b = 1 -- a
@@ -343,15 +364,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr int su = GROUPED ? ((t == 1) ? (u + 1) % P : u) : 0;  // scales of the NEXT step's stage
     const int st_x = i + LA < NST ? i + LA : NST - 1;
     const unsigned xso = (unsigned)(st0 + st_x) * 128u;
-    constexpr int NI = 2 * (4 + UPARTS);
+    constexpr int NI = HW * (4 + UPARTS);
     auto slot = [&](auto kc) __attribute__((always_inline)) {
-      constexpr int k = decltype(kc)::value, mt = k / 4, q = k % 4;
+      constexpr int k = decltype(kc)::value, mt = k / NQ, q = k % NQ;
       mfma(acc[mt][q], aop[cur][q], x[mt]);
       if constexpr (!(QQQ_WIDE_ABLATE & 4)) {
         // MT == 16: the NI items go to the NE = 34 memory-free slots of the step (per-channel one each, per-group 2-3 each)
-        constexpr bool MAPPED = (QQQ_WIDE_SLOTMAP & (GROUPED ? 2 : 1)) != 0 && (MT == 16 || (QQQ_WIDE_SLOTMAP & 4) != 0);
-        constexpr int NE = wide_item_slots_before(NSLOT), e = wide_item_slots_before(k);
-        constexpr bool here = wide_item_slot(k);
+        constexpr bool MAPPED = HW == 1 || ((QQQ_WIDE_SLOTMAP & (GROUPED ? 2 : 1)) != 0 && (MT == 16 || (QQQ_WIDE_SLOTMAP & 4) != 0));
+        constexpr int NE = wide_item_slots_before(HW, NSLOT), e = wide_item_slots_before(HW, k);
+        constexpr bool here = wide_item_slot(HW, k);
         constexpr int lo = MAPPED ? (here ? (e * NI) / NE : 0) : (k * NI) / NSLOT;
         constexpr int hi = MAPPED ? (here ? ((e + 1) * NI) / NE : 0) : ((k + 1) * NI) / NSLOT;
         qqq_static_for<(hi - lo)>([&](auto jc) {
@@ -361,7 +382,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if constexpr (w_ == 0) {
               // ring slot sn, half hf: loaded RS - 1 steps ago at slot 2 + 4 hf; everything older (the group scales of this
               // stage among it) has landed once at most the loads issued since are outstanding
-              constexpr int younger = wide_loads_between(GROUPED, NSLOT, (t + RS - 1) & 1, 2 + 4 * hf, RS - 1, k);
+              constexpr int younger = wide_loads_between(GROUPED, MT, HW, (t + RS - 1) & 1, 2 + 4 * hf, RS - 1, k);
               static_assert(younger < 64, "vmcnt is a 6-bit counter");
               if constexpr (GROUPED) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(wr[sn][hf]), "+v"(scr[su][hf]) : "n"(younger));
               else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(wr[sn][hf]) : "n"(younger));
@@ -373,28 +394,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           }
         });
       } else if constexpr (k == 0) {
-        aop[nxt][0] = aop[nxt][1] = (v4i){(int)wr[sn][0][0], (int)wr[sn][0][1], (int)wr[sn][0][2], (int)wr[sn][0][3]};
-        aop[nxt][2] = aop[nxt][3] = (v4i){(int)wr[sn][1][0], (int)wr[sn][1][1], (int)wr[sn][1][2], (int)wr[sn][1][3]};
+        qqq_static_for<NQ>([&](auto qc) {
+          constexpr int qq = decltype(qc)::value;
+          aop[nxt][qq] = (v4i){(int)wr[sn][qq / 2][0], (int)wr[sn][qq / 2][1], (int)wr[sn][qq / 2][2], (int)wr[sn][qq / 2][3]};
+        });
       }
-      if constexpr (q == 3 && !(QQQ_WIDE_ABLATE & 16)) read_x(t == 0 ? (u % P) : ((u + 1) % P), t == 0 ? 1 : 0, mt);
+      if constexpr (wide_frag_slot(HW, k) && !(QQQ_WIDE_ABLATE & 16)) read_x(t == 0 ? (u % P) : ((u + 1) % P), t == 0 ? 1 : 0, mt);
       // (the order of the loads inside a slot is the order wide_loads_in_slot counts them in)
-      if constexpr (GROUPED && t == 1 && k == 1 && !(QQQ_WIDE_ABLATE & 8)) load_sc(i + P, scr[u]);
+      if constexpr (GROUPED && t == 1 && k == wide_scale_slot(HW) && !(QQQ_WIDE_ABLATE & 8)) load_sc(i + P, scr[u]);
       if constexpr (!(QQQ_WIDE_ABLATE & 8)) {  // ring refill, one 16-byte load per slot
         const int sw = step_abs + RS < KS ? step_abs + RS : KS - 1;
         const unsigned swo = (unsigned)(4 * (2 * st0 + sw)) * rowbytes;
-        if constexpr (k == 2) asm_load_w(wr[sl][0], std::integral_constant<int, 0>{}, swo);
-        if constexpr (k == 6) asm_load_w(wr[sl][1], std::integral_constant<int, 1>{}, swo);
+        if constexpr (wide_refill_slot(HW, k, 0)) asm_load_w(wr[sl][0], std::integral_constant<int, 0>{}, swo);
+        if constexpr (wide_refill_slot(HW, k, 1)) asm_load_w(wr[sl][HW - 1], std::integral_constant<int, 1>{}, swo);
       }
-      if constexpr (k % 16 == 8 && !(QQQ_WIDE_ABLATE & 2))  // chunk (XPT / 2) t + k / 16 of stage i + LA: M0, then the DMA
-        dma_m0(std::integral_constant<int, (u + LA) % P>{}, std::integral_constant<int, (XPT / 2) * t + k / 16>{});
-      if constexpr (k % 16 == 9 && !(QQQ_WIDE_ABLATE & 2)) dma_go(std::integral_constant<int, (XPT / 2) * t + k / 16>{}, xso);
+      constexpr int DP = wide_dma_period(MT, HW);  // chunk (XPT / 2) t + k / DP of stage i + LA: M0, then the DMA
+      if constexpr (wide_m0_slot(MT, HW, k) && !(QQQ_WIDE_ABLATE & 2))
+        dma_m0(std::integral_constant<int, (u + LA) % P>{}, std::integral_constant<int, (XPT / 2) * t + k / DP>{});
+      if constexpr (wide_dma_slot(MT, HW, k) && !(QQQ_WIDE_ABLATE & 2)) dma_go(std::integral_constant<int, (XPT / 2) * t + k / DP>{}, xso);
       __builtin_amdgcn_sched_barrier(0);
     };
     qqq_static_for<NSLOT>(slot);
   };
 
   // ---- epilogue operands that do not depend on the accumulators: fetched here, 12 registers carried through the loop ----
-  const int c8 = tid % (BN / 8), er0 = tid / (BN / 8);  // epilogue: this thread's 8 columns; rows er0 + 8 * ps of a pass
+  constexpr int RST = NT / (BN / 8);     // epilogue: rows a pass-step of the workgroup covers (8 / 16)
+  const int c8 = tid % (BN / 8), er0 = tid / (BN / 8);  // this thread's 8 columns; rows er0 + RST * ps of a pass
   const int n = tile_n * BN + c8 * 8;
   float2 s2v[4] = {};
   const _Float16 nz = (_Float16)-0.0f;
@@ -420,7 +445,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   qqq_static_for<RS>([&](auto jc) {  // (the asm loads' results are tied to the wait: nothing may read them before it)
     constexpr int j = decltype(jc)::value;
     (void)wr[0];
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(wr[j][0]), "+v"(wr[j][1]));
+    // (HW = 1: ONE operand -- the same variable tied twice gets two registers and a copy in front of the wait)
+    if constexpr (HW == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(wr[j][0]), "+v"(wr[j][HW - 1]));
+    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(wr[j][0]));
   });
   if constexpr (GROUPED) {
     qqq_static_for<P>([&](auto jc) {
@@ -431,7 +458,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   __syncthreads();
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) read_x(0, 0, mt);
-  qqq_static_for<2>([&](auto hfc) {  // both halves of step 0 into operand set 0
+  qqq_static_for<HW>([&](auto hfc) {  // both halves of step 0 into operand set 0
     constexpr int hf = decltype(hfc)::value;
     un_setup(__builtin_bit_cast(h2, scr[0][hf]));
     qqq_static_for<4>([&](auto pc) { tr_piece(pc, wr[0][hf]); __builtin_amdgcn_sched_barrier(0); });
@@ -443,8 +470,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     step(i, uc, std::integral_constant<int, 0>{});
     step(i, uc, std::integral_constant<int, 1>{});
     // the LDS-DMA of stage i + LA - 1, issued during stage i - 1: done when at most the loads issued since its last chunk
-    // (slot NSLOT - 7 of that stage's second step) are outstanding, i.e. this stage's
-    constexpr int since = wide_loads_between(GROUPED, NSLOT, 1, NSLOT - 7, 2, NSLOT);
+    // (the last DMA slot of that stage's second step) are outstanding, i.e. this stage's
+    constexpr int since = wide_loads_between(GROUPED, MT, HW, 1, wide_last_dma_slot(MT, HW), 2, NSLOT);
     static_assert(since < 64, "vmcnt is a 6-bit counter");
     asm volatile("s_waitcnt vmcnt(%0)" : : "n"(since) : "memory");
     if constexpr (!(QQQ_WIDE_ABLATE & 1)) __syncthreads();  // stage i + LA - 1 is in LDS for everybody; buffer (i % P) is free
@@ -469,7 +496,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   qqq_static_for<RS>([&](auto jc) {
     (void)wr[0];
-    asm volatile("" : : "v"(wr[decltype(jc)::value][0]), "v"(wr[decltype(jc)::value][1]));
+    asm volatile("" : : "v"(wr[decltype(jc)::value][0]), "v"(wr[decltype(jc)::value][HW - 1]));
   });
   if constexpr (GROUPED) {
     qqq_static_for<P>([&](auto jc) {
@@ -479,21 +506,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
   // ---- epilogue: EPR rows at a time: int32 -> LDS (row-major, skewed rows) -> 8 consecutive n per thread -> 16-byte stores ----
   // D lane ln of the MFMA holds token j = ln & 15, rows 4 * (ln >> 4) + r -> c' = ln >> 4, jt = r:
-  //   column inside the strip  nl = 64 * wn + 16 * jt + 8 * b + 4 * hf + c'
+  //   column inside the strip  nl = 64 * (column group of the wave) + 16 * jt + 8 * b + 4 * hf + c'
   QQQ_TR(2);
   // (the MFMAs are inline asm: hipcc does not know that the accumulators it is about to read were written by the matrix pipe)
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
   int* ep = reinterpret_cast<int*>(smem);
   const int ej = lane & 15, ecp = lane >> 4;
+  const int egrp = HW == 2 ? wn : (wn >> 1), ehalf = wn & 1;  // the wave's 64-column group of the strip (and, HW = 1, its half)
   constexpr int EP_ITEMS = EPR * (BN / 8), EP_PASSES = EP_ITEMS / NT;  // 16 rows per thread and pass
   auto image = [&](const int pass) {  // this wave's accumulators of EPR rows -> the row-major LDS image
 #pragma unroll
     for (int jm = 0; jm < EPR / 16; ++jm)
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+      for (int q = 0; q < NQ; ++q)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          ep[(16 * jm + ej) * EP_STRIDE + 64 * wn + 16 * r + 8 * (q & 1) + 4 * (q >> 1) + ecp] = acc[pass * (EPR / 16) + jm][q][r];
+          ep[(16 * jm + ej) * EP_STRIDE + 64 * egrp + 16 * r + 8 * (q & 1) + 4 * (HW == 2 ? (q >> 1) : ehalf) + ecp] = acc[pass * (EPR / 16) + jm][q][r];
   };
 
   // ---- in-launch split-K (ksplit > 1): arrival-order tickets as in the panel kernel.  A depositor sends its partial tile
@@ -518,7 +546,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         __syncthreads();
 #pragma unroll
         for (int ps = 0; ps < EP_PASSES; ++ps) {
-          const int row = er0 + 8 * ps;
+          const int row = er0 + RST * ps;
           const unsigned off = (unsigned)(((pass * EPR + row) * BN + c8 * 8) * 4);
           const v4i lo = *reinterpret_cast<const v4i*>(ep + row * EP_STRIDE + c8 * 8);
           const v4i hi4 = *reinterpret_cast<const v4i*>(ep + row * EP_STRIDE + c8 * 8 + 4);
@@ -540,7 +568,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   for (int pass = 0; pass < ROWS / EPR; ++pass)
 #pragma unroll
     for (int ps = 0; ps < EP_PASSES; ++ps) {
-      const int m = mbase + pass * EPR + er0 + 8 * ps;
+      const int m = mbase + pass * EPR + er0 + RST * ps;
       a_s[pass][ps] = s1[m < M ? m : M - 1];
     }
   // interior tiles without the test hook: branch-free stores (a guard per row makes hipcc drain the memory queue per row)
@@ -554,7 +582,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     v4i lo[RB], hi4[RB];
 #pragma unroll
     for (int j = 0; j < RB; ++j) {
-      const int row = er0 + 8 * (half * RB + j);
+      const int row = er0 + RST * (half * RB + j);
       lo[j] = *reinterpret_cast<const v4i*>(ep + row * EP_STRIDE + c8 * 8);
       hi4[j] = *reinterpret_cast<const v4i*>(ep + row * EP_STRIDE + c8 * 8 + 4);
     }
@@ -564,7 +592,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         v4i d0[RB], d1[RB];
 #pragma unroll
         for (int j = 0; j < RB; ++j) {
-          const unsigned off = (unsigned)(((pass * EPR + er0 + 8 * (half * RB + j)) * BN + c8 * 8) * 4);
+          const unsigned off = (unsigned)(((pass * EPR + er0 + RST * (half * RB + j)) * BN + c8 * 8) * 4);
           d0[j] = load16_agent(sv, off);
           d1[j] = load16_agent(sv, off + 16);
         }
@@ -578,7 +606,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int j = 0; j < RB; ++j) {
       const int ps = half * RB + j;
-      const int m = mbase + pass * EPR + er0 + 8 * ps;
+      const int m = mbase + pass * EPR + er0 + RST * ps;
       const h4 o0 = epilogue_vals4(lo[j][0], lo[j][1], lo[j][2], lo[j][3], a_s[pass][ps], s2v[0], s2v[1]);
       const h4 o1 = epilogue_vals4(hi4[j][0], hi4[j][1], hi4[j][2], hi4[j][3], a_s[pass][ps], s2v[2], s2v[3]);
       h8 o = {o0[0], o0[1], o0[2], o0[3], o1[0], o1[1], o1[2], o1[3]};

@@ -80,7 +80,8 @@ def variants(M, K, N):
         if nst >= 3:
             v += [dict(kernel=4, ksplit=3, mt=1), dict(kernel=4, bm=256, ksplit=3), dict(kernel=4, bm=256, mt=8, pw=2, pf=3, ksplit=3)]
     if N % 64 == 0:  # wide kernel: 256 tokens x 256 columns per workgroup, four 512-register waves, no split-K
-        v += [dict(kernel=5), dict(kernel=5, pf=8), dict(kernel=5, pw=4), dict(kernel=5, mt=8), dict(kernel=5, mt=8, pf=4)]
+        v += [dict(kernel=5), dict(kernel=5, pf=8), dict(kernel=5, pw=4), dict(kernel=5, mt=8), dict(kernel=5, mt=8, pf=4),
+              dict(kernel=5, bm=128), dict(kernel=5, bm=128, pf=8, pw=16)]
         if K % 128 == 0 and K // 128 >= 8:  # in-launch split-K: row-major partial tiles in C, tickets in workspace
             v += [dict(kernel=5, ksplit=2), dict(kernel=5, mt=8, ksplit=2)]
         if K % 128 == 0 and K // 128 >= 12:

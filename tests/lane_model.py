@@ -462,20 +462,24 @@ def wide_tile_order(tiles_m, tiles_n, ksplit, PW):
     return out
 
 
-def wide_kernel_model(A, B, s3, M, N, K, MT, ksplit, grouped, PW=8):
+def wide_kernel_model(A, B, s3, M, N, K, MT, ksplit, grouped, PW=8, BN=256):
     """qqq_wide_kernel: a workgroup = 16*MT tokens x 256 columns x one K slice, four waves; wave wn owns the 64-column group
     tile_n*4 + wn (both halves) and all m-tiles.  Weights: buffer loads at lane offset h*rowbytes + cq*64 + q4*16 (+256 per
     half) over the descriptor base B + ng*512, scalar offset 4*(2*st0 + s)*rowbytes, quad transpose; activations by LDS-DMA: instruction
     q of wave wn fills the lane-linear 1 KiB at q*4096 + wn*1024 of the stage image (lane l -> byte 16 l: row (tid >> 3) + 32 q,
     slot tid & 7) and FETCHES piece slot ^ ((row >> 1) & 7) of that row (the swizzle is on the source side), scalar
     offset (st0 + st)*128 over the base A + mbase*K; fragments as in the panel kernel; epilogue / split-K slot image
-    row-major [ROWS][256] with column 64*wn + 16*r + 8*b + 4*hf + c'.  Returns (acc [M,N], the list of slot images)."""
+    row-major [ROWS][BN] with column 64*wn + 16*r + 8*b + 4*hf + c'.  BN = 128 (MT = 16 only): a wave owns ONE 32-column half
+    (cb & 1) of the 64-column group cb >> 1, cb = tile_n*4 + wn: lane offset + 256*half, one weight load per step, image column
+    64*(wn >> 1) + 16*r + 8*b + 4*(wn & 1) + c'.  Returns (acc [M,N], the list of slot images)."""
     assert K % 128 == 0
     Bb = np.ascontiguousarray(B).view(np.uint8).reshape(-1)
     Ab = np.ascontiguousarray(A).view(np.uint8).reshape(-1)
     s3h = None if not grouped else np.ascontiguousarray(s3).reshape(-1)
     rowbytes = N * 8
-    ROWS, BN = 16 * MT, 256
+    ROWS = 16 * MT
+    HW = BN // 128
+    assert BN == 256 or (BN == 128 and MT == 16)
     XPT = ROWS * 128 // 16 // 256
     ngroups = N >> 6
     tiles_m, tiles_n = -(-M // ROWS), -(-N // BN)
@@ -506,20 +510,22 @@ def wide_kernel_model(A, B, s3, M, N, K, MT, ksplit, grouped, PW=8):
                     img[dst[t_] : dst[t_] + 16] = Ab[src[t_] : src[t_] + 16]
             imgs.append(img)
         for wn in range(4):
-            ng = min(tile_n * 4 + wn, ngroups - 1)
-            woff = h * rowbytes + cq * 64 + q4 * 16
-            acc = np.zeros((MT, 4, 64, 4), np.int64)
+            cb = tile_n * 4 + wn
+            ng = min(cb if HW == 2 else cb >> 1, ngroups - 1)
+            whalf = 0 if HW == 2 else (cb & 1)
+            woff = h * rowbytes + cq * 64 + q4 * 16 + 256 * whalf
+            acc = np.zeros((MT, 2 * HW, 64, 4), np.int64)
             for st in range(nst):
                 for t in range(2):
                     s = 2 * st + t
                     ops = []
-                    for hf in range(2):
+                    for hf in range(HW):
                         src = ng * 512 + woff + 256 * hf + 4 * (2 * st0 + s) * rowbytes
                         w = Bb[src[:, None] + np.arange(16)[None, :]].reshape(64, 4, 4)
                         w = (w.astype(np.uint32) << (8 * np.arange(4, dtype=np.uint32))).sum(-1).astype(np.uint32)
                         y = _quad_transpose4(w)
                         if grouped:
-                            so = ng * 64 + cq * 8 + 2 * q4 + 32 * hf + (st0 + st) * N   # halves: lane offset + 64 B per half + stage
+                            so = ng * 64 + cq * 8 + 2 * q4 + 32 * (hf + whalf) + (st0 + st) * N   # halves: lane offset + 64 B per half + stage
                             w0, w1 = unpack_pair(y, True, s3h[so][:, None], s3h[so + 1][:, None])
                         else:
                             w0, w1 = y & MASK, (y << np.uint32(4)) & MASK
@@ -527,13 +533,13 @@ def wide_kernel_model(A, B, s3, M, N, K, MT, ksplit, grouped, PW=8):
                     for mt in range(MT):
                         ad = panel_fragment_addr(mt, t)
                         x = imgs[st][ad[:, None] + np.arange(16)[None, :]].view(np.int8)
-                        for q in range(4):
+                        for q in range(2 * HW):
                             acc[mt, q] += mfma_16x16x64(ops[q], x)
             j, cp = lane & 15, lane >> 4
             for mt in range(MT):
-                for q in range(4):
+                for q in range(2 * HW):
                     for r in range(4):
-                        col = 64 * wn + 16 * r + 8 * (q & 1) + 4 * (q >> 1) + cp
+                        col = (64 * wn + 4 * (q >> 1) if HW == 2 else 64 * (wn >> 1) + 4 * (wn & 1)) + 16 * r + 8 * (q & 1) + cp
                         np.add.at(image, (16 * mt + j, col), acc[mt, q, :, r])
         partial.setdefault((tile_m, tile_n), []).append(image)
     assert len(seen) == tiles_m * tiles_n * ksplit

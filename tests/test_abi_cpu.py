@@ -110,13 +110,13 @@ def _check_plan(m, n, k, grouped, max_par):
     p = _lib.plan(m, n, k, gs, max_par)
     assert p["kernel"] in (1, 2, 3, 4, 5) and p["ksplit"] >= 1
     cap_rows, cap_tk = max_par * 64, (n // 128) * max_par
-    if p["kernel"] == 5:  # wide: 256 x 256 tiles; 32-bit offsets into the packed weights; one slot of C per depositing slice
+    if p["kernel"] == 5:  # wide: 256 x 256 / 256 x 128 / 128 x 256 tiles; 32-bit offsets into the packed weights; one slot of C per depositing slice
         assert m > 256 and n % 64 == 0 and k % 128 == 0 and n * k // 2 < 2**32
-        assert p["pf"] in (4, 8) and p["stages"] == 1 and p["pw"] in (4, 8, 16, 32) and p["mt"] in (8, 16)
+        assert p["pf"] in (4, 8) and p["stages"] == 1 and p["pw"] in (4, 8, 16, 32) and (p["mt"], p["bm"]) in ((16, 256), (16, 128), (8, 256))
         rows = 16 * p["mt"]
-        tiles = -(-m // rows) * -(-n // 256)
+        tiles = -(-m // rows) * -(-n // p["bm"])
         if p["ksplit"] > 1:
-            assert tiles * rows * 256 * (p["ksplit"] - 1) <= cap_rows * n and 2 * tiles <= cap_tk and p["ksplit"] <= (k // 128) // 4
+            assert tiles * rows * p["bm"] * (p["ksplit"] - 1) <= cap_rows * n and 2 * tiles <= cap_tk and p["ksplit"] <= (k // 128) // 4
         assert _lib.plan(m, n, k, gs, max_par, have_scratch=False)["ksplit"] == 1
         return p
     if p["kernel"] == 4:  # panel: one slot of C per depositing slice, two ticket words per tile
@@ -199,12 +199,18 @@ def test_dispatch_of_the_baseline_sweep(L):
     assert _lib.plan(16, N, K, -1, 16)["kernel"] == 1
     p = _lib.plan(128, N, K, -1, 16)
     assert (p["kernel"], p["mt"], p["ksplit"]) == (4, 8, 4)
-    # 640 - 1024 tokens: per-channel the wide kernel's 128-token tiles (one round of 128 x 256 tiles, no split); per-group its
-    # 256-token tiles with two K slices (128 tiles x 2 slices = one round: the re-quantiser wants 256 tokens per weight operand)
+    # 320 - 512 tokens: 256 x 128 tiles of the wide kernel in two K slices (2 m-tiles x 64 strips x 2 = one round), both modes;
+    # 640 - 1024 tokens: per-channel its 128-token tiles (one round of 128 x 256 tiles, no split); per-group its 256 x 128
+    # tiles, unsplit (the re-quantiser wants 256 tokens per weight operand; 4 m-tiles x 64 strips = one round)
+    # (profiles/r03_dispatch_check_wide3.txt)
+    for m in (320, 512):
+        for gs in (-1, 128):
+            p = _lib.plan(m, N, K, gs, 16)
+            assert (p["kernel"], p["mt"], p["bm"], p["ksplit"]) == (5, 16, 128, 2), (m, gs, p)
     for m in (640, 768, 1024):
         p, g = _lib.plan(m, N, K, -1, 16), _lib.plan(m, N, K, 128, 16)
-        assert (p["kernel"], p["mt"], p["ksplit"]) == (5, 8, 1), (m, p)
-        assert (g["kernel"], g["mt"], g["ksplit"]) == (5, 16, 2), (m, g)
+        assert (p["kernel"], p["mt"], p["bm"], p["ksplit"]) == (5, 8, 256, 1), (m, p)
+        assert (g["kernel"], g["mt"], g["bm"], g["ksplit"]) == (5, 16, 128, 1), (m, g)
     p = _lib.plan(1024, N, K, -1, 16, tune=dict(kernel=4, bm=256, mt=8, pw=2))  # the round-2 choice stays available
     assert (p["kernel"], p["bm"], p["mt"], p["pw"], p["ksplit"]) == (4, 256, 8, 2, 1), p
     # from ~1.5 K tokens (>= 3/4 of a round of 256 x 256 tiles) the wide kernel, both modes (round 3:
@@ -212,7 +218,8 @@ def test_dispatch_of_the_baseline_sweep(L):
     for m in (1280, 1536, 2048, 4096, 8192):
         for gs in (-1, 128):
             p = _lib.plan(m, N, K, gs, 16)
-            assert (p["kernel"], p["ksplit"], p["pf"], p["stages"], p["pw"]) == (5, 1, 4 if gs < 0 else 8, 1, 8), (m, gs, p)
+            assert (p["kernel"], p["mt"], p["bm"], p["ksplit"], p["pf"], p["stages"], p["pw"]) == (5, 16, 256, 1, 4 if gs < 0 else 8, 1, 8), (m, gs, p)
+    assert _lib.plan(1024, N, K, -1, 16, tune=dict(kernel=5, bm=128))["bm"] == 128 and _lib.plan(1024, N, K, -1, 16, tune=dict(kernel=5, mt=8, bm=128))["bm"] == 256
     assert _lib.plan(4096, N, K, -1, 16, tune=dict(kernel=5, pf=8))["pf"] == 8 and _lib.plan(4096, N, K, 128, 16, tune=dict(kernel=5, pf=4))["pf"] == 4
     assert _lib.plan(4096, N, K, -1, 16, tune=dict(kernel=5, stages=3))["stages"] == 1  # LDS-DMA staging: one lead, a full stage
     assert _lib.plan(1024, N, K, -1, 16, tune=dict(kernel=5, mt=8))["mt"] == 8 and _lib.plan(1024, N, K, -1, 16, tune=dict(kernel=5))["mt"] == 16

@@ -63,8 +63,9 @@ def test_hot_instantiations(table):
         # one workgroup must fit a CU: 512 registers per lane and SIMD, 8-wave workgroups -> 2 waves per SIMD
         assert k["vgpr_count"] <= 512, n
         if n.startswith("qqq_wide_kernel"):  # 4-wave workgroups, one wave per SIMD: all 256 accumulation registers
-            mt = int(n.split("<")[1].split(",")[1])  # 16 / 8 m-tiles x 4 column sets x 4 registers
-            assert k["agpr_count"] == 16 * mt and k["max_flat_workgroup_size"] == 256, (n, k)
+            args = n.split("<")[1].rstrip(">").split(",")
+            mt, hw = int(args[1]), int(args[4])  # 16 / 8 m-tiles x 2 hw column sets x 4 registers
+            assert k["agpr_count"] == 8 * hw * mt and k["max_flat_workgroup_size"] == 256, (n, k)
 
 
 def _loop(name):
@@ -105,7 +106,7 @@ def test_steady_state_loops(table):
     # scratch inside the loop, counted waits, and the issue budget of a LONE wave: at most 4 instructions per MFMA
     # (16 matrix-pipe cycles = 4 issue slots) in the per-channel mode.  LDS-DMA staging: no ds_write at all, per trip
     # 4 x 8 activation DMAs + 8 x 2 ring refills (+ 4 x 2 scale words per-group), every one inline asm.
-    for name, grouped in (("qqq_wide_kernel<false,16,4,4>", False), ("qqq_wide_kernel<true,16,4,8>", True)):
+    for name, grouped in (("qqq_wide_kernel<false,16,4,4,2>", False), ("qqq_wide_kernel<true,16,4,8,2>", True)):
         mix, waits = _loop(name)
         assert mix["v_mfma_i32_16x16x64_i8"] == 512 and mix["s_barrier"] == 4, name
         assert _count(mix, "scratch") == 0 and not any("vmcnt(0)" in w for w in waits), (name, waits)
@@ -128,9 +129,9 @@ def test_steady_state_loops(table):
 def test_wide_kernel_hand_counted_waits_replayed_on_the_compiled_code():
     """Every vector-memory load of the wide kernel's loop is inline asm and its waits are hand-counted (LDS-DMA staging: hipcc
     cannot count what it cannot see).  tools/check_waits.py replays the compiled instruction stream -- the loop twice, then every
-    feasible path through the ragged tail up to the drain -- with loads retiring in issue order, and reports any instruction that
+    feasible path through the ragged tail up to the drain, and the prologue's asm loads -- with loads retiring in issue order, and reports any instruction that
     touches a register a load still in flight is going to write (a too-large count, or hipcc reusing the destination of a dead
-    load: both happened while this was written).  All eight instantiations; and at each barrier exactly the current stage's
+    load: both happened while this was written).  All twelve instantiations; and at each barrier exactly the current stage's
     loads may be in flight (the previous stage's DMAs, which the barrier publishes, have retired)."""
     import check_waits
     import code_object
@@ -138,16 +139,19 @@ def test_wide_kernel_hand_counted_waits_replayed_on_the_compiled_code():
 
     ks = {k["demangled"]: k["name"] for k in code_object.kernels(build.LIB)}
     for grouped in (False, True):
-        for mt in (16, 8):
+        for mt, hw in ((16, 2), (8, 2), (16, 1)):
             for rs in (4, 8):
-                name = f"qqq_wide_kernel<{'true' if grouped else 'false'},{mt},4,{rs}>"
+                name = f"qqq_wide_kernel<{'true' if grouped else 'false'},{mt},4,{rs},{hw}>"
                 text = code_object.disassemble(build.LIB, ks[name])
                 body, paths = check_waits.tail_paths(text.split("\n"))
-                assert sum("v_mfma" in x for x in body) == 32 * mt and len(paths) == 4, (name, len(paths))
+                assert sum("v_mfma" in x for x in body) == 16 * hw * mt and len(paths) == 4, (name, len(paths))
                 problems, at_barrier = check_waits.check(body)
                 for path in paths:
                     problems += check_waits.check(body, path)[0]
+                problems += check_waits.check_prologue(text.split("\n"))
                 assert not problems, (name, sorted(set(problems))[:4])
-                per_step = "rr" + "D" * (mt // 4)
-                assert at_barrier == [per_step + ("rr" if grouped else "") + per_step] * 4, (name, at_barrier)
+                per_step = "r" * hw + "D" * (mt // 4)  # ring refill(s), then the step's activation chunks
+                second = ("rr" if grouped else "") + per_step if hw == 2 else "r" + ("rr" if grouped else "") + "D" * (mt // 4)
+                per_step = per_step + second
+                assert at_barrier == [per_step] * 4, (name, at_barrier)
 

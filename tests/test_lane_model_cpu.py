@@ -125,6 +125,12 @@ def test_wide_kernel_model(grouped):
     A, B, s3, acc = _case(rng, 70, 512, 1024, grouped)
     got, slots = LM.wide_kernel_model(A, B, s3, 70, 512, 1024, MT=16, ksplit=3, **kw)
     assert np.array_equal(got, acc) and len(slots) == 2 * 2
+    # 256 x 128 tiles: a wave owns one 32-column half of a 64-column group (ragged n: 320 = 2 strips + half a strip)
+    got, slots = LM.wide_kernel_model(A, B, s3, 70, 512, 1024, MT=16, ksplit=2, BN=128, **kw)
+    assert np.array_equal(got, acc) and len(slots) == 4 and all(sl.shape == (256, 128) for sl in slots)
+    A, B, s3, acc = _case(rng, 300, 320, K, grouped)
+    got, _ = LM.wide_kernel_model(A, B, s3, 300, 320, K, MT=16, ksplit=1, BN=128, PW=4, **kw)
+    assert np.array_equal(got, acc)
 
 
 def test_wide_tile_order_is_a_bijection_and_keeps_slices_together():

@@ -126,6 +126,35 @@ def check(body, tail=()):
     return problems, barrier_counts
 
 
+def check_prologue(lines):
+    """the asm loads (buffer_load ...) in front of the loop: nothing may touch their destinations before the wait that drains
+    them.  (The compiler's own global_loads up there are its business: it counts them itself.)"""
+    body = loop_body(lines)
+    if not body:
+        return []
+    start = next(i for i in range(len(lines)) if lines[i : i + len(body)] == body)
+    queue, problems = [], []
+    for l in lines[:start]:
+        ins = l.split(";")[0].strip()
+        if not ins or ins.startswith(".") or ins.endswith(":"):
+            continue
+        op, _, rest = ins.partition(" ")
+        toks = [t.strip() for t in rest.split(",")]
+        m = re.search(r"vmcnt\((\d+)\)", ins)
+        if op == "s_waitcnt" and m:
+            n = int(m.group(1))
+            queue = queue[len(queue) - n :] if n and len(queue) > n else ([] if n == 0 else queue)
+            continue
+        if op.startswith("buffer_load"):
+            queue.append(None if " lds" in ins else regs(toks[0]))
+            continue
+        used = set()
+        for t in toks:
+            used |= regs(t.split()[0] if t else "")
+        problems += [ins for q in queue if q and (q & used)]
+    return problems
+
+
 def main():
     src, name = sys.argv[1], sys.argv[2]
     if src.endswith(".so"):
@@ -140,7 +169,7 @@ def main():
     problems, barrier = check(body)
     for path in paths:
         problems += check(body, path)[0]
-    problems = sorted(set(problems))
+    problems = sorted(set(problems + check_prologue(text.split("\n"))))
     print(f"{len(paths)} paths from the loop exit to the drain")
     print(f"{sum('v_mfma' in x for x in body)} MFMAs in the loop; in flight at each s_barrier (oldest first): {barrier}")
     for p in problems:

@@ -28,9 +28,13 @@ for (N, K) in shapes:
                    "panel": t(dict(kernel=4)), "panel256": t(dict(kernel=4, bm=256)),
                    "panel256x2": t(dict(kernel=4, bm=256, pw=2, pf=4)) if M >= 256 else float("nan"),
                    "wide": t(dict(kernel=5)) if M > 256 else float("nan")}
+            if os.environ.get("WIDE_SHAPES") == "1" and M > 256:  # every shape of the wide kernel, for fitting its cost model
+                res.update({"w16x2": t(dict(kernel=5, ksplit=2)), "w8": t(dict(kernel=5, mt=8)), "w128": t(dict(kernel=5, bm=128)),
+                            "w128x2": t(dict(kernel=5, bm=128, ksplit=2))})
             best = min((v, k) for k, v in res.items() if v == v and k != "auto")
             flag = "" if res["auto"] <= best[0] * 1.03 else f"   <-- {best[1]} is {100 * (res['auto'] / best[0] - 1):.0f}% faster"
-            print(f"N={N:5d} K={K:5d} {mode:4s} M={M:4d}  auto(k{p['kernel']},ks{p['ksplit']}) {res['auto']:7.1f} | stream {res['stream']:7.1f} tiled {res['tiled']:7.1f} panel {res['panel']:7.1f} panel256 {res['panel256']:7.1f} panel256x2 {res['panel256x2']:7.1f} wide {res['wide']:7.1f}{flag}")
+            extra = "".join(f" {k} {res[k]:7.1f}" for k in ("w16x2", "w8", "w128", "w128x2") if k in res)
+            print(f"N={N:5d} K={K:5d} {mode:4s} M={M:4d}  auto(k{p['kernel']},ks{p['ksplit']}) {res['auto']:7.1f} | stream {res['stream']:7.1f} tiled {res['tiled']:7.1f} panel {res['panel']:7.1f} panel256 {res['panel256']:7.1f} panel256x2 {res['panel256x2']:7.1f} wide {res['wide']:7.1f}{extra}{flag}")
             sys.stdout.flush()
         del layer
         torch.cuda.empty_cache()
