@@ -340,7 +340,7 @@ static hipError_t launch_tiled(const LaunchArgs& a, bool grouped, int bm, int st
 template <bool GROUPED, int MT, int P, int RS, int HW>
 static hipError_t launch_wide_t(const LaunchArgs& a, int pw, int ksplit) {
   constexpr int ROWS = 16 * MT, BN = 128 * HW;
-  constexpr int XBUF = P * ROWS * 128, EP = (MT == 16 ? (HW == 2 ? 128 : 256) : 64) * (BN + 4) * 4 + 16;  // + the ticket exchange word
+  constexpr int XBUF = P * ROWS * 128, EP = (HW == 2 ? 8 * MT : 16 * MT) * (BN + 4) * 4 + 16;  // + the ticket exchange word
   constexpr int LDS = XBUF > EP ? XBUF : EP;
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static bool attr_set[64] = {};  // per instantiation, per device
@@ -607,6 +607,8 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
     // one slot of C per depositing slice (row-major partial tiles) and two ticket words per tile
     pl.mt = (t.mt == 8) ? 8 : 16;                         // 16-token m-tiles per workgroup: 256- or 128-token tiles
     pl.bm = (t.bm == 128 && pl.mt == 16) ? 128 : 256;     // columns per workgroup: 64 or (256-token tiles only) 32 per wave
+    // (128 x 128 tiles compile from the same template and were measured: 39 us at M=128 against the panel kernel's 36, 4 % ahead
+    // of it only at 160-256 tokens in two K slices -- not instantiated; profiles/r03_wide_128x128.txt)
     pl.stages = 1;                                        // activation lead: the LDS-DMA of a stage is issued a full stage ahead
     pl.pf = (t.pf == 8 || t.pf == 4) ? t.pf : (grouped ? 8 : 4);  // weight ring in 64-k steps (per-group: 8 measured 1.5 % ahead)
     pl.pw = (t.pw == 4 || t.pw == 8 || t.pw == 16 || t.pw == 32) ? t.pw : 8;

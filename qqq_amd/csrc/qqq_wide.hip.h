@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     int32_t* __restrict__ acc_out, int* __restrict__ tickets, const _Float16* __restrict__ bias, const int M, const int N,
     const int K, const int tiles_m, const int tiles_n, const int PW, const int ksplit) {
   static_assert(MT == 16 || MT == 8, "m-tiles of 16 tokens per wave (= per workgroup): 256 or 128 tokens");
-  static_assert(HW == 2 || (HW == 1 && MT == 16), "a wave owns both 32-column halves of a 64-column group, or (256 x 128 tiles) one");
+  static_assert(HW == 2 || HW == 1, "a wave owns both 32-column halves of a 64-column group, or (128-column tiles) one");
   constexpr int ROWS = 16 * MT;
   constexpr int NQ = 2 * HW;             // column sets (of 16) per wave
   constexpr int BN = 128 * HW;           // 4 waves x 32 HW columns
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   static_assert(P == 4, "four LDS stage buffers: one being read, one complete, two in flight");
   constexpr int LA = P - 1;
   constexpr int NSLOT = NQ * MT;         // issue slots (= MFMAs) of a 64-k step
-  constexpr int EPR = (MT == 16) ? (HW == 2 ? 128 : 256) : 64;  // rows per epilogue pass (int32 image: EPR x (BN + 4) x 4 B = 130 / 132 / 65 KiB)
+  constexpr int EPR = HW == 2 ? 8 * MT : 16 * MT;  // rows per epilogue pass: half the tile, or (128-column tiles) all of it (int32 image: EPR x (BN + 4) x 4 B = 130 / 65 / 132 / 66 KiB)
   constexpr int EP_STRIDE = BN + 4;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
