@@ -506,6 +506,36 @@ def test_panel_two_workgroups_per_cu(dev):
                     assert ulp_distance(D, eD) == 0, (grouped, M, tune, rep)
 
 
+def test_wide_every_instantiation_every_k_tail(dev):
+    """The wide kernel stages by LDS-DMA and counts its own waits: every one of its twelve instantiations
+    (per-channel / per-group x 256 x 256, 128 x 256, 256 x 128 tiles x ring of 4 / 8 steps), alone and in two K slices, on
+    K = 1 ... 11 stages of 128 -- no loop trip at all, whole trips of four stages, and every length of ragged tail behind them
+    (where the first LDS-DMA build let hipcc reuse the destination of a dead load) -- against the oracle, ragged m and n."""
+    from oracle import c_oracle as C
+    from oracle import qqq_ref as R
+
+    rng = np.random.default_rng(2024)
+    N, M = 448, 300  # 1.75 strips of 256 / 3.5 of 128; 1.2 / 2.3 m-tiles
+    for grouped in (False, True):
+        for st in (1, 2, 3, 4, 5, 6, 7, 8, 9, 11):
+            K = 128 * st
+            codes = rng.integers(0 if grouped else -8, 16 if grouped else 8, size=(K, N)).astype(np.int8)
+            B = R.pack_codes(codes, grouped)
+            s2 = rng.random((1, N), dtype=np.float32) * 2e-4 + 1e-5
+            s3 = (rng.random((K // 128, N), dtype=np.float32) * 15 + 0.5).astype(np.float16) if grouped else None
+            h = GemmHarness(B, s2, s3, dev)
+            A = rng.integers(-128, 128, size=(M, K), dtype=np.int8)
+            s1 = rng.random((M, 1), dtype=np.float32) * 0.05 + 0.001
+            eD, eacc = C.qqq_gemm(A, B, s1, s2, s3, return_acc=True)
+            for shape in (dict(), dict(mt=8), dict(bm=128)):
+                for pf in (4, 8):
+                    for ks in (1, 2) if st >= 8 else (1,):
+                        tune = dict(kernel=5, pf=pf, ksplit=ks, **shape)
+                        D, acc = h.run(A, s1, tune)
+                        assert np.array_equal(acc, eacc), (grouped, K, tune)
+                        assert ulp_distance(D, eD) == 0, (grouped, K, tune)
+
+
 def test_every_variant_under_load(dev):
     """Every tuning variant, repeatedly, while a second stream keeps the chip busy with other GEMMs of mixed weight (so
     that workgroups of different kernels share CUs and the waves of a workgroup drift apart): results must equal the
