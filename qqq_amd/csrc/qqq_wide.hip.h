@@ -191,8 +191,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // Every vector-memory load from here to the end of the main loop is inline asm (see QQQ_WIDE_DMA above): descriptors as plain
   // SGPR quads (base, stride 0, no bound, raw-buffer flags), 32-bit lane offset, scalar step / stage offset.
   auto descriptor = [](const void* base_uniform) {
-    const unsigned long long a = (unsigned long long)base_uniform;
-    return (v4u){(unsigned)a, (unsigned)(a >> 32), 0xffffffffu, 0x00020000u};
+    const unsigned long long a = (unsigned long long)base_uniform;  // (readfirstlane: an "s" operand must not reach the asm in VGPRs)
+    return (v4u){(unsigned)__builtin_amdgcn_readfirstlane((int)a), (unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)), 0xffffffffu,
+                 0x00020000u};
   };
   const v4u wdesc = descriptor(B + (size_t)ng * 512);
   const unsigned woff = (unsigned)h * rowbytes + (unsigned)(cq * 64 + q4 * 16 + 256 * whalf);   // + step * 4 * rowbytes (scalar) + 256 * hf
@@ -220,8 +221,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     (void)lds_wave;  // (odr-use: clang does not capture what only an asm operand of a generic lambda names)
     asm volatile("s_add_u32 m0, %0, %1" : : "s"(lds_wave), "n"(dst) : "scc");
   };
-  auto dma_go = [&](auto qc, const unsigned so) __attribute__((always_inline)) {
+  // (the scalar offset is pinned to an SGPR: a value hipcc can fold to a literal is not a valid soffset operand)
+  auto dma_go = [&](auto qc, unsigned so) __attribute__((always_inline)) {
     (void)xoff[0], (void)xdesc;
+    so = __builtin_amdgcn_readfirstlane(so);
+    asm("" : "+s"(so));
     asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(xoff[decltype(qc)::value]), "s"(xdesc), "s"(so) : "memory");
   };
   auto dma_x = [&](auto bufc, auto qc, const unsigned so) __attribute__((always_inline)) {  // chunk q of a stage -> LDS buffer buf
@@ -234,8 +238,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const unsigned so = (unsigned)(st0 + st) * 128u;
     qqq_static_for<XPT>([&](auto qc) { dma_x(bufc, qc, so); });
   };
-  auto asm_load_w = [&](v4u& dst, auto hfc, const unsigned so) __attribute__((always_inline)) {
+  auto asm_load_w = [&](v4u& dst, auto hfc, unsigned so) __attribute__((always_inline)) {
     (void)woff, (void)wdesc;
+    so = __builtin_amdgcn_readfirstlane(so);
+    asm("" : "+s"(so));
     asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=v"(dst) : "v"(woff), "s"(wdesc), "s"(so), "n"(256 * decltype(hfc)::value));
   };
   auto load_w = [&](const int step_rel, v4u (&dst)[HW]) __attribute__((always_inline)) {
@@ -247,7 +253,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // static schedule do not depend on HW)
   auto load_sc = [&](const int st_rel, unsigned (&dst)[2]) __attribute__((always_inline)) {  // (raw words: an h2 copy behind the asm would read early)
     const int st = st_rel < NST ? st_rel : NST - 1;
-    const unsigned so = (unsigned)(st0 + st) * (unsigned)N * 2u;
+    unsigned so = (unsigned)(st0 + st) * (unsigned)N * 2u;
+    so = __builtin_amdgcn_readfirstlane(so);
+    asm("" : "+s"(so));
     asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(dst[0]) : "v"(soff_l), "s"(sdesc), "s"(so));
     asm volatile("buffer_load_dword %0, %1, %2, %3 offen offset:%4" : "=v"(dst[1]) : "v"(soff_l), "s"(sdesc), "s"(so), "n"(HW == 2 ? 64 : 0));
   };

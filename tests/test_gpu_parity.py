@@ -467,8 +467,8 @@ def test_wide_inlaunch_splitk_stress_two_streams(dev):
             for li, h in enumerate(layers):
                 M = Ms[(it + 2 * li) % len(Ms)]
                 A, s1 = toks[M]
-                tune = [dict(kernel=5, ksplit=2), dict(kernel=5, mt=8, ksplit=2), dict(kernel=5, ksplit=3), dict(kernel=5, mt=8, ksplit=3, pf=6),
-                        dict(kernel=5, ksplit=2, pw=4)][it % 5]
+                tune = [dict(kernel=5, ksplit=2), dict(kernel=5, mt=8, ksplit=2), dict(kernel=5, ksplit=3), dict(kernel=5, mt=8, ksplit=3, pf=8),
+                        dict(kernel=5, ksplit=2, pw=4), dict(kernel=5, bm=128, ksplit=2)][it % 6]
                 D = torch.empty((M, N), dtype=torch.float16, device=dev)
                 with torch.cuda.stream(streams[li]):
                     ops.qqq_gemm_ex(A, h.B, h.C, D, s1, h.s2, h.s3, h.ws, -1, -1, -1, 16, tune=tune)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Phase timeline of the wide kernel from inside the kernel (thread 0 of every workgroup: 100 MHz wall clock at entry / loop
-start / loop end / last store drained, shader clock at the top of the first 12 trips of the 3-stage loop).
+start / loop end / last store drained, shader clock at the top of the first 12 trips of the 4-stage loop).
 
 Build (where hipcc is):   QQQ_AMD_LIB=$PWD/qqq_amd/libqqq_amd_trace.so QQQ_AMD_CXXFLAGS=-DQQQ_PANEL_TRACE python -m qqq_amd.build
 Run (GPU box):            QQQ_AMD_LIB=$PWD/qqq_amd/libqqq_amd_trace.so MS=4096 python tools/trace_wide.py"""
@@ -22,7 +22,8 @@ q = lambda v: f"{np.min(v):8.2f} {np.median(v):8.2f} {np.max(v):8.2f}"
 for M in [int(x) for x in os.environ.get("MS", "4096").split(",")]:
     A, s1 = Bn.make_tokens(dev, M, M, K=KK)
     D = torch.empty((M, NN), dtype=torch.float16, device=dev)
-    nwg = -(-NN // 256) * -(-M // 256)
+    pl = _lib.plan(M, NN, KK, 128 if grouped else -1, 16, tune=tune)  # the grid of the shape that will run (tile height / width, K slices)
+    nwg = -(-NN // pl["bm"]) * -(-M // (16 * pl["mt"])) * pl["ksplit"]
     buf = torch.zeros((nwg, 16), dtype=torch.int64, device=dev)
     L.qqq_trace_set(None)
     ev = layer.time_calls(A, s1, D, 6, tune=tune)
