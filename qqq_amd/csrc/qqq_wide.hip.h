@@ -134,10 +134,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   constexpr int XB = ROWS * 128;         // bytes of one activation stage (128 k)
   constexpr int XPT = XB / 16 / NT;      // 16-byte chunks per thread and stage (8 / 4)
   static_assert((2 * P) % RS == 0, "weight ring (in 64-k steps) must divide the unroll period");
-  // P LDS stage buffers = unroll period in stages.  The LDS-DMA of stage i + LA is ISSUED during stage i (its buffer was last
-  // read in stage i - 1), is waited for at the end of stage i + 1 (a full stage of lead) and published by that stage's barrier:
-  // the fragment reads of stage i + LA begin in the last step of stage i + LA - 1 = i + 2.
-  static_assert(P == 4, "four LDS stage buffers: one being read, one complete, two in flight");
+  // P LDS stage buffers = unroll period in stages.  The LDS-DMA of stage i + LA (LA = P - 1) is ISSUED during stage i (its
+  // buffer was last read in stage i - 1), is waited for at the end of stage i + LA - 2 -- P - 3 full stages of lead: one with
+  // four buffers, three with six -- and published by that stage's barrier: the fragment reads of stage i + LA begin in the last
+  // step of stage i + LA - 1.  (A stage of 128 tokens lasts 0.7 us: less than an HBM round trip under load.)
+  static_assert(P >= 4 && P <= 6, "LDS stage buffers: one being read, one complete, P - 2 in flight");
   constexpr int LA = P - 1;
   constexpr int NSLOT = NQ * MT;         // issue slots (= MFMAs) of a 64-k step
   constexpr int EPR = HW == 2 ? 8 * MT : 16 * MT;  // rows per epilogue pass: half the tile, or (128-column tiles) all of it (int32 image: EPR x (BN + 4) x 4 B = 130 / 65 / 132 / 66 KiB)
@@ -390,8 +391,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if constexpr (w_ == 0) {
               // ring slot sn, half hf: loaded RS - 1 steps ago at slot 2 + 4 hf; everything older (the group scales of this
               // stage among it) has landed once at most the loads issued since are outstanding
-              constexpr int younger = wide_loads_between(GROUPED, MT, HW, (t + RS - 1) & 1, 2 + 4 * hf, RS - 1, k);
-              static_assert(younger < 64, "vmcnt is a 6-bit counter");
+              // (vmcnt is a 6-bit counter: a deeper ring than 63 loads waits a little early, never late)
+              constexpr int younger_all = wide_loads_between(GROUPED, MT, HW, (t + RS - 1) & 1, 2 + 4 * hf, RS - 1, k);
+              constexpr int younger = younger_all < 63 ? younger_all : 63;
               if constexpr (GROUPED) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(wr[sn][hf]), "+v"(scr[su][hf]) : "n"(younger));
               else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(wr[sn][hf]) : "n"(younger));
               un_setup(__builtin_bit_cast(h2, scr[su][hf]));
@@ -477,12 +479,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   auto do_stage = [&](const int i, auto uc) __attribute__((always_inline)) {  // one 128-k stage: two steps and the barrier that publishes stage i + LA
     step(i, uc, std::integral_constant<int, 0>{});
     step(i, uc, std::integral_constant<int, 1>{});
-    // the LDS-DMA of stage i + LA - 1, issued during stage i - 1: done when at most the loads issued since its last chunk
-    // (the last DMA slot of that stage's second step) are outstanding, i.e. this stage's
-    constexpr int since = wide_loads_between(GROUPED, MT, HW, 1, wide_last_dma_slot(MT, HW), 2, NSLOT);
+    // the LDS-DMA of stage i + 2, issued during stage i + 3 - P: done when at most the loads issued since its last chunk
+    // (the last DMA slot of that stage's second step) are outstanding, i.e. those of the P - 3 stages since
+    constexpr int since = wide_loads_between(GROUPED, MT, HW, 1, wide_last_dma_slot(MT, HW), 2 * (P - 3), NSLOT);
     static_assert(since < 64, "vmcnt is a 6-bit counter");
     asm volatile("s_waitcnt vmcnt(%0)" : : "n"(since) : "memory");
-    if constexpr (!(QQQ_WIDE_ABLATE & 1)) __syncthreads();  // stage i + LA - 1 is in LDS for everybody; buffer (i % P) is free
+    if constexpr (!(QQQ_WIDE_ABLATE & 1)) __syncthreads();  // stage i + 2 is in LDS for everybody; buffer (i % P) is free
   };
   QQQ_TR(1);
   // ---- steady state: P stages per iteration (ring slots and LDS buffers are compile-time), branch-free ----
