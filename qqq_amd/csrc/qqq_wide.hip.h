@@ -23,14 +23,14 @@
 //     k % 4) + its share of everything else -- the NEXT step's weights (HBM -> VGPR ring, RS steps ahead) are transposed
 //     (4 x 4 quad transpose as four 3-instruction pieces) and unpacked into a second operand set over the whole step, every
 //     activation fragment is re-read from LDS for the next step right behind its fourth MFMA, and the activations are staged
-//     global -> VGPR -> LDS one 16-byte chunk per thread every 16 slots (ds_write of stage i + 2, four slots later the reload
-//     of the same register for stage i + 3).  Everything is spread EVENLY: the four waves of a workgroup run in lock step
-//     (one barrier per stage), so anything issued in a burst hits the LDS store path / the vector-memory issue four times
-//     at once (the first version staged in a burst and ran 7-9 % slower, profiles/r03_wide_uniform_schedule.txt).
-// MT = 16: 256-token tiles; MT = 8: 128-token tiles (128 accumulators; on a par with the panel kernel's 64-column shape).
+//     by LDS-DMA, one 16-byte chunk per lane every 16 slots (see "LDS-DMA staging" below; at first global -> VGPR -> ds_write).
+//     Everything is spread EVENLY: the four waves of a workgroup run in lock step (one barrier per stage), so anything issued
+//     in a burst hits the LDS / the vector-memory issue four times at once (the first version staged in a burst and ran 7-9 %
+//     slower, profiles/r03_wide_uniform_schedule.txt).
+// MT = 16: 256-token tiles; MT = 8: 128-token tiles (128 accumulators); HW = 1: 128-column tiles, a wave owns 32 columns.
 //
-// grid = tiles_m * tiles_n (XCD-aware order as in the tiled kernel), block = 256.  No split-K: the host picks this shape
-// only when the tiles fill about a round of the chip.  K % 128 == 0 (the host sends other K to the panel kernel).
+// grid = tiles_m * tiles_n * ksplit (XCD-aware order as in the tiled kernel), block = 256.  The host picks the shape that
+// fills about a round of the chip (and at most two K slices).  K % 128 == 0 (the host sends other K to the panel kernel).
 // Addresses: wave-uniform buffer descriptors + 32-bit lane offsets + scalar step offsets (buffer_load ... v_off, s[rsrc],
 // s_off): no 64-bit per-lane address arithmetic on the issue port the MFMAs share.
 // ------------------------------------------------------------------------------------------
@@ -84,16 +84,13 @@ __host__ __device__ constexpr int wide_item_slots_before(int hw, int k) {  // nu
   return n;
 }
 
-// LDS-DMA staging (QQQ_WIDE_DMA, default): the activations go global -> LDS directly (buffer_load_dwordx4 ... lds, one
+// LDS-DMA staging: the activations go global -> LDS directly (buffer_load_dwordx4 ... lds, one
 // 16-byte chunk per lane and instruction, lane-linear destination M0 + 16 * lane; the row swizzle is applied on the SOURCE
 // side).  The second ablation (profiles/r03_wide_ablation2.txt) put 10 % of the loop on the staging's reload + ds_write pair
 // -- their issue cost, not their latency.  An LDS-DMA is invisible to hipcc's wait-count bookkeeping, and its counted waits
 // for the VISIBLE loads would then over-wait (vmcnt counts every load in flight), so EVERY vector-memory load of the loop is
 // inline asm and the waits are placed by hand from the static schedule below: loads complete in issue order, so "the load I
 // need is done" == "at most <number of loads issued after it> are outstanding".
-#ifndef QQQ_WIDE_DMA
-#define QQQ_WIDE_DMA 1
-#endif
 // Vector-memory loads slot k of a step (parity t = second step of its stage) issues, in the order the slot issues them.
 __host__ __device__ constexpr int wide_loads_in_slot(bool grouped, int mt, int hw, int t, int k) {
   int n = 0;
@@ -189,7 +186,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
   // ---- per-lane sources ----
   const int h = lane >> 4, cq = (lane >> 2) & 3, q4 = lane & 3;  // q4: kq as a load lane, jt as an MFMA lane
-  // Every vector-memory load from here to the end of the main loop is inline asm (see QQQ_WIDE_DMA above): descriptors as plain
+  // Every vector-memory load from here to the end of the main loop is inline asm (see "LDS-DMA staging" above): descriptors as plain
   // SGPR quads (base, stride 0, no bound, raw-buffer flags), 32-bit lane offset, scalar step / stage offset.
   auto descriptor = [](const void* base_uniform) {
     const unsigned long long a = (unsigned long long)base_uniform;  // (readfirstlane: an "s" operand must not reach the asm in VGPRs)
