@@ -155,3 +155,26 @@ def test_wide_kernel_hand_counted_waits_replayed_on_the_compiled_code():
                 per_step = per_step + second
                 assert at_barrier == [per_step] * 4, (name, at_barrier)
 
+
+def test_check_waits_flags_planted_faults():
+    """The wait replay must catch what it exists for.  A toy loop in compiler syntax: a register load consumed three instructions
+    later behind `vmcnt(1)` with one younger load in flight is fine; a count one too large (`vmcnt(2)`) is flagged, and so is
+    a value written into the destination of a load still in flight (the dead-load register reuse of the first LDS-DMA build)."""
+    import check_waits
+
+    def loop(wait, younger):
+        body = [".LBB0_1:", "\tbuffer_load_dwordx4 v[10:13], v1, s[4:7], s8 offen"]
+        body += ["\tbuffer_load_dwordx4 v2, s[4:7], s9 offen lds"] * younger
+        body += ["\tv_mfma_i32_16x16x64_i8 a[0:3], v[20:23], v[24:27], a[0:3]", f"\ts_waitcnt vmcnt({wait})",
+                 "\tv_and_b32_e32 v30, 0xf0f0f0f0, v10", "\ts_waitcnt vmcnt(0)", "\ts_cbranch_scc1 .LBB0_1"]
+        return body
+
+    assert check_waits.check(check_waits.loop_body(loop(1, 1)))[0] == []
+    assert check_waits.check(check_waits.loop_body(loop(2, 2)))[0] == []
+    bad = check_waits.check(check_waits.loop_body(loop(2, 1)))[0]
+    assert bad and all("v_and_b32" in x for x in bad), bad
+    reuse = [".LBB0_1:", "\tbuffer_load_dwordx4 v[10:13], v1, s[4:7], s8 offen", "\tv_mfma_i32_16x16x64_i8 a[0:3], v[20:23], v[24:27], a[0:3]",
+             "\tv_mov_b32_e32 v12, 0", "\ts_waitcnt vmcnt(0)", "\ts_cbranch_scc1 .LBB0_1"]
+    bad = check_waits.check(check_waits.loop_body(reuse))[0]
+    assert bad and "v_mov_b32" in bad[0], bad
+
