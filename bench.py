@@ -9,8 +9,9 @@ per-channel W4A8, M in {1,16,128,1024,4096}, N=8192, K=21760, on synthetic int8 
 range, produced by the fused dynamic_quant of N(0,1) fp16 tokens) and random int4 weights, all resident
 in HBM before the timed region.  Consecutive calls use DIFFERENT 89 MB weight buffers (5 of them, 445 MB
 > the 256 MiB Infinity Cache) so that "HBM GB/s" is not an L3 number.  `value` = sum(2*M*N*K) / time.
-The timed region replays hipGraphs that hold several consecutive steps each (--steps-per-graph, default 10, plus one shorter
-graph for the remainder; exactly K steps run): the idle gap at a replay boundary is launch plumbing, not GEMM.
+The timed region replays hipGraphs: a one-step graph opens it (the GPU idles behind the barrier until the host has launched the
+first graph, and a short one launches fastest), the rest hold several consecutive steps each (--steps-per-graph, default 10,
+plus one shorter graph for the remainder; exactly K steps run): the idle gap at a replay boundary is launch plumbing, not GEMM.
 
 N > 1 (BASELINE configs[4]): same sweep, rows of every point with M >= 64*N sharded over the ranks
 (weights replicated), output shards all-gathered over RCCL/xGMI, chunk-pipelined against the GEMM
@@ -425,8 +426,12 @@ def main():
                     gg.replay()
                     torch.cuda.synchronize()
                     return gg
-                graph_n = capture(spg)
-                graph_r = capture(args.steps % spg) if args.steps % spg else None
+                # The timed region opens with the single-step graph `g`: the GPU is idle behind the barrier, and what it waits for
+                # is the host's launch of the first graph -- a few hundred us for 10 steps' nodes, tens for one step's.  The
+                # larger graphs behind it are launched while the GPU works.  (With K = 20 the 10-step opener cost 3.5 % of `value`.)
+                rest = args.steps - 1
+                graph_n = capture(spg) if rest >= spg else None
+                graph_r = capture(rest % spg) if rest % spg else None
             else:
                 spg = 1
         except Exception as e:  # pragma: no cover
@@ -449,11 +454,12 @@ def main():
         run_step()
     barrier()
     t0 = time.perf_counter()
-    if graph_n is not None:
-        for _ in range(args.steps // spg):  # EXACTLY args.steps steps: spg steps per replay ...
-            graph_n.replay()
-        if graph_r is not None:             # ... and the remainder in one more graph
+    if graph is not None and spg > 1:
+        graph.replay()                              # EXACTLY args.steps steps: one step in the opening graph ...
+        if graph_r is not None:                     # ... the remainder of (K - 1) % spg next (short: launched under the opener) ...
             graph_r.replay()
+        for _ in range((args.steps - 1) // spg):    # ... and spg steps per replay for the rest
+            graph_n.replay()
     else:
         for _ in range(args.steps):
             run_step()
@@ -531,7 +537,7 @@ def main():
                        + ("W ~ N(0, 0.02^2) quantised GPTQ-style (SURVEY 8d)" if os.environ.get("QQQ_BENCH_WEIGHTS", "gptq") != "uniform"
                           else "uniformly random int4 codes"),
             "tokens": "x ~ N(0,1) fp16 through the fused dynamic int8 quantiser",
-            "launch": (f"hipGraph replay, {spg} step(s) per graph in the timed region (each sweep point bound to one of the rotating "
+            "launch": (f"hipGraph replay: a one-step graph opens the timed region, then {spg} step(s) per graph (each sweep point bound to one of the rotating "
                        "weight buffers: a buffer is re-read only after the other four, 356 MB, have passed through the 256 MiB "
                        "Infinity Cache)") if graph is not None else "eager",
             "parallelism": "single GPU" if world == 1 else f"M-sharded over {world} GPUs + RCCL all-gather of fp16 shards (points with M >= {64*world})",
