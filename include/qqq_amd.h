@@ -60,16 +60,17 @@ typedef struct qqq_tune {
                   3 = "column" (decode: 32 columns x all of K per workgroup, no split-K),
                   4 = "panel" (m-blocks of up to 128 tokens: all tokens of an m-block x bm columns x a K slice per
                       workgroup, weights straight to VGPRs, activations shared through LDS, in-launch split-K),
-                  5 = "wide" (256 -- mt = 8: 128 -- tokens x 256 columns per workgroup, four waves with 512 registers each, 256
-                      int32 accumulators per lane, weights straight to VGPRs, activations through LDS, in-launch split-K
-                      through row-major slots of C: from ~640 tokens up) */
+                  5 = "wide" (256 -- mt = 8: 128 -- tokens x 256 -- bm = 128: 128 -- columns per workgroup, four waves with 512
+                      registers each, up to 256 int32 accumulators per lane, weights straight to VGPRs, activations into LDS by
+                      LDS-DMA, in-launch split-K through row-major slots of C: from ~320 tokens up) */
   int ksplit;  /* 0 auto, else number of K slices (partials go through C)                   */
   int waves;   /* stream: waves per workgroup (4, 8 or 16); panel (bm = 128): 4 or 8 (two k-groups); 0 auto */
   int fused;   /* split-K finish; 0 auto.  stream: 1 = last-arriving workgroup reduces in-launch (tickets in
                   workspace, release fence), 3 = same with write-through slab stores (no release fence),
                   2 = separate reduce launch.  tiled: 1 = in-launch (K slices of a tile meet in tile-sized int32
                   slots of C, tickets in workspace), 2 = ksplit [m,n] slabs in C + separate reduce launch      */
-  int bm;      /* tiled: rows per workgroup tile (64, 128, 256); panel: COLUMNS per workgroup (128, 256); 0 auto */
+  int bm;      /* tiled: rows per workgroup tile (64, 128, 256); panel: COLUMNS per workgroup (128, 256); wide: COLUMNS per
+                  workgroup (256; 128 with mt = 16 only: 32 columns per wave); 0 auto */
   int glds;    /* tiled: 1 = direct global->LDS loads, 2 = register staged; 0 auto          */
   int pf;      /* stream: prefetch depth in 4 KiB steps per wave (3, 5, 7); column: 1 KiB steps per wave
                   (2..12); panel: weight ring depth in 128-k stages (2, 3, 4; 8 for mt <= 4); wide: weight ring depth in
