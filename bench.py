@@ -147,6 +147,17 @@ class Layer:
         return np.array(out[:], dtype=np.float64)
 
 
+def graph_schedule(steps, spg):
+    """Sizes (in steps) of the hipGraphs replayed in the timed region, in order: a one-step opener, the remainder of
+    (steps - 1) % spg, then spg steps per graph; they add up to EXACTLY `steps`."""
+    if steps <= 0:
+        return []
+    if spg <= 1:
+        return [1] * steps
+    rest = steps - 1
+    return [1] + ([rest % spg] if rest % spg else []) + [spg] * (rest // spg)
+
+
 def fp16_gemm_us(dev, M, iters=10, N=N_FULL, K=K_FULL):
     """torch fp16 GEMM (hipBLASLt) on the same GPU, weights rotated over 2 x 356 MB buffers"""
     Ws = [torch.randn((K, N), device=dev, dtype=torch.float16) * 0.02 for _ in range(2)]
@@ -401,7 +412,7 @@ def main():
     step_body()
     torch.cuda.synchronize()
     graph = None
-    graph_n, graph_r, spg = None, None, 1  # graphs holding `spg` (and K % spg) consecutive steps: fewer replay boundaries in the timed region
+    by_size, spg = {}, 1  # graphs holding 1, (K - 1) % spg and spg consecutive steps: fewer replay boundaries in the timed region
     if world == 1:
         try:
             side = torch.cuda.Stream(device=dev)
@@ -426,12 +437,12 @@ def main():
                     gg.replay()
                     torch.cuda.synchronize()
                     return gg
-                # The timed region opens with the single-step graph `g`: the GPU is idle behind the barrier, and what it waits for
-                # is the host's launch of the first graph -- a few hundred us for 10 steps' nodes, tens for one step's.  The
-                # larger graphs behind it are launched while the GPU works.  (With K = 20 the 10-step opener cost 3.5 % of `value`.)
-                rest = args.steps - 1
-                graph_n = capture(spg) if rest >= spg else None
-                graph_r = capture(rest % spg) if rest % spg else None
+                # The timed region opens with the single-step graph `g` (graph_schedule): the GPU is idle behind the barrier until
+                # the first graph has been launched and taken up; the larger graphs behind it are launched while the GPU works.
+                sizes = set(graph_schedule(args.steps, spg))
+                by_size = {1: g}
+                for n in sorted(sizes - {1}):
+                    by_size[n] = capture(n)
             else:
                 spg = 1
         except Exception as e:  # pragma: no cover
@@ -455,11 +466,8 @@ def main():
     barrier()
     t0 = time.perf_counter()
     if graph is not None and spg > 1:
-        graph.replay()                              # EXACTLY args.steps steps: one step in the opening graph ...
-        if graph_r is not None:                     # ... the remainder of (K - 1) % spg next (short: launched under the opener) ...
-            graph_r.replay()
-        for _ in range((args.steps - 1) // spg):    # ... and spg steps per replay for the rest
-            graph_n.replay()
+        for n in graph_schedule(args.steps, spg):   # EXACTLY args.steps steps
+            by_size[n].replay()
     else:
         for _ in range(args.steps):
             run_step()
