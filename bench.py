@@ -197,7 +197,7 @@ def int8_gemm_us(dev, M, iters=10, N=N_FULL, K=K_FULL):
         return None
 
 
-def cpu_baseline(sample_rows=64, budget_s=12.0):
+def cpu_baseline(sample_rows=64, budget_s=12.0, fp16_budget_s=30.0):
     """The C oracle (restatement of the reference arithmetic, `kind: port`) on the host cores, on a bounded
     sample of the same workload: `sample_rows` tokens x the full N x K weight matrix, repeated until
     ~budget_s of CPU work.  Also times torch's fp16 CPU GEMM (north_star's "PyTorch fp16 CPU GEMM")."""
@@ -229,8 +229,18 @@ def cpu_baseline(sample_rows=64, budget_s=12.0):
         torch.set_num_threads(cores)
         W = (torch.randn((N_FULL, K_FULL)) * 0.02).to(torch.float16)
         res = {}
+        t_fp16 = time.perf_counter()
         for M in (1, 16, 128, 1024, 4096):  # the whole sweep (north_star: "in the same run"); one repetition at large m
-            x = torch.randn((M, K_FULL)).to(torch.float16)
+            if M > 128:
+                # bounded: a full-size point is run only if its time, extrapolated from the M=128 rate, fits what is left of the
+                # budget (measured on the 256-thread bench host: 2 s and 15-19 s; an ordinary host would take minutes); otherwise
+                # a row sample of the same GEMM is timed and scaled, and the entry says so
+                est = res["128"]["ms"] * 1e-3 * M / 128.0
+                left = fp16_budget_s - (time.perf_counter() - t_fp16)
+                rows = M if est <= left else max(128, int(M * max(left, 1.0) / est) // 128 * 128)
+            else:
+                rows = M
+            x = torch.randn((rows, K_FULL)).to(torch.float16)
             if M <= 128:
                 torch.matmul(x, W.t())
             ts = []
@@ -238,7 +248,10 @@ def cpu_baseline(sample_rows=64, budget_s=12.0):
                 t1 = time.perf_counter()
                 torch.matmul(x, W.t())
                 ts.append(time.perf_counter() - t1)
-            res[str(M)] = {"ms": float(np.median(ts) * 1e3), "tflops": algorithmic_ops(M, N_FULL, K_FULL) / np.median(ts) / 1e12}
+            ms = float(np.median(ts) * 1e3) * M / rows
+            res[str(M)] = {"ms": ms, "tflops": algorithmic_ops(M, N_FULL, K_FULL) / (ms * 1e-3) / 1e12}
+            if rows != M:
+                res[str(M)]["sampled_rows"] = rows
         out["torch_fp16_cpu_gemm"] = {"threads": torch.get_num_threads(), "per_m": res}
     except Exception as e:  # pragma: no cover
         out["torch_fp16_cpu_gemm"] = {"error": str(e)}
@@ -325,6 +338,38 @@ def live_traffic(timeout_s=240):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def gpu_clocks(dev, busy_fn=None):
+    """SURVEY 8d "print rocminfo clocks": the part's maximum shader clock (rocminfo) and the clock rocm-smi reports while the GPU
+    is busy with `busy_fn` (about a second of M=4096 launches queued ahead of the query) -- under the wide kernel the chip runs
+    well below its 2.4 GHz maximum (power), which is half of what `roofline.frac` is made of."""
+    import re
+    import shutil
+    import subprocess
+
+    out = {"max_mhz": None, "busy_sclk": None}
+    try:
+        exe = shutil.which("rocminfo") or "/opt/rocm/bin/rocminfo"
+        txt = subprocess.run([exe], capture_output=True, text=True, timeout=30).stdout
+        blocks = [b for b in txt.split("*******") if "gfx" in b and "Max Clock Freq" in b]
+        if blocks:
+            out["max_mhz"] = int(re.search(r"Max Clock Freq\. \(MHz\):\s+(\d+)", blocks[0]).group(1))
+    except Exception as e:  # pragma: no cover
+        out["rocminfo_error"] = f"{type(e).__name__}: {e}"
+    try:
+        exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+        if busy_fn is not None:
+            busy_fn()
+        txt = subprocess.run([exe, "--showclocks", "-d", str(dev.index or 0)], capture_output=True, text=True, timeout=30).stdout
+        torch.cuda.synchronize()
+        m = re.search(r"sclk clock level[^\n]*\((\d+)Mhz\)", txt)
+        out["busy_sclk"] = {"mhz": int(m.group(1)) if m else None,
+                            "raw": [ln.strip() for ln in txt.split("\n") if "sclk" in ln or "mclk" in ln][:4],
+                            "note": "rocm-smi --showclocks sampled while ~1 s of M=4096 launches was queued"}
+    except Exception as e:  # pragma: no cover
+        out["rocm_smi_error"] = f"{type(e).__name__}: {e}"
+    return out
+
+
 def cpu_model_name():
     try:
         for line in open("/proc/cpuinfo"):
@@ -346,6 +391,8 @@ def main():
     ap.add_argument("--steps-per-graph", type=int, default=0,
                     help="steps captured per hipGraph of the timed region (0 = 10; a shorter graph takes the remainder of --steps)")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 PMC traffic passes; quote the committed ones")
+    ap.add_argument("--no-llama", action="store_true", help="skip the BASELINE configs[3] block (Llama-2-7B linears)")
+    ap.add_argument("--llama-budget", type=float, default=90.0, help="wall-clock bound of the configs[3] block, seconds")
     ap.add_argument("--check", action="store_true",
                     help="after the timed region verify the gathered outputs of the sharded points against a local full GEMM")
     args = ap.parse_args()
@@ -450,6 +497,32 @@ def main():
             graph = None
             torch.cuda.synchronize()
 
+    # N > 1: the per-rank step (local chunk GEMMs + the collectives on the side stream) is an eager Python loop by default.
+    # QQQ_BENCH_NGRAPH=1 tries to capture it into a hipGraph (RCCL supports stream capture; gloo cannot be captured), falls
+    # back to eager on any error and the JSON line says which one ran (`config.launch`, `multi_gpu.launch`).  Opt-in because a
+    # capture that goes wrong inside the collective library can hang instead of raising, and no multi-GPU box was available to
+    # try it on; the eager N = 1 figure (`eager`) is printed so that a 1 -> N curve can compare like with like either way.
+    n_launch = "eager"
+    if world > 1 and os.environ.get("QQQ_BENCH_NGRAPH", "0") == "1" and os.environ.get("QQQ_BENCH_BACKEND", "nccl") == "nccl":
+        try:
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                step_body()
+            g.replay()
+            torch.cuda.synchronize()
+            graph = g
+            n_launch = "hipGraph (one step per graph, collectives captured)"
+        except Exception as e:  # pragma: no cover
+            print(f"[bench] rank {rank}: hipGraph capture of the sharded step failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+        if dist is not None:  # every rank must run the same way
+            ok = torch.tensor([1 if graph is not None else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                graph, n_launch = None, "eager (hipGraph capture failed on at least one rank)"
+
     def run_step():
         if graph is not None:
             graph.replay()
@@ -483,6 +556,19 @@ def main():
             b.record()
         torch.cuda.synchronize()
         step_us = [a.elapsed_time(b) * 1e3 for a, b in evs]
+    eager = None
+    if world == 1 and graph is not None:
+        # the same K steps launched eagerly (Python loop, compiled binding): what an N > 1 run, whose step is eager, should be
+        # compared with -- the graph figure above removes ~5 host calls per step that the N > 1 loop still pays
+        for _ in range(3):
+            step_body()
+        torch.cuda.synchronize()
+        te = time.perf_counter()
+        for _ in range(args.steps):
+            step_body()
+        torch.cuda.synchronize()
+        de = time.perf_counter() - te
+        eager = {"ms_per_step": de / args.steps * 1e3, "steps": args.steps}
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -548,11 +634,21 @@ def main():
             "launch": (f"hipGraph replay: a one-step graph opens the timed region, then {spg} step(s) per graph (each sweep point bound to one of the rotating "
                        "weight buffers: a buffer is re-read only after the other four, 356 MB, have passed through the 256 MiB "
                        "Infinity Cache)") if graph is not None else "eager",
-            "parallelism": "single GPU" if world == 1 else f"M-sharded over {world} GPUs + RCCL all-gather of fp16 shards (points with M >= {64*world})",
+            "parallelism": "single GPU" if world == 1 else f"M-sharded over {world} GPUs + RCCL all-gather of fp16 shards (points with M >= {64*world}); step launch: {n_launch}",
         },
     }
 
-    if multi:
+    if eager is not None:
+        eager["value"] = total_ops / (eager["ms_per_step"] * 1e-3) / 1e12
+        eager["note"] = "N = 1 with the step launched eagerly instead of replayed from a hipGraph: the like-for-like base of an N > 1 point"
+        result["eager"] = eager
+    if multi is not None:
+        # proof that the collective backend really spanned `world` ranks: an all_reduce of ones
+        seen = torch.ones(1, dtype=torch.int32, device=dev)
+        dist.all_reduce(seen)
+        multi["world_seen"] = int(seen.item())
+        multi["backend"] = dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")
+        multi["launch"] = n_launch
         result["multi_gpu"] = multi
     if step_us:
         result["step_us"] = {"min": float(np.min(step_us)), "median": float(np.median(step_us)), "max": float(np.max(step_us)),
@@ -614,13 +710,14 @@ def main():
             "algorithmic_bytes": algorithmic_bytes(4096, N_FULL, K_FULL), "avg_launch_us": a["us_median"],
             "frac_of_ubench_ceiling": a["tops"] / 4404.0,
             "sustained_on_random_int8": sus,
-            "frac_of_sustained_mfma_only": (a["tops"] / sus["mfma_only_tops"]) if "mfma_only_tops" in sus else None,
+            # (the kernel issues v_mfma_i32_16x16x64_i8: the only probe rung that is a ceiling FOR IT is the register-only loop of that
+            # instruction; the 32x32x32 rungs -- the round-1 tiled kernel's shapes -- are context, not ceilings, and carry no fraction)
             "frac_of_sustained_mfma_16x16x64_only": (a["tops"] / sus["mfma_16x16x64_only_tops"]) if "mfma_16x16x64_only_tops" in sus else None,
-            "frac_of_sustained_kstep_shape": (a["tops"] / sus["mfma_lds_unpack_tops"]) if "mfma_lds_unpack_tops" in sus else None,
             "note": "peak = 256 CU x 2.4 GHz x 8192 int8 op/clk; 4404 TOPS is the v_mfma_i32_32x32x32_i8 micro-benchmark ceiling; "
-                    "under the M=4096 kernels the chip clocks ~1.9 GHz (power), profiles/r02_pmc_*_m4096.txt; "
-                    "sustained_on_random_int8 = this part's matrix pipe measured in this run on random operands, MFMAs only and "
-                    "with the k-step's LDS reads + int4 unpack (profiles/r02_mfma_power_ceiling.txt)",
+                    "under the M=4096 kernel the chip clocks ~2.06 GHz (power; `clocks`, profiles/r03_pmc_wide_m4096.txt); "
+                    "sustained_on_random_int8 = this part's matrix pipe measured in this run on random operands: register-only loops of "
+                    "32x32x32 / 16x16x64 MFMAs, and the round-1 tiled kernel's k-step (32x32x32 + LDS reads + int4 unpack) for context "
+                    "(profiles/r02_mfma_power_ceiling.txt)",
         }
         h = per_m["1"]
         result["roofline_hbm"] = {
@@ -646,13 +743,37 @@ def main():
                 lg.time_calls(A, s1, Dfull[M], 3)
                 cold = lg.time_calls(A, s1, Dfull[M], it, rotate=True) * 1e3
                 us = float(np.mean(cold[cold <= 3.0 * np.median(cold)]))
-                pg[str(M)] = {"us": us, "tops": algorithmic_ops(M, N_FULL, K_FULL) / us / 1e6,
-                              "gbs": algorithmic_bytes(M, N_FULL, K_FULL, True) / us / 1e3}
+                hbm_us = algorithmic_bytes(M, N_FULL, K_FULL, True) / PEAK_HBM_GBS / 1e3
+                mfma_us = algorithmic_ops(M, N_FULL, K_FULL) / PEAK_MFMA_TOPS / 1e6
+                pln = _L.plan(M, N_FULL, K_FULL, 128, MAX_PAR)
+                pg[str(M)] = {"us": us, "us_median": float(np.median(cold)), "tops": algorithmic_ops(M, N_FULL, K_FULL) / us / 1e6,
+                              "gbs": algorithmic_bytes(M, N_FULL, K_FULL, True) / us / 1e3,
+                              "kernel": {1: "stream", 2: "tiled", 3: "column", 4: "panel", 5: "wide"}[pln["kernel"]], "ksplit": pln["ksplit"],
+                              "roof": "hbm" if hbm_us >= mfma_us else "mfma", "roof_frac": max(hbm_us, mfma_us) / us,
+                              "roof_frac_median": max(hbm_us, mfma_us) / float(np.median(cold))}
                 if "fp16_gemm_us" in per_m[str(M)]:
                     pg[str(M)]["speedup_vs_fp16"] = per_m[str(M)]["fp16_gemm_us"] / us
             result["per_m_g128"] = pg
         except Exception as e:  # pragma: no cover
             result["per_m_g128"] = {"error": str(e)}
+        # the clocks behind `roofline.frac`: rocminfo's maximum, and rocm-smi's reading with ~1 s of M=4096 launches queued
+        try:
+            A4, s14 = toks[4096]
+            result["clocks"] = gpu_clocks(dev, busy_fn=lambda: [ops.qqq_gemm(A4, lg.Bs[i % NBUF], lg.C, Dfull[4096], s14, lg.s2, lg.s3, lg.ws, -1, -1, -1, MAX_PAR) for i in range(1800)])
+        except Exception as e:  # pragma: no cover
+            result["clocks"] = {"error": f"{type(e).__name__}: {e}"}
+        # BASELINE configs[3]: the seven Llama-2-7B linears at batch 1 / 8 / 32 x seq 1024, both modes (tools/bench_llama.py: ONE
+        # implementation for this block and for the stand-alone tool), bounded in wall-clock time
+        if not args.no_llama:
+            try:
+                del lg
+                torch.cuda.empty_cache()
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import bench_llama
+
+                result["llama7b"] = bench_llama.llama_matrix(dev, budget_s=args.llama_budget)
+            except Exception as e:  # pragma: no cover
+                result["llama7b"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_cpu:
             result["cpu_baseline"] = cpu_baseline()
             result["cpu_baseline"]["cpu_model"] = cpu_model_name()

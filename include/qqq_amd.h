@@ -71,7 +71,11 @@ typedef struct qqq_tune {
                   slots of C, tickets in workspace), 2 = ksplit [m,n] slabs in C + separate reduce launch      */
   int bm;      /* tiled: rows per workgroup tile (64, 128, 256); panel: COLUMNS per workgroup (128, 256); wide: COLUMNS per
                   workgroup (256; 128 with mt = 16 only: 32 columns per wave); 0 auto */
-  int glds;    /* tiled: 1 = direct global->LDS loads, 2 = register staged; 0 auto          */
+  int glds;    /* tiled: 1 = direct global->LDS loads, 2 = register staged; 0 auto.
+                  wide: 2 = persistent tile walk wherever it applies (one workgroup per CU walks its run of tiles, the next
+                  tile's first stages are fetched under the current tile's last ones, LDS-free flush at the seam; needs
+                  ksplit = 1, K >= 1024 and at least one tile per CU), 1 = one tile per workgroup, 0 = automatic
+                  (the walk for K <= 6144 when there is more than one 256 x 256 tile per CU)                      */
   int pf;      /* stream: prefetch depth in 4 KiB steps per wave (3, 5, 7); column: 1 KiB steps per wave
                   (2..12); panel: weight ring depth in 128-k stages (2, 3, 4; 8 for mt <= 4); wide: weight ring depth in
                   64-k steps (4, 8); 0 auto                                                                  */

@@ -337,14 +337,34 @@ static hipError_t launch_tiled(const LaunchArgs& a, bool grouped, int bm, int st
                  : launch_tiled_bm<false>(a, bm, stages, ksplit, nslots, pw);
 }
 
-template <bool GROUPED, int MT, int P, int RS, int HW>
+// compute units of the current device (the persistent tile walk launches one workgroup per CU), cached per device
+static int device_cus() {
+  static int cus[64] = {};
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  if (cur >= 0 && cur < 64 && cus[cur] > 0) return cus[cur];
+  int n = 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, cur) != hipSuccess || n <= 0) n = 256;
+  if (cur >= 0 && cur < 64) cus[cur] = n;
+  return n;
+}
+
+// the persistent tile walk needs whole tiles (no K split), a K range longer than its prefetch leads and at least one tile per
+// workgroup of its grid (a multiple of 8: workgroup b lands on XCD b % 8)
+static bool wide_chain_ok(int M, int N, int K, int rows, int bn, int ksplit) {
+  const long long tl = (long long)((M + rows - 1) / rows) * ((N + bn - 1) / bn);
+  return ksplit == 1 && K / 128 >= 8 && tl >= (long long)(device_cus() & ~7) && (device_cus() & ~7) >= 8;
+}
+
+template <bool GROUPED, int MT, int P, int RS, int HW, bool CHAIN = false>
 static hipError_t launch_wide_t(const LaunchArgs& a, int pw, int ksplit) {
   constexpr int ROWS = 16 * MT, BN = 128 * HW;
   constexpr int XBUF = P * ROWS * 128, EP = (HW == 2 ? 8 * MT : 16 * MT) * (BN + 4) * 4 + 16;  // + the ticket exchange word
-  constexpr int LDS = XBUF > EP ? XBUF : EP;
+  constexpr int CH = XBUF + 2 * (ROWS * 4 + BN * 6);  // CHAIN: stage buffers + two scale regions, no epilogue image
+  constexpr int LDS = CHAIN ? CH : (XBUF > EP ? XBUF : EP);
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static bool attr_set[64] = {};  // per instantiation, per device
-  auto kern = qqq_wide_kernel<GROUPED, MT, P, RS, HW>;
+  auto kern = qqq_wide_kernel<GROUPED, MT, P, RS, HW, CHAIN>;
   int cur = 0;
   (void)hipGetDevice(&cur);
   if (cur < 0 || cur >= 64 || !attr_set[cur]) {
@@ -353,7 +373,8 @@ static hipError_t launch_wide_t(const LaunchArgs& a, int pw, int ksplit) {
     if (cur >= 0 && cur < 64) attr_set[cur] = true;
   }
   const int tiles_m = (a.M + ROWS - 1) / ROWS, tiles_n = (a.N + BN - 1) / BN;
-  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n * ksplit), dim3(256), LDS, a.stream, a.A, a.B, a.C, a.D, a.s1, a.s2, a.s3,
+  const int grid = CHAIN ? (device_cus() & ~7) : tiles_m * tiles_n * ksplit;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, a.stream, a.A, a.B, a.C, a.D, a.s1, a.s2, a.s3,
                      a.acc_out, a.tickets, a.bias, a.M, a.N, a.K, tiles_m, tiles_n, pw, ksplit);
   return hipGetLastError();
 }
@@ -364,7 +385,22 @@ template <bool GROUPED, int MT>
 static hipError_t launch_wide_m(const LaunchArgs& a, int pf, int pw, int ksplit) {
   return pf == 4 ? launch_wide_t<GROUPED, MT, 4, 4, 2>(a, pw, ksplit) : launch_wide_t<GROUPED, MT, 4, 8, 2>(a, pw, ksplit);
 }
-static hipError_t launch_wide(const LaunchArgs& a, bool grouped, int mt, int bn, int pf, int pw, int ksplit) {
+// the persistent tile walk: the ring depth each mode runs by default (per-channel 4 steps, per-group 8)
+static hipError_t launch_wide_chain(const LaunchArgs& a, bool grouped, int mt, int bn, int pw) {
+  if (bn == 128) return grouped ? launch_wide_t<true, 16, 4, 8, 1, true>(a, pw, 1) : launch_wide_t<false, 16, 4, 4, 1, true>(a, pw, 1);
+  if (mt == 8) return grouped ? launch_wide_t<true, 8, 4, 8, 2, true>(a, pw, 1) : launch_wide_t<false, 8, 4, 4, 2, true>(a, pw, 1);
+  return grouped ? launch_wide_t<true, 16, 4, 8, 2, true>(a, pw, 1) : launch_wide_t<false, 16, 4, 4, 2, true>(a, pw, 1);
+}
+// Automatic choice (profiles/r04_tile_walk_sweep.txt: plain vs walk over nine layer shapes x five token counts x both modes).
+// A seam costs 5.5 us (per-group 7) where the plain grid pays 9 us between two tiles of a CU (epilogue 6.3 + relaunch 0.2 +
+// prologue 2.6), and the walk's stage loop pays ~2-3 % for its per-stage bookkeeping: it wins where tiles are short and every CU
+// gets more than one -- K <= 6144 (4096 / 5120-deep layers: +4 ... +8 % from two tiles per CU on), is neutral around K = 8192
+// and loses 2-6 % at K = 21760.  256 x 256 tiles only: the 128-column shape loses with it, the 128-token shape gains less.
+static bool wide_chain_pays(long long tiles, int K, int mt, int bn) {
+  return mt == 16 && bn == 256 && K / 128 <= 48 && tiles > (long long)(device_cus() & ~7);
+}
+static hipError_t launch_wide(const LaunchArgs& a, bool grouped, int mt, int bn, int pf, int pw, int ksplit, bool chain = false) {
+  if (chain) return launch_wide_chain(a, grouped, mt, bn, pw);
   if (bn == 128) {
     if (grouped) return pf == 4 ? launch_wide_t<true, 16, 4, 4, 1>(a, pw, ksplit) : launch_wide_t<true, 16, 4, 8, 1>(a, pw, ksplit);
     return pf == 4 ? launch_wide_t<false, 16, 4, 4, 1>(a, pw, ksplit) : launch_wide_t<false, 16, 4, 8, 1>(a, pw, ksplit);
@@ -544,6 +580,7 @@ struct Plan {
   int fused;   // stream: 1 / 3 in-launch, 2 separate reduce.  tiled: 1 in-launch slots, 2 slabs + reduce
   int mt, waves, pf;      // stream
   int bm, stages, nslots, pw; // tiled
+  int chain;                  // wide: 1 = persistent tile walk (one workgroup per CU walks its run of tiles)
 };
 
 static Plan make_plan(const int M, const int N, const int K, const bool grouped, const int max_par,
@@ -622,6 +659,9 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
     while (ksplit > 1 && tl * rows * pl.bm * (ksplit - 1) > cap_rows * (long long)N) --ksplit;
     pl.ksplit = ksplit;
     pl.fused = 1;
+    // the persistent tile walk (t.glds: 1 = never, 2 = whenever it applies, 0 = automatic); its ring depth is the mode's default
+    pl.chain = (t.glds != 1 && wide_chain_ok(M, N, K, rows, pl.bm, ksplit) && (t.glds == 2 || wide_chain_pays(tl, K, pl.mt, pl.bm))) ? 1 : 0;
+    if (pl.chain) pl.pf = grouped ? 8 : 4;
     return pl;
   }
 
@@ -786,7 +826,7 @@ extern "C" int qqq_w4a8_plan(int prob_m, int prob_n, int prob_k, int groupsize, 
   plan_out->mt = pl.mt;
   plan_out->bm = pl.bm;
   plan_out->stages = pl.stages;
-  plan_out->glds = pl.kernel == 2 ? (pl.stages == 0 ? 2 : 1) : 0;
+  plan_out->glds = pl.kernel == 2 ? (pl.stages == 0 ? 2 : 1) : pl.kernel == 5 ? (pl.chain ? 2 : 1) : 0;
   plan_out->nslots = pl.nslots;
   plan_out->pw = pl.pw;
   return QQQ_OK;
@@ -844,7 +884,7 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
     return QQQ_ERR_ARG;
   }
   if (pl.kernel == 5) {
-    e = launch_wide(a, grouped, pl.mt, pl.bm, pl.pf, pl.pw, pl.ksplit);
+    e = launch_wide(a, grouped, pl.mt, pl.bm, pl.pf, pl.pw, pl.ksplit, pl.chain != 0);
     if (e != hipSuccess) return fail_hip(e, "qqq_wide_kernel launch");
     reduce_launch = false;
   } else if (pl.kernel == 4) {

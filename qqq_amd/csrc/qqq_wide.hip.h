@@ -41,6 +41,19 @@
 #ifndef QQQ_WIDE_ABLATE
 #define QQQ_WIDE_ABLATE 0
 #endif
+// Phase clocks of the measurement build (-DQQQ_PANEL_TRACE, see qqq_panel.hip.h), written by WAVE 0 of the workgroup -- all 64
+// lanes store the same word: a lane-0 guard is a divergent branch, and behind one hipcc no longer treats the tile walk's
+// scalars as scalars (an "s" asm operand then fails to compile).  `wn` is the wave index (wave-uniform).
+#ifdef QQQ_PANEL_TRACE
+#define QQQ_WTRV(i, v)                                                                                   \
+  do {                                                                                                   \
+    if (wn == 0 && qqq_trace_buf) qqq_trace_buf[(size_t)blockIdx.x * 16 + (i)] = (unsigned long long)(v); \
+  } while (0)
+#define QQQ_WTR(i) QQQ_WTRV(i, wall_clock64())
+#else
+#define QQQ_WTR(i) do {} while (0)
+#define QQQ_WTRV(i, v) do {} while (0)
+#endif
 // f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>), in order: compile-time indices for hand-placed code
 template <int... S, class F>
 __device__ __forceinline__ void qqq_static_for(std::integer_sequence<int, S...>, F&& f) {
@@ -116,7 +129,17 @@ __host__ __device__ constexpr int wide_last_dma_slot(int mt, int hw) {
   return last;
 }
 
-template <bool GROUPED, int MT, int P, int RS, int HW>
+// CHAIN (round 4): the persistent tile walk.  grid = one workgroup per CU; a workgroup walks ITS run of tiles (the positions
+// the one-tile-per-workgroup grid would have given this CU round after round, same XCD-aware order) without ever draining its
+// pipeline: the loads that the plain kernel redirects past the end of K (LDS-DMA LA stages ahead, weight ring RS steps ahead,
+// group scales P stages ahead) fetch the NEXT tile's first stages instead, so at the tile seam the next tile's operands are
+// already in LDS / in the ring, its first step is already unpacked, and the only thing between the last MFMA of a tile and the
+// first MFMA of the next is the flush of the accumulators: an LDS-free epilogue (register-index <-> lane-row transposition with
+// the gfx950 row swaps, straight from the registers to D) -- the stage buffers stay untouched.  The flat stage sequence keeps
+// rotating through the P LDS buffers / RS ring slots across seams (a tile need not be a multiple of P stages), so the seam
+// exists once per stage position of the unrolled trip.  The counterpart of the reference's stripe walk
+// (csrc/qqq_gemm.cu:261-338, :729-760, :792-812), without partial tiles: ksplit == 1 only.
+template <bool GROUPED, int MT, int P, int RS, int HW, bool CHAIN = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void qqq_wide_kernel(
     const int8_t* __restrict__ A, const unsigned char* __restrict__ B, int32_t* __restrict__ C, _Float16* __restrict__ D,
     const float* __restrict__ s1, const float* __restrict__ s2, const _Float16* __restrict__ s3,
@@ -146,29 +169,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);  // 64-column group of the strip
-  QQQ_TR(0);  // (measurement builds only, -DQQQ_PANEL_TRACE: see qqq_panel.hip.h; grid is 1-D here)
+  QQQ_WTR(0);  // (measurement builds only, -DQQQ_PANEL_TRACE)
 
   // ---- XCD-aware tile order (speed only): block b runs on XCD b % 8; an XCD walks panels of PW strips x all m-tiles ----
   int tile_m, tile_n, tile_lin, sp;  // tile coordinates, tile index, K slice
+  auto locate = [&](const int lin, int& tm, int& tn) {
+    const int full = (tiles_n / PW) * PW * tiles_m;
+    if (lin < full) {
+      const int panel = lin / (PW * tiles_m), within = lin % (PW * tiles_m);
+      tm = within / PW;
+      tn = panel * PW + within % PW;
+    } else {
+      const int rem = lin - full, pw = tiles_n % PW;
+      tm = rem / pw;
+      tn = (tiles_n / PW) * PW + rem % pw;
+    }
+  };
+  int ch_first = 0, ch_stride = 0, ch_tiles = 1;  // CHAIN: position of this workgroup's first tile in the XCD-ordered run, step, count
   {
     // (with a K split the slices of a tile take consecutive positions of the XCD's run: resident together, on one XCD)
-    const int ntot = tiles_m * tiles_n * ksplit;
+    const int ntot = tiles_m * tiles_n * (CHAIN ? 1 : ksplit);
     const int bid = blockIdx.x;
     const int q = ntot >> 3, rr = ntot & 7;
     const int xcd = bid & 7, idx = bid >> 3;
     const int lin2 = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
-    const int lin = lin2 / ksplit;
-    sp = lin2 - lin * ksplit;
-    tile_lin = lin;
-    const int full = (tiles_n / PW) * PW * tiles_m;
-    if (lin < full) {
-      const int panel = lin / (PW * tiles_m), within = lin % (PW * tiles_m);
-      tile_m = within / PW;
-      tile_n = panel * PW + within % PW;
+    if constexpr (CHAIN) {
+      // the XCD's run has cnt positions; this workgroup takes idx, idx + stride, ... (what the CU would have been handed round
+      // after round by the one-tile-per-workgroup grid).  The host launches a multiple of 8 workgroups, at most as many as tiles.
+      const int cnt = q + (xcd < rr ? 1 : 0);
+      ch_stride = (int)(gridDim.x >> 3);
+      ch_first = lin2;
+      ch_tiles = idx < cnt ? (cnt - idx + ch_stride - 1) / ch_stride : 0;
+      if (ch_tiles == 0) return;
+      sp = 0;
+      tile_lin = lin2;
+      locate(lin2, tile_m, tile_n);
     } else {
-      const int rem = lin - full, pw = tiles_n % PW;
-      tile_m = rem / pw;
-      tile_n = (tiles_n / PW) * PW + rem % pw;
+      const int lin = lin2 / ksplit;
+      sp = lin2 - lin * ksplit;
+      tile_lin = lin;
+      locate(lin, tile_m, tile_n);
     }
   }
   const int mbase = tile_m * ROWS;
@@ -193,23 +233,69 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     return (v4u){(unsigned)__builtin_amdgcn_readfirstlane((int)a), (unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)), 0xffffffffu,
                  0x00020000u};
   };
-  const v4u wdesc = descriptor(B + (size_t)ng * 512);
+  // (CHAIN: one descriptor over the whole tensor, the tile's column group goes into the scalar offset -- ng * 512 / ng * 128 bytes)
+  const v4u wdesc = descriptor(CHAIN ? (const void*)B : (const void*)(B + (size_t)ng * 512));
   const unsigned woff = (unsigned)h * rowbytes + (unsigned)(cq * 64 + q4 * 16 + 256 * whalf);   // + step * 4 * rowbytes (scalar) + 256 * hf
-  const v4u sdesc = descriptor(GROUPED ? (const void*)(s3 + (size_t)ng * 64) : (const void*)B);
+  const v4u sdesc = descriptor(GROUPED ? (CHAIN ? (const void*)s3 : (const void*)(s3 + (size_t)ng * 64)) : (const void*)B);
   const unsigned soff_l = (unsigned)((cq * 8 + 2 * q4) * 2 + 64 * whalf);         // + stage * N * 2 (scalar) + 64 * hf
   // Activation staging by LDS-DMA: instruction q of wave wn fills the 1 KiB [rows 8 wn + 32 q .. + 8) x 128 bytes of the stage
   // image, lane l -> byte 16 l of it = (row l >> 3, slot l & 7).  The image keeps the XOR swizzle of the fragment reads
   // (16-byte piece p of a row sits in slot p ^ ((row >> 1) & 7)), so the lane FETCHES piece slot ^ ((row >> 1) & 7).
-  const v4u xdesc = descriptor(A + (size_t)mbase * K);
+  // (CHAIN: the descriptor follows the LDS-DMA cursor from tile to tile; its size field ends at the tile's last valid row, so
+  // rows past M are out of range for the buffer unit -- whatever lands in their LDS rows is computed on and never stored)
+  v4u xdesc = descriptor(A + (size_t)mbase * K);
   const int xr0 = tid >> 3, xslot = tid & 7;
   unsigned xoff[XPT];
 #pragma unroll
   for (int q = 0; q < XPT; ++q) {
     int row = xr0 + 32 * q;
-    if (mbase + row >= M) row = M - 1 - mbase;  // rows past M: re-read the last row (computed, never stored)
+    if (!CHAIN && mbase + row >= M) row = M - 1 - mbase;  // rows past M: re-read the last row (computed, never stored)
     xoff[q] = (unsigned)row * (unsigned)K + (unsigned)((xslot ^ ((xr0 >> 1) & 7)) * 16);  // (rows 32 apart: same swizzle)
   }
   const unsigned lds_wave = (unsigned)wn * 1024u;  // + buffer * XB + q * 4096: the LDS-DMA's M0
+
+  // ---- CHAIN: what a tile contributes to the three load cursors (all wave-uniform) ----
+  // A-descriptor words of its m-tile, scalar offsets of this wave's column group into B (ng * 512) and s3 (ng * 128 bytes)
+  auto tile_ref = [&](const int tm, const int tn, unsigned& a_lo, unsigned& a_hi, unsigned& a_rec, unsigned& w_so, unsigned& s_so) {
+    const unsigned long long a = (unsigned long long)(A + (size_t)tm * ROWS * (size_t)K);
+    a_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)a);
+    a_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32));
+    const int rows = M - tm * ROWS < ROWS ? M - tm * ROWS : ROWS;
+    a_rec = (unsigned)__builtin_amdgcn_readfirstlane(rows * K);
+    const int cbw = tn * 4 + wn;
+    int g = HW == 2 ? cbw : cbw >> 1;
+    if (g >= ngroups) g = ngroups - 1;
+    // (readfirstlane: these feed the cursors, which must stay scalar -- a cursor kept in a VGPR reaches its load through a
+    // v_readfirstlane one instruction ahead of it, inside the 5 wait states a VALU-written SGPR needs before a vector-memory
+    // instruction may read it; hipcc's hazard bookkeeping does not see through the inline-asm MFMA in between.  Seen as stale
+    // offsets in the first load behind every such copy: column half 0 and the first LDS-DMA chunk of every stage.)
+    w_so = (unsigned)__builtin_amdgcn_readfirstlane(g * 512);
+    s_so = (unsigned)__builtin_amdgcn_readfirstlane(g * 128);
+  };
+  // the tile being computed (its epilogue needs the coordinates) and the one after it (which the loads cross into over the last
+  // P stages of the current one); a workgroup on its last tile crosses into that same tile again: loaded, never used
+  int cur_tm = tile_m, cur_tn = tile_n, nx_tm = tile_m, nx_tn = tile_n, ch_pos = 0;  // ch_pos: index of the current tile in this workgroup's run
+  unsigned cu_a_lo = 0, cu_a_hi = 0, cu_a_rec = 0, cu_w_so = 0, cu_s_so = 0;
+  unsigned nx_a_lo = 0, nx_a_hi = 0, nx_a_rec = 0, nx_w_so = 0, nx_s_so = 0;
+  // Where the loads of a stage read.  With `left` stages of the tile to go (this one included) the LDS-DMA fetches stage
+  // NST - left + LA, the ring refills steps 2 (NST - left) + t + RS, the scale load stage NST - left + P.  While all of them
+  // stay inside the tile (left > P: all but the last P stages) three running offsets advance by constants -- scalar adds, the
+  // only bookkeeping the common stage pays.  In the last P stages the offsets are worked out from `left`, each load going to the
+  // current tile or to the next one; the seam then restarts the running offsets at the new tile's stage 0.
+  unsigned cx_so = 0, cr_so = 0, cc_so = 0;
+  auto sgpr = [](const unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
+  auto cursors_at_stage0 = [&]() {
+    cx_so = (unsigned)LA * 128u;
+    cr_so = sgpr(cu_w_so + (unsigned)RS * 4u * rowbytes);
+    cc_so = sgpr(cu_s_so + (unsigned)P * (unsigned)N * 2u);
+    xdesc[0] = sgpr(cu_a_lo), xdesc[1] = sgpr(cu_a_hi), xdesc[2] = sgpr(cu_a_rec);
+  };
+  if constexpr (CHAIN) {
+    tile_ref(tile_m, tile_n, cu_a_lo, cu_a_hi, cu_a_rec, cu_w_so, cu_s_so);
+    if (ch_tiles > 1) locate(ch_first + ch_stride, nx_tm, nx_tn);
+    tile_ref(nx_tm, nx_tn, nx_a_lo, nx_a_hi, nx_a_rec, nx_w_so, nx_s_so);
+    cursors_at_stage0();
+  }
 
   // stage / step indices past the end are redirected to the last one (loaded, never used): the loop stays branch-free
   // (M0 is reserved: hipcc never allocates it, and nothing else in this kernel uses it.  A write of M0 needs one wait state in
@@ -231,10 +317,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     asm volatile("s_nop 0");
     dma_go(qc, so);
   };
+  auto dma_stage_so = [&](auto bufc, const unsigned so) __attribute__((always_inline)) {
+    qqq_static_for<XPT>([&](auto qc) { dma_x(bufc, qc, so); });
+  };
   auto dma_stage = [&](auto bufc, const int st_rel) __attribute__((always_inline)) {
     const int st = st_rel < NST ? st_rel : NST - 1;
-    const unsigned so = (unsigned)(st0 + st) * 128u;
-    qqq_static_for<XPT>([&](auto qc) { dma_x(bufc, qc, so); });
+    dma_stage_so(bufc, (unsigned)(st0 + st) * 128u);
   };
   auto asm_load_w = [&](v4u& dst, auto hfc, unsigned so) __attribute__((always_inline)) {
     (void)woff, (void)wdesc;
@@ -242,20 +330,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     asm("" : "+s"(so));
     asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=v"(dst) : "v"(woff), "s"(wdesc), "s"(so), "n"(256 * decltype(hfc)::value));
   };
+  auto load_w_so = [&](const unsigned so, v4u (&dst)[HW]) __attribute__((always_inline)) {
+    qqq_static_for<HW>([&](auto hfc) { asm_load_w(dst[decltype(hfc)::value], hfc, so); });
+  };
   auto load_w = [&](const int step_rel, v4u (&dst)[HW]) __attribute__((always_inline)) {
     const int s = step_rel < KS ? step_rel : KS - 1;
-    const unsigned so = (unsigned)(4 * (2 * st0 + s)) * rowbytes;
-    qqq_static_for<HW>([&](auto hfc) { asm_load_w(dst[decltype(hfc)::value], hfc, so); });
+    load_w_so((unsigned)(4 * (2 * st0 + s)) * rowbytes, dst);
   };
   // (the scales of a stage are always fetched as two words -- HW = 1 needs only the first -- so that the load counts of the
   // static schedule do not depend on HW)
-  auto load_sc = [&](const int st_rel, unsigned (&dst)[2]) __attribute__((always_inline)) {  // (raw words: an h2 copy behind the asm would read early)
-    const int st = st_rel < NST ? st_rel : NST - 1;
-    unsigned so = (unsigned)(st0 + st) * (unsigned)N * 2u;
+  auto load_sc_so = [&](unsigned so, unsigned (&dst)[2]) __attribute__((always_inline)) {  // (raw words: an h2 copy behind the asm would read early)
     so = __builtin_amdgcn_readfirstlane(so);
     asm("" : "+s"(so));
     asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(dst[0]) : "v"(soff_l), "s"(sdesc), "s"(so));
     asm volatile("buffer_load_dword %0, %1, %2, %3 offen offset:%4" : "=v"(dst[1]) : "v"(soff_l), "s"(sdesc), "s"(so), "n"(HW == 2 ? 64 : 0));
+  };
+  auto load_sc = [&](const int st_rel, unsigned (&dst)[2]) __attribute__((always_inline)) {
+    const int st = st_rel < NST ? st_rel : NST - 1;
+    load_sc_so((unsigned)(st0 + st) * (unsigned)N * 2u, dst);
   };
 
   v4i acc[MT][NQ];  // [mt][2 * hf + b]
@@ -342,13 +434,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         gha[b] = __builtin_elementwise_fma(gha[b], sb[b], c_mag);
         ghb[b] = __builtin_elementwise_fma(ghb[b], sb[b], c_mag);
       } else {
-        a[2 * hf + b][kq] = (int)(__builtin_amdgcn_perm(__builtin_bit_cast(unsigned, ghb[b]), __builtin_bit_cast(unsigned, gha[b]), 0x06040200u) ^ 0x80808080u);
+        int w = (int)(__builtin_amdgcn_perm(__builtin_bit_cast(unsigned, ghb[b]), __builtin_bit_cast(unsigned, gha[b]), 0x06040200u) ^ 0x80808080u);
+        if constexpr (CHAIN) asm volatile("" : "+v"(w));  // (see below)
+        a[2 * hf + b][kq] = w;
       }
     } else {
+      // (CHAIN: every stage is a basic block of its own -- a seam may follow -- and hipcc sinks an operand word that is only
+      // used by the next stage's MFMAs into that block, in front of its first MFMA: 24 VALU instructions per stage with the
+      // matrix pipe idle.  The empty asm holds each word where its slot put it.)
       constexpr int kq = pi / 3, part = pi % 3;
-      if constexpr (part == 0) a[2 * hf][kq] = (int)(y[kq] & nmask);         // odd nibbles  -> 16*w4 of column n      (b = 0)
-      else if constexpr (part == 1) gt0[0] = y[kq] << 4;
-      else a[2 * hf + 1][kq] = (int)(gt0[0] & nmask);                           // even nibbles -> 16*w4 of column n + 8  (b = 1)
+      if constexpr (part == 0) {
+        int w = (int)(y[kq] & nmask);                                            // odd nibbles  -> 16*w4 of column n      (b = 0)
+        if constexpr (CHAIN) asm volatile("" : "+v"(w));
+        a[2 * hf][kq] = w;
+      } else if constexpr (part == 1) {
+        gt0[0] = y[kq] << 4;
+        if constexpr (CHAIN) asm volatile("" : "+v"(gt0[0]));
+      } else {
+        int w = (int)(gt0[0] & nmask);                                           // even nibbles -> 16*w4 of column n + 8  (b = 1)
+        if constexpr (CHAIN) asm volatile("" : "+v"(w));
+        a[2 * hf + 1][kq] = w;
+      }
     }
   };
   auto mfma = [&](v4i& c, const v4i& wa, const v4i& xb) {
@@ -362,6 +468,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // over the 4 MT slots), re-reads fragment x[mt] for step s + 1 right behind its fourth MFMA, refills ring slot s % RS (read by
   // the unpack that ran during step s - 1) with step s + RS, and issues the LDS-DMA of one 16-byte chunk per lane of activation
   // stage i + LA every 16 slots.  The waits are hand-counted from the static schedule (wide_loads_between).
+  unsigned st_xso = 0, st_swo[2] = {0, 0}, st_sco = 0;  // CHAIN: the scalar offsets of the current stage's loads (do_stage_chain)
   auto step = [&](const int i, auto uc, auto tc) __attribute__((always_inline)) {
     constexpr int t = decltype(tc)::value, u = decltype(uc)::value;
     constexpr int cur = t, nxt = 1 - t;         // 2 P steps per trip: the step's parity is its t
@@ -369,7 +476,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int step_abs = 2 * i + t;
     constexpr int su = GROUPED ? ((t == 1) ? (u + 1) % P : u) : 0;  // scales of the NEXT step's stage
     const int st_x = i + LA < NST ? i + LA : NST - 1;
-    const unsigned xso = (unsigned)(st0 + st_x) * 128u;
+    const unsigned xso = CHAIN ? st_xso : (unsigned)(st0 + st_x) * 128u;  // (CHAIN: i is not used; do_stage_chain says where the loads read)
+    const unsigned cswo = st_swo[t], csco = st_sco;
     constexpr int NI = HW * (4 + UPARTS);
     auto slot = [&](auto kc) __attribute__((always_inline)) {
       constexpr int k = decltype(kc)::value, mt = k / NQ, q = k % NQ;
@@ -391,7 +499,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
               // (vmcnt is a 6-bit counter: a deeper ring than 63 loads waits a little early, never late)
               constexpr int younger_all = wide_loads_between(GROUPED, MT, HW, (t + RS - 1) & 1, 2 + 4 * hf, RS - 1, k);
               constexpr int younger = younger_all < 63 ? younger_all : 63;
-              if constexpr (GROUPED) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(wr[sn][hf]), "+v"(scr[su][hf]) : "n"(younger));
+              // (CHAIN, 32-column waves: the second scale word is fetched -- the load counts do not depend on HW -- and never
+              // used; tied in here it stays allocated until it has landed.  The plain kernel keeps it live by using it behind its loop.)
+              if constexpr (GROUPED && CHAIN && HW == 1) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(wr[sn][hf]), "+v"(scr[su][0]), "+v"(scr[su][1]) : "n"(younger));
+              else if constexpr (GROUPED) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(wr[sn][hf]), "+v"(scr[su][hf]) : "n"(younger));
               else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(wr[sn][hf]) : "n"(younger));
               un_setup(__builtin_bit_cast(h2, scr[su][hf]));
             }
@@ -408,10 +519,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
       if constexpr (wide_frag_slot(HW, k) && !(QQQ_WIDE_ABLATE & 16)) read_x(t == 0 ? (u % P) : ((u + 1) % P), t == 0 ? 1 : 0, mt);
       // (the order of the loads inside a slot is the order wide_loads_in_slot counts them in)
-      if constexpr (GROUPED && t == 1 && k == wide_scale_slot(HW) && !(QQQ_WIDE_ABLATE & 8)) load_sc(i + P, scr[u]);
+      if constexpr (GROUPED && t == 1 && k == wide_scale_slot(HW) && !(QQQ_WIDE_ABLATE & 8)) {
+        if constexpr (CHAIN) load_sc_so(csco, scr[u]);
+        else load_sc(i + P, scr[u]);
+      }
       if constexpr (!(QQQ_WIDE_ABLATE & 8)) {  // ring refill, one 16-byte load per slot
         const int sw = step_abs + RS < KS ? step_abs + RS : KS - 1;
-        const unsigned swo = (unsigned)(4 * (2 * st0 + sw)) * rowbytes;
+        const unsigned swo = CHAIN ? cswo : (unsigned)(4 * (2 * st0 + sw)) * rowbytes;
         if constexpr (wide_refill_slot(HW, k, 0)) asm_load_w(wr[sl][0], std::integral_constant<int, 0>{}, swo);
         if constexpr (wide_refill_slot(HW, k, 1)) asm_load_w(wr[sl][HW - 1], std::integral_constant<int, 1>{}, swo);
       }
@@ -424,6 +538,132 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     qqq_static_for<NSLOT>(slot);
   };
 
+  // ---- CHAIN: the tile seam.  The scales of a tile (token scales of its rows, channel scales and bias of its columns) sit in
+  // one of two small LDS regions behind the stage buffers, written by LDS-DMA one seam earlier (region = parity of the tile's
+  // index in the run: the region being overwritten was last read a whole tile ago, and every stage-end barrier since has
+  // joined the waves), read here with plain ds_reads -- no vector-memory wait in the seam at all.  The flush itself: lane
+  // (token j = lane & 15, c' = lane >> 4) holds, for column set q = (b, hf), register r <-> column 16 r + 8 b + 4 hf + c' of
+  // its wave's 64; two v_permlane16_swap + two v_permlane32_swap per set exchange the register index r with the lane row c',
+  // after which lane row rho holds columns 16 rho + 8 b + 4 hf + {0..3}: 16 consecutive columns of one token per lane
+  // (HW = 1: two groups of four), converted and stored straight from the registers. ----
+  constexpr int SCB = ROWS * 4 + BN * 6;  // bytes of a scale region: float s1[ROWS], float s2[BN] (stored order), fp16 bias[BN]
+  constexpr int SC0 = P * XB;
+  const int cej = lane & 15, cecp = lane >> 4;
+  const int cegrp = HW == 2 ? wn : (wn >> 1), cehalf = wn & 1;
+  auto scale_dma = [&](const int tm, const int tn, const int par) __attribute__((always_inline)) {
+    const unsigned voff = (unsigned)((64 * wn + lane) * 4);
+    const int rows = M - tm * ROWS < ROWS ? M - tm * ROWS : ROWS, cols = N - tn * BN < BN ? N - tn * BN : BN;
+    auto one = [&](const void* base, const unsigned bytes, const unsigned dst) {  // 256 bytes per wave; past `bytes`: out of range
+      v4u d = descriptor(base);
+      d[2] = (unsigned)__builtin_amdgcn_readfirstlane((int)bytes);
+      const unsigned m0v = (unsigned)__builtin_amdgcn_readfirstlane((int)dst);
+      // (s_nop 4: the descriptor may just have come out of a v_readlane -- 5 wait states before a vector-memory instruction reads it)
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tbuffer_load_dword %0, %1, 0 offen lds" : : "v"(voff), "s"(d), "s"(m0v) : "memory");
+    };
+    const unsigned r0 = (unsigned)(SC0 + par * SCB + 256 * wn);
+    if (wn < ROWS / 64) one(s1 + (size_t)tm * ROWS, (unsigned)rows * 4u, r0);
+    if (wn < BN / 64) one(s2 + (size_t)tn * BN, (unsigned)cols * 4u, r0 + ROWS * 4);
+    if (wn < BN / 128 && bias) one(bias + (size_t)tn * BN, (unsigned)cols * 2u, r0 + ROWS * 4 + BN * 4);
+  };
+  auto flush_tile = [&](const int tm, const int tn, const int par) __attribute__((always_inline)) {
+    // (the MFMAs are inline asm: hipcc does not know that the accumulators it is about to read were written by the matrix pipe)
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    const unsigned char* sc = smem + SC0 + par * SCB;
+    const float* s1t = reinterpret_cast<const float*>(sc);
+    const float* s2t = reinterpret_cast<const float*>(sc + ROWS * 4);
+    const _Float16* bt = reinterpret_cast<const _Float16*>(sc + ROWS * 4 + BN * 4);
+    const _Float16 nzc = (_Float16)-0.0f;
+    const int cl = 64 * cegrp + 16 * cecp;                   // this lane's 16 columns inside the strip, once transposed
+    const bool cols_ok = tn * BN + 64 * cegrp < N;           // (N % 64 == 0: a wave's 64 columns are inside N or not at all)
+    float2 dsa[NQ], dsb[NQ];
+    h4 dbv[NQ];
+    int dl[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      dl[q] = cl + 8 * (q & 1) + 4 * (HW == 2 ? (q >> 1) : cehalf);
+      const int i0 = s2_stored_index(dl[q]);                 // (a tile starts on a multiple of 32 columns: the stored order is tile-local)
+      dsa[q] = *reinterpret_cast<const float2*>(s2t + i0);
+      dsb[q] = *reinterpret_cast<const float2*>(s2t + i0 + 8);
+      dbv[q] = (h4){nzc, nzc, nzc, nzc};
+    }
+    if (bias) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) dbv[q] = *reinterpret_cast<const h4*>(bt + dl[q]);
+    }
+    v4i zero4 = {0, 0, 0, 0};
+    asm volatile("" : "+v"(zero4));  // (a VGPR quad of zeros: the operand of the accumulator reset below)
+    // Stores through buffer descriptors that END at the tile's last valid row: a row past M is out of range for the buffer unit
+    // and dropped there -- no per-lane guard, no divergent branch anywhere in the tile walk (behind one, hipcc's structurizer
+    // rebuilds the whole stage loop around exit flags and lane-mask branches: three taken branches per stage, and nothing
+    // hides a fetch bubble when the wave is alone on its SIMD).  The row offset sits in the VECTOR offset, which the range
+    // check certainly covers.
+    const int rows = M - tm * ROWS < ROWS ? M - tm * ROWS : ROWS;
+    const __amdgpu_buffer_rsrc_t dview = __builtin_amdgcn_make_buffer_rsrc(D + (size_t)tm * ROWS * N, 0, rows * N * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t aview = __builtin_amdgcn_make_buffer_rsrc(acc_out ? acc_out + (size_t)tm * ROWS * N : (int32_t*)D, 0, rows * N * 4, 0x00020000);
+    const unsigned drow = (unsigned)(cej * N + tn * BN) * 2u;  // + 16 mt N * 2: this lane's token row, at the strip's first column
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const float ts = s1t[16 * mt + cej];
+      h4 o[NQ];
+      // the 4 x 4 transposition between register index and lane row, two column sets per statement, in place: behind the
+      // accumulator reads two wait states (VALU write -> row swap), every later swap has its two producers' worth of distance.
+      // The accumulators are reset IN PLACE right behind their read: D = 0 x 0 + 0 (the tied operand keeps the register; a
+      // fresh zero value would have to be coalesced with the loop-carried accumulator, and with all 256 accumulation registers
+      // taken a failed coalescing is a spill)
+#pragma unroll
+      for (int q = 0; q < NQ; q += 2) {
+        v4i ra = acc[mt][q], rb = acc[mt][q + 1];
+        asm volatile("" : "+v"(ra), "+v"(rb));  // out of the accumulation registers, now (as whole quads: element by element hipcc moves the accumulators around instead)
+        asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %1, 0" : "+a"(acc[mt][q]) : "v"(zero4));
+        asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %1, 0" : "+a"(acc[mt][q + 1]) : "v"(zero4));
+        int a0 = ra[0], a1 = ra[1], a2 = ra[2], a3 = ra[3], b0 = rb[0], b1 = rb[1], b2 = rb[2], b3 = rb[3];
+        asm volatile("s_nop 1\n\t"
+                     "v_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\t"
+                     "v_permlane16_swap_b32 %4, %5\n\tv_permlane16_swap_b32 %6, %7\n\t"
+                     "v_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\t"
+                     "v_permlane32_swap_b32 %4, %6\n\tv_permlane32_swap_b32 %5, %7"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
+        if (acc_out && cols_ok) {  // (test hook, wave-uniform: the int32 accumulators, 4 consecutive columns per set)
+          const unsigned ar = (drow + (unsigned)(16 * mt) * (unsigned)N * 2u) * 2u;
+          __builtin_amdgcn_raw_buffer_store_b128((v4u){(unsigned)a0, (unsigned)a1, (unsigned)a2, (unsigned)a3}, aview, ar + (unsigned)dl[q] * 4u, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128((v4u){(unsigned)b0, (unsigned)b1, (unsigned)b2, (unsigned)b3}, aview, ar + (unsigned)dl[q + 1] * 4u, 0, 0);
+        }
+        o[q] = epilogue_vals4(a0, a1, a2, a3, ts, dsa[q], dsb[q]) + dbv[q];  // (x + (-0.0) == x for every x)
+        o[q + 1] = epilogue_vals4(b0, b1, b2, b3, ts, dsa[q + 1], dsb[q + 1]) + dbv[q + 1];
+      }
+      if (cols_ok) {  // (wave-uniform)
+        const unsigned dr = drow + (unsigned)(16 * mt) * (unsigned)N * 2u;
+        if constexpr (HW == 2) {  // column sets in column order: q = 0, 2, 1, 3
+          const h8 lo8 = {o[0][0], o[0][1], o[0][2], o[0][3], o[2][0], o[2][1], o[2][2], o[2][3]};
+          const h8 hi8 = {o[1][0], o[1][1], o[1][2], o[1][3], o[3][0], o[3][1], o[3][2], o[3][3]};
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, lo8), dview, dr + (unsigned)cl * 2u, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, hi8), dview, dr + (unsigned)cl * 2u + 16u, 0, 0);
+        } else {
+          typedef unsigned v2u __attribute__((ext_vector_type(2)));
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, o[q]), dview, dr + (unsigned)dl[q] * 2u, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);  // m-tile by m-tile: the seam must not ask for more registers than the loop leaves free
+    }
+  };
+  // flush the finished tile, then move on: the loads are already inside the next tile, whose scales go to the other region
+  auto seam = [&]() __attribute__((always_inline)) {
+    QQQ_WTRV(ch_pos < 7 ? 2 + 2 * ch_pos : 15, wall_clock64());
+    flush_tile(cur_tm, cur_tn, ch_pos & 1);
+    QQQ_WTRV(ch_pos < 7 ? 3 + 2 * ch_pos : 15, wall_clock64());
+    ++ch_pos;
+    cur_tm = nx_tm, cur_tn = nx_tn;
+    cu_a_lo = nx_a_lo, cu_a_hi = nx_a_hi, cu_a_rec = nx_a_rec, cu_w_so = nx_w_so, cu_s_so = nx_s_so;
+    if (ch_pos < ch_tiles) {
+      scale_dma(cur_tm, cur_tn, ch_pos & 1);
+      if (ch_pos + 1 < ch_tiles) locate(ch_first + (ch_pos + 1) * ch_stride, nx_tm, nx_tn);
+      nx_tm = __builtin_amdgcn_readfirstlane(nx_tm), nx_tn = __builtin_amdgcn_readfirstlane(nx_tn);
+      tile_ref(nx_tm, nx_tn, nx_a_lo, nx_a_hi, nx_a_rec, nx_w_so, nx_s_so);
+    }
+    cursors_at_stage0();
+  };
+
   // ---- epilogue operands that do not depend on the accumulators: fetched here, 12 registers carried through the loop ----
   constexpr int RST = NT / (BN / 8);     // epilogue: rows a pass-step of the workgroup covers (8 / 16)
   const int c8 = tid % (BN / 8), er0 = tid / (BN / 8);  // this thread's 8 columns; rows er0 + RST * ps of a pass
@@ -431,7 +671,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   float2 s2v[4] = {};
   const _Float16 nz = (_Float16)-0.0f;
   h8 bv = {nz, nz, nz, nz, nz, nz, nz, nz};
-  if (n < N) {
+  if (!CHAIN && n < N) {  // (CHAIN: the seam reads the tile's scales from LDS; nothing is carried through the loop)
     const int i0s = s2_stored_index(n), i1s = s2_stored_index(n + 4);
     s2v[0] = *reinterpret_cast<const float2*>(s2 + i0s);
     s2v[1] = *reinterpret_cast<const float2*>(s2 + i0s + 8);
@@ -442,12 +682,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
   // ---- prologue: stages 0 .. LA - 1 by LDS-DMA, the weight ring, the scales; then EVERYTHING has landed (the loop's hand-counted
   // waits presuppose that nothing older than its own loads is in flight) ----
-  qqq_static_for<LA>([&](auto jc) { dma_stage(jc, decltype(jc)::value); });
+  if constexpr (CHAIN) {  // the same loads, read through the cursors (which end up LA stages / RS steps / P stages into the run)
+    scale_dma(tile_m, tile_n, 0);
+    qqq_static_for<LA>([&](auto jc) { dma_stage_so(jc, (unsigned)decltype(jc)::value * 128u); });
 #pragma unroll
-  for (int j = 0; j < RS; ++j) load_w(j, wr[j]);
-  if constexpr (GROUPED) {
+    for (int j = 0; j < RS; ++j) load_w_so(cu_w_so + (unsigned)j * 4u * rowbytes, wr[j]);
+    if constexpr (GROUPED) {
 #pragma unroll
-    for (int j = 0; j < P; ++j) load_sc(j, scr[j]);
+      for (int j = 0; j < P; ++j) load_sc_so(cu_s_so + (unsigned)j * (unsigned)N * 2u, scr[j]);
+    }
+  } else {
+    qqq_static_for<LA>([&](auto jc) { dma_stage(jc, decltype(jc)::value); });
+#pragma unroll
+    for (int j = 0; j < RS; ++j) load_w(j, wr[j]);
+    if constexpr (GROUPED) {
+#pragma unroll
+      for (int j = 0; j < P; ++j) load_sc(j, scr[j]);
+    }
   }
   qqq_static_for<RS>([&](auto jc) {  // (the asm loads' results are tied to the wait: nothing may read them before it)
     constexpr int j = decltype(jc)::value;
@@ -483,12 +734,71 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     asm volatile("s_waitcnt vmcnt(%0)" : : "n"(since) : "memory");
     if constexpr (!(QQQ_WIDE_ABLATE & 1)) __syncthreads();  // stage i + 2 is in LDS for everybody; buffer (i % P) is free
   };
-  QQQ_TR(1);
+  QQQ_WTR(1);
+  if constexpr (CHAIN) {
+    // ---- the flat stage sequence of this workgroup's whole run: the trip of P stages never ends, a seam follows whichever
+    // stage completes a tile; after the last tile's flush the wave is done (s_endpgm waits for what is still in flight) ----
+    static_assert(!CHAIN || P == 4, "the trip is written out for four stage buffers");
+    int left = NST;
+    auto do_stage_chain = [&](auto uc) __attribute__((always_inline)) {
+      const unsigned wstep = 4u * rowbytes, sstep = (unsigned)N * 2u;
+      if (__builtin_expect(left > P, 1)) {  // every load of this stage stays inside the tile
+        // (sgpr(): a no-op on a value that is scalar already; it only tells hipcc so where it cannot see it)
+        st_xso = sgpr(cx_so), st_swo[0] = sgpr(cr_so), st_swo[1] = sgpr(cr_so + wstep), st_sco = sgpr(cc_so);
+        cx_so += 128u, cr_so += 2u * wstep, cc_so += sstep;
+        asm volatile("" : "+s"(st_xso), "+s"(st_swo[0]), "+s"(st_swo[1]), "+s"(st_sco));
+      } else {         // the last P stages: the loads cross into the next tile one kind after the other
+        const int done = NST - left;                       // stages of this tile behind us
+        const bool xn = left <= LA, cn = true;             // (left <= P: the scale load is always in the next tile)
+        st_xso = sgpr(xn ? (unsigned)(LA - left) * 128u : (unsigned)(done + LA) * 128u);
+        xdesc[0] = sgpr(xn ? nx_a_lo : cu_a_lo), xdesc[1] = sgpr(xn ? nx_a_hi : cu_a_hi), xdesc[2] = sgpr(xn ? nx_a_rec : cu_a_rec);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int sn_ = 2 * done + t + RS;               // the step the ring refill of step t fetches
+          st_swo[t] = sgpr(sn_ < KS ? cu_w_so + (unsigned)sn_ * wstep : nx_w_so + (unsigned)(sn_ - KS) * wstep);
+        }
+        st_sco = sgpr(cn ? nx_s_so + (unsigned)(P - left) * sstep : 0u);
+        // in SGPRs and settled HERE: a value that reaches its load through a VALU copy (v_readfirstlane / v_readlane) one slot
+        // ahead of it is read inside the 5 wait states a VALU-written SGPR needs before a vector-memory instruction may use it
+        // -- hipcc's own count is thrown off by the inline-asm MFMA in between (tools/check_vmem.py checks the compiled code)
+        asm volatile("s_nop 4" : "+s"(st_xso), "+s"(st_swo[0]), "+s"(st_swo[1]), "+s"(st_sco), "+s"(xdesc));
+      }
+      step(0, uc, std::integral_constant<int, 0>{});
+      step(0, uc, std::integral_constant<int, 1>{});
+      constexpr int since = wide_loads_between(GROUPED, MT, HW, 1, wide_last_dma_slot(MT, HW), 2 * (P - 3), NSLOT);
+      static_assert(since < 64, "vmcnt is a 6-bit counter");
+      asm volatile("s_waitcnt vmcnt(%0)" : : "n"(since) : "memory");
+      __syncthreads();
+    };
+    bool more = true;
+    // (the expectations put the seams and the tile-end offset code out of line: the common stage falls through from one MFMA
+    // run into the next -- a taken branch is a fetch bubble nothing hides when the wave is alone on its SIMD)
+#define QQQ_CHAIN_STAGE(U)                                    \
+  if (__builtin_expect(more, 1)) {                            \
+    do_stage_chain(std::integral_constant<int, U>{});         \
+    if (__builtin_expect(--left == 0, 0)) {                   \
+      seam();                                                 \
+      left = NST;                                             \
+      if (ch_pos == ch_tiles) {                               \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      \
+        more = false;                                         \
+      }                                                       \
+    }                                                         \
+  }
+    do {
+      QQQ_CHAIN_STAGE(0)
+      QQQ_CHAIN_STAGE(1)
+      QQQ_CHAIN_STAGE(2)
+      QQQ_CHAIN_STAGE(3)
+    } while (more);
+    return;
+#undef QQQ_CHAIN_STAGE
+  }
   // ---- steady state: P stages per iteration (ring slots and LDS buffers are compile-time), branch-free ----
   int i0 = 0;
   for (; i0 + P <= NST; i0 += P) {
 #ifdef QQQ_PANEL_TRACE
-    if (i0 < 12 * P) QQQ_TRV(4 + i0 / P, __builtin_amdgcn_s_memtime());  // shader clock at the top of the first 12 trips
+    if (i0 < 12 * P) QQQ_WTRV(4 + i0 / P, __builtin_amdgcn_s_memtime());  // shader clock at the top of the first 12 trips
 #endif
     qqq_static_for<P>([&](auto uc) __attribute__((always_inline)) { do_stage(i0 + decltype(uc)::value, uc); });
   }
@@ -514,7 +824,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // ---- epilogue: EPR rows at a time: int32 -> LDS (row-major, skewed rows) -> 8 consecutive n per thread -> 16-byte stores ----
   // D lane ln of the MFMA holds token j = ln & 15, rows 4 * (ln >> 4) + r -> c' = ln >> 4, jt = r:
   //   column inside the strip  nl = 64 * (column group of the wave) + 16 * jt + 8 * b + 4 * hf + c'
-  QQQ_TR(2);
+  QQQ_WTR(2);
   // (the MFMAs are inline asm: hipcc does not know that the accumulators it is about to read were written by the matrix pipe)
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
   int* ep = reinterpret_cast<int*>(smem);
@@ -668,7 +978,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
 #ifdef QQQ_PANEL_TRACE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  QQQ_TR(3);
+  QQQ_WTR(3);
 #endif
 }
 

@@ -66,6 +66,8 @@ def test_hot_instantiations(table):
             args = n.split("<")[1].rstrip(">").split(",")
             mt, hw = int(args[1]), int(args[4])  # 16 / 8 m-tiles x 2 hw column sets x 4 registers
             assert k["agpr_count"] == 8 * hw * mt and k["max_flat_workgroup_size"] == 256, (n, k)
+            if args[5] == "true":  # the persistent tile walk: nothing in scratch at all (its seams sit inside the stage loop)
+                assert k["private_segment_fixed_size"] == 0 and k["vgpr_spill_count"] == 0, (n, k)
 
 
 def _loop(name):
@@ -106,7 +108,7 @@ def test_steady_state_loops(table):
     # scratch inside the loop, counted waits, and the issue budget of a LONE wave: at most 4 instructions per MFMA
     # (16 matrix-pipe cycles = 4 issue slots) in the per-channel mode.  LDS-DMA staging: no ds_write at all, per trip
     # 4 x 8 activation DMAs + 8 x 2 ring refills (+ 4 x 2 scale words per-group), every one inline asm.
-    for name, grouped in (("qqq_wide_kernel<false,16,4,4,2>", False), ("qqq_wide_kernel<true,16,4,8,2>", True)):
+    for name, grouped in (("qqq_wide_kernel<false,16,4,4,2,false>", False), ("qqq_wide_kernel<true,16,4,8,2,false>", True)):
         mix, waits = _loop(name)
         assert mix["v_mfma_i32_16x16x64_i8"] == 512 and mix["s_barrier"] == 4, name
         assert _count(mix, "scratch") == 0 and not any("vmcnt(0)" in w for w in waits), (name, waits)
@@ -141,7 +143,7 @@ def test_wide_kernel_hand_counted_waits_replayed_on_the_compiled_code():
     for grouped in (False, True):
         for mt, hw in ((16, 2), (8, 2), (16, 1)):
             for rs in (4, 8):
-                name = f"qqq_wide_kernel<{'true' if grouped else 'false'},{mt},4,{rs},{hw}>"
+                name = f"qqq_wide_kernel<{'true' if grouped else 'false'},{mt},4,{rs},{hw},false>"
                 text = code_object.disassemble(build.LIB, ks[name])
                 body, paths = check_waits.tail_paths(text.split("\n"))
                 assert sum("v_mfma" in x for x in body) == 16 * hw * mt and len(paths) == 4, (name, len(paths))
@@ -178,3 +180,71 @@ def test_check_waits_flags_planted_faults():
     bad = check_waits.check(check_waits.loop_body(reuse))[0]
     assert bad and "v_mov_b32" in bad[0], bad
 
+
+
+CHAIN_KERNELS = [f"qqq_wide_kernel<{g},{mt},4,{rs},{hw},true>" for g, rs in (("false", 4), ("true", 8)) for mt, hw in ((16, 2), (8, 2), (16, 1))]
+
+
+def test_tile_walk_waits_replayed_over_the_whole_control_flow_graph():
+    """The persistent tile walk (round 4) has a seam behind every stage of its trip: tools/check_vmem.py pushes the queue of loads
+    in flight through the kernel's whole control-flow graph to a fixpoint (loads retire in order; stores left out, which only
+    makes the replay stricter) and reports every instruction that touches a register a load in flight will write -- a lax
+    hand-counted wait, a compiler copy / spill / re-use of a ring register across a seam.  Plus the two hazards hipcc's own
+    bookkeeping misses around inline asm: an LDS-DMA without its M0 write, and a vector-memory instruction that reads an SGPR
+    a VALU instruction wrote fewer than 5 wait states earlier (stale scalar offsets on the device: the first bug of the walk).
+    All six instantiations; the stage loop keeps the plain kernel's instruction budget."""
+    import check_vmem
+    import code_object
+    from qqq_amd import build
+
+    ks = {k["demangled"]: k["name"] for k in code_object.kernels(build.LIB)}
+    for name in CHAIN_KERNELS:
+        ins = check_vmem.parse(code_object.disassemble(build.LIB, ks[name]))
+        problems, info = check_vmem.run(ins)
+        real = {i: t for i, t in problems.items() if not check_vmem.scalar_peek(ins, i)}
+        assert not real, (name, sorted(real.items())[:4])
+        assert not check_vmem.m0_discipline(ins, info), name
+        assert not check_vmem.sgpr_vmem_hazards(ins), (name, check_vmem.sgpr_vmem_hazards(ins)[:3])
+        args = name.split("<")[1].rstrip(">").split(",")
+        mt, hw = int(args[1]), int(args[4])
+        loop_mfma = sum(1 for _, op, rest in ins if op.startswith("v_mfma") and not rest.rstrip().endswith(", 0"))
+        reset_mfma = sum(1 for _, op, rest in ins if op.startswith("v_mfma") and rest.rstrip().endswith(", 0"))
+        assert loop_mfma == 4 * 2 * 2 * hw * mt, (name, loop_mfma)       # four stage copies, no tail copies
+        assert reset_mfma == 4 * 2 * hw * mt, (name, reset_mfma)          # one seam per stage position: in-place accumulator resets
+        assert not any(op.startswith("scratch_") for _, op, _ in ins), name
+
+
+def test_check_vmem_flags_planted_faults():
+    """The CFG replay must catch what it exists for, on toy kernels in compiler syntax: a consumer behind a wait that is one too
+    lax -- also when the load and the consumer sit in different blocks of a loop with a side branch; a copy of a register whose
+    load is in flight; a scalar offset written by v_readfirstlane one MFMA ahead of the load that reads it."""
+    import check_vmem
+
+    def kernel(wait, extra=()):
+        return "\n".join([
+            "\ts_mov_b32 s8, 0", ".LBB0_1:", "\tbuffer_load_dwordx4 v[10:13], v1, s[4:7], s8 offen",
+            "\tbuffer_load_dwordx4 v2, s[4:7], s9 offen lds", "\ts_cmp_eq_u32 s20, 0", "\ts_cbranch_scc1 .LBB0_3",
+            "\tv_mfma_i32_16x16x64_i8 a[0:3], v[20:23], v[24:27], a[0:3]", *extra, ".LBB0_3:", f"\ts_waitcnt vmcnt({wait})",
+            "\tv_and_b32_e32 v30, 0xf0f0f0f0, v10", "\ts_waitcnt vmcnt(0)", "\ts_add_i32 s21, s21, -1", "\ts_cmp_lg_u32 s21, 0",
+            "\ts_cbranch_scc1 .LBB0_1", "\ts_endpgm"])
+
+    assert check_vmem.run(check_vmem.parse(kernel(1)))[0] == {}
+    bad = check_vmem.run(check_vmem.parse(kernel(2)))[0]
+    assert bad and all("v_and_b32" in t for t in bad.values()), bad
+    bad = check_vmem.run(check_vmem.parse(kernel(1, extra=["\tv_mov_b32_e32 v40, v12"])))[0]
+    assert bad and all("v_mov_b32" in t for t in bad.values()), bad
+    # stores are not queued: a wait that relies on counting one is flagged (the conservative direction)
+    assert check_vmem.run(check_vmem.parse(kernel(2, extra=["\tglobal_store_dword v[50:51], v52, off"])))[0]
+    hz = check_vmem.sgpr_vmem_hazards(check_vmem.parse("\n".join([
+        "\tv_readfirstlane_b32 s0, v4", "\tv_mfma_i32_16x16x64_i8 a[0:3], v[20:23], v[24:27], a[0:3]", "\ts_nop 0",
+        "\tbuffer_load_dwordx4 v[10:13], v1, s[4:7], s0 offen", "\ts_endpgm"])))
+    assert len(hz) == 1
+    ok = check_vmem.sgpr_vmem_hazards(check_vmem.parse("\n".join([
+        "\tv_readfirstlane_b32 s0, v4", "\tv_mfma_i32_16x16x64_i8 a[0:3], v[20:23], v[24:27], a[0:3]", "\ts_nop 4",
+        "\tbuffer_load_dwordx4 v[10:13], v1, s[4:7], s0 offen", "\ts_endpgm"])))
+    assert ok == []
+    # an exit flag the structurizer would leave behind: the path it rules out is not walked
+    flagged = "\n".join([
+        ".LBB0_1:", "\tbuffer_load_dwordx4 v[10:13], v1, s[4:7], s8 offen", "\ts_mov_b64 s[24:25], 0", "\ts_and_b64 vcc, exec, s[24:25]",
+        "\ts_cbranch_vccz .LBB0_9", "\tv_mov_b32_e32 v40, v12", ".LBB0_9:", "\ts_waitcnt vmcnt(0)", "\ts_endpgm"])
+    assert check_vmem.run(check_vmem.parse(flagged))[0] == {}

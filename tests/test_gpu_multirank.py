@@ -32,6 +32,9 @@ def test_bench_two_ranks_one_gpu_gloo(dev):
     mg = out["multi_gpu"]["4096"]
     assert mg["chunks"] >= 2 and mg["rows_per_rank"] == 2048
     assert all(mg[k] > 0 for k in ("gemm_only_us", "allgather_only_us", "overlapped_us"))
+    # what lets a reader verify an N > 1 line: the collective really spanned N ranks, over which backend, and how the step was launched
+    assert out["multi_gpu"]["world_seen"] == 2 and out["multi_gpu"]["backend"] == "gloo" and out["multi_gpu"]["launch"] == "eager"
+    assert "step launch: eager" in out["config"]["parallelism"]
 
 
 def test_bench_two_ranks_rccl_when_two_gpus():

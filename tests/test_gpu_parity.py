@@ -536,6 +536,45 @@ def test_wide_every_instantiation_every_k_tail(dev):
                         assert ulp_distance(D, eD) == 0, (grouped, K, tune)
 
 
+def test_tile_walk_three_tiles_per_workgroup_every_stage_phase(dev):
+    """The persistent tile walk of the wide kernel (tune glds=2): one workgroup per CU walks its run of tiles, the
+    loads of a tile's last stages already fetch the next tile, the seam flushes the accumulators without touching LDS.  More than
+    three tiles per workgroup, a ragged last m-tile, a last strip that overhangs n, and K = 8 ... 11 stages of 128: the flat stage
+    sequence keeps rotating through the four LDS buffers / the register ring across seams, so a seam falls behind every stage
+    position of the unrolled trip (K % 512 = 0, 128, 256, 384) -- all six instantiations against the oracle, int32 and fp16,
+    with a bias; the plan must really be the tile walk."""
+    from oracle import c_oracle as C
+    from oracle import qqq_ref as R
+    from qqq_amd import _lib
+
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    rng = np.random.default_rng(4)
+    N = 4160                                            # 16.25 strips of 256 / 32.5 of 128
+    for grouped in (False, True):
+        for st in (8, 9, 10, 11):
+            K = 128 * st
+            M = 256 * (-(-3 * cus // 17) + 1) + 37      # > 3 tiles of 256 x 256 per CU, ragged last m-tile
+            codes = rng.integers(0 if grouped else -8, 16 if grouped else 8, size=(K, N)).astype(np.int8)
+            B = R.pack_codes(codes, grouped)
+            s2 = rng.random((1, N), dtype=np.float32) * 2e-4 + 1e-5
+            s3 = (rng.random((K // 128, N), dtype=np.float32) * 15 + 0.5).astype(np.float16) if grouped else None
+            bias = (rng.standard_normal(N) * 0.1).astype(np.float16)
+            h = GemmHarness(B, s2, s3, dev)
+            A = rng.integers(-128, 128, size=(M, K), dtype=np.int8)
+            s1 = rng.random((M, 1), dtype=np.float32) * 0.05 + 0.001
+            eD, eacc = C.qqq_gemm(A, B, s1, s2, s3, return_acc=True)
+            eDb = (torch.from_numpy(eD.copy()) + torch.from_numpy(bias)).numpy()
+            for shape in (dict(), dict(mt=8), dict(bm=128)):
+                tune = dict(kernel=5, glds=2, **shape)
+                pl = _lib.plan(M, N, K, 128 if grouped else -1, 16, tune=tune)
+                assert pl["kernel"] == 5 and pl["glds"] == 2 and pl["ksplit"] == 1, pl
+                D, acc = h.run(A, s1, tune)
+                assert np.array_equal(acc, eacc), (grouped, K, tune)
+                assert ulp_distance(D, eD) == 0, (grouped, K, tune)
+                Db, _ = h.run(A, s1, tune, want_acc=False, bias=bias)   # the production flush: no test hook in the way
+                assert ulp_distance(Db, eDb) == 0, (grouped, K, tune)
+
+
 def test_every_variant_under_load(dev):
     """Every tuning variant, repeatedly, while a second stream keeps the chip busy with other GEMMs of mixed weight (so
     that workgroups of different kernels share CUs and the waves of a workgroup drift apart): results must equal the

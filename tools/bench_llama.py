@@ -51,21 +51,41 @@ def time_fn(fn, iters=10, reps=8):
     return float(np.median([a.elapsed_time(b) for a, b in ev]) * 1e3 / reps)
 
 
-def main():
-    dev = torch.device("cuda:0")
-    out = {"device": torch.cuda.get_device_name(dev), "launch": "hipGraph replay (8 calls per graph)", "layers": {}}
-    for gs in (-1, 128):
+TOKENS = (1024, 8192, 32768)  # batch 1 / 8 / 32 x seq 1024
+
+
+def llama_matrix(dev, tokens=TOKENS, modes=(-1, 128), budget_s=None, merged=True):
+    """BASELINE configs[3] as a dict: per linear / token count / mode the QuantLinear time (fused dynamic quant + W4A8 GEMM),
+    the GEMM alone, the fp16 nn.Linear, `gemm_tops` and `speedup_vs_fp16`; the sum over the 7 linears of a block; and (merged)
+    the same block with the projections that share an input fused.  One implementation for `python
+    tools/bench_llama.py` and for bench.py's `llama7b` object.  budget_s: wall-clock bound; what did not fit is listed under
+    "skipped" (nothing is extrapolated)."""
+    import time
+    from qqq_amd import fuse_quant_linears, ops
+
+    t_start = time.perf_counter()
+    out = {"device": torch.cuda.get_device_name(dev), "launch": "hipGraph replay (8 calls per graph)", "tokens": list(tokens),
+           "layers": {}, "skipped": []}
+
+    def over():
+        return budget_s is not None and time.perf_counter() - t_start > budget_s
+
+    for gs in modes:
         mode = "per_channel" if gs == -1 else "g128"
         tot = {}
+        complete = True
         for (name, N, K) in LAYERS:
+            if over():
+                out["skipped"].append(f"{mode}/{name}")
+                complete = False
+                continue
             ql = make_ql(dev, N, K, gs, hash((name, gs)) & 0xFFFF)
             lin = torch.nn.Linear(K, N, bias=False).half().to(dev)
-            for M in (1024, 8192, 32768):
+            for M in tokens:
                 x = torch.randn((M, K), device=dev, dtype=torch.float16)
                 t_q = time_fn(lambda: ql(x))
                 xq, s1 = ql.dynamic_quant(x)
                 D = torch.empty((M, N), dtype=torch.float16, device=dev)
-                from qqq_amd import ops
                 t_g = time_fn(lambda: ops.mul(xq, ql.B, ql.reduce_buffer, D, s1, ql.s_channel, ql.s_group, ql.workspace, max_par=16))
                 t_f = time_fn(lambda: lin(x))
                 out["layers"].setdefault(mode, {}).setdefault(name, {})[str(M)] = {
@@ -76,17 +96,24 @@ def main():
                 del x, D
             del ql, lin
             torch.cuda.empty_cache()
-        out.setdefault("sum_of_7_linears", {})[mode] = {str(M): {"quantlinear_us": a, "fp16_us": b, "speedup": b / a} for M, (a, b) in tot.items()}
+        if complete:
+            out.setdefault("sum_of_7_linears", {})[mode] = {str(M): {"quantlinear_us": a, "fp16_us": b, "speedup": b / a} for M, (a, b) in tot.items()}
+        if not merged:
+            continue
         # the same block with the projections that share an input merged (what vLLM does): q/k/v -> one layer
         # with N = 12288, gate/up -> N = 22016; the fp16 side gets the same merge (one nn.Linear each)
-        from qqq_amd import fuse_quant_linears
         ftot = {}
+        complete = True
         for (name, parts, K) in (("qkv_proj", [4096, 4096, 4096], 4096), ("o_proj", [4096], 4096), ("gate_up_proj", [11008, 11008], 4096), ("down_proj", [4096], 11008)):
+            if over():
+                out["skipped"].append(f"{mode}/merged/{name}")
+                complete = False
+                continue
             qls = [make_ql(dev, n, K, gs, hash((name, i, gs)) & 0xFFFF) for i, n in enumerate(parts)]
             ql = fuse_quant_linears(qls) if len(qls) > 1 else qls[0]
             N = sum(parts)
             lin = torch.nn.Linear(K, N, bias=False).half().to(dev)
-            for M in (1024, 8192, 32768):
+            for M in tokens:
                 x = torch.randn((M, K), device=dev, dtype=torch.float16)
                 t_q = time_fn(lambda: ql(x))
                 t_f = time_fn(lambda: lin(x))
@@ -97,8 +124,14 @@ def main():
                 del x
             del ql, qls, lin
             torch.cuda.empty_cache()
-        out.setdefault("sum_of_4_merged_linears", {})[mode] = {str(M): {"quantlinear_us": a, "fp16_us": b, "speedup": b / a} for M, (a, b) in ftot.items()}
-    print(json.dumps(out))
+        if complete:
+            out.setdefault("sum_of_4_merged_linears", {})[mode] = {str(M): {"quantlinear_us": a, "fp16_us": b, "speedup": b / a} for M, (a, b) in ftot.items()}
+    out["seconds"] = time.perf_counter() - t_start
+    return out
+
+
+def main():
+    print(json.dumps(llama_matrix(torch.device("cuda:0"))))
 
 
 if __name__ == "__main__":
