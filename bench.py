@@ -442,7 +442,7 @@ def main():
                 def gemm_fn(a_rows, s1_rows, d_rows, Bj=Bj):
                     ops.qqq_gemm(a_rows, Bj, layer.C, d_rows, s1_rows, layer.s2, layer.s3, layer.ws, -1, -1, -1, MAX_PAR)
 
-                sg = ShardedGemm(gemm_fn)  # chunk count from the shard size (qqq_amd.parallel.pick_chunks)
+                sg = ShardedGemm(gemm_fn, K=K_FULL)  # chunk count from the shard size and the layer (qqq_amd.parallel.pick_chunks)
                 spans = sg.spans(M, N_FULL)
                 sharded[M] = (sg, take_rows(A, spans), take_rows(s1, spans))
 

@@ -68,7 +68,10 @@ typedef struct qqq_tune {
   int fused;   /* split-K finish; 0 auto.  stream: 1 = last-arriving workgroup reduces in-launch (tickets in
                   workspace, release fence), 3 = same with write-through slab stores (no release fence),
                   2 = separate reduce launch.  tiled: 1 = in-launch (K slices of a tile meet in tile-sized int32
-                  slots of C, tickets in workspace), 2 = ksplit [m,n] slabs in C + separate reduce launch      */
+                  slots of C, tickets in workspace), 2 = ksplit [m,n] slabs in C + separate reduce launch.
+                  tiled / panel / wide in-launch hand-off, OR-ed in: 4 = formal agent-scope acquire fence in front of the
+                  fold, 8 = agent-scope release on the depositor's completion count (both off as shipped: the deposits
+                  are written through and read with agent-scope loads; the switches exist so that tests run both ways) */
   int bm;      /* tiled: rows per workgroup tile (64, 128, 256); panel: COLUMNS per workgroup (128, 256); wide: COLUMNS per
                   workgroup (256; 128 with mt = 16 only: 32 columns per wave); 0 auto */
   int glds;    /* tiled: 1 = direct global->LDS loads, 2 = register staged; 0 auto.

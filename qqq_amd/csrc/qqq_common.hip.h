@@ -29,6 +29,24 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 // small device helpers
 // ------------------------------------------------------------------------------------------
 
+// In-launch split-K hand-off, the two ends of it (tiled / panel / wide kernels).  As shipped: deposits are written through
+// (`sc0 sc1`), `s_waitcnt vmcnt(0)` + barrier, then a RELAXED agent-scope add on the completion count; the last arrival polls
+// that count (relaxed), barrier, and reads the deposits with agent-scope `sc1` loads -- no fences: an agent-scope acquire is a
+// `buffer_inv sc1` over the whole L2 (~3 us on the finisher's critical path, and it evicts every other workgroup's operand
+// lines on the XCD).  The formal variants are RUNTIME switches (tune.fused bits 2 / 3 -> `hflags`), so that the same library
+// runs both ways and the stress tests cover both (tests/test_gpu_parity.py); `-DQQQ_HANDOFF_ACQUIRE_FENCE` still forces bit 0.
+__device__ __forceinline__ bool qqq_formal_acquire(const int hflags) {
+#ifdef QQQ_HANDOFF_ACQUIRE_FENCE
+  return true;
+#else
+  return (hflags & 1) != 0;
+#endif
+}
+__device__ __forceinline__ void qqq_publish_add(int* counter, const int hflags) {  // a depositor's "my deposit is complete"
+  if (hflags & 2) __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  else __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // stored position of logical column n's per-channel scale (inverse of _scale_perm_single,
 // qlinear_marlin.py:173-175):  n%32 = 2*i + 8*q + e  ->  32*(n/32) + 8*i + 2*q + e
 __device__ __forceinline__ int s2_stored_index(int n) {

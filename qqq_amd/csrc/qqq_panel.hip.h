@@ -74,7 +74,10 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
     const int8_t* __restrict__ A, const unsigned char* __restrict__ B, int32_t* __restrict__ C,
     _Float16* __restrict__ D, const float* __restrict__ s1, const float* __restrict__ s2,
     const _Float16* __restrict__ s3, int32_t* __restrict__ acc_out, int* __restrict__ tickets,
-    const _Float16* __restrict__ bias, const int M, const int N, const int K, const int ksplit) {
+    const _Float16* __restrict__ bias, const int M, const int N, const int K, const int ksplit_hf) {
+  // (hand-off switches ride in the upper half of the K-split argument -- tune.fused bits 2 / 3: 1 = the formal agent-scope ACQUIRE
+  // fence in front of the fold, 2 = agent-scope RELEASE on the depositor's completion count; see qqq_common.hip.h)
+  const int ksplit = ksplit_hf & 0xffff, hflags = ksplit_hf >> 16;
   constexpr int NW = WN * KG;            // waves
   constexpr int NT = NW * 64;            // threads
   constexpr int BN = 32 * WN * HW;       // columns per workgroup
@@ -518,7 +521,7 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
       }
       __syncthreads();  // every wave's part of the deposit has reached memory
       QQQ_TR(5);
-      if (tid == 0) __hip_atomic_fetch_add(tk + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0) qqq_publish_add(tk + 1, hflags);
       return;
     }
     if (tid == 0) {  // everybody waited for has arrived already (is depositing): short, and bounded as a matter of principle
@@ -531,9 +534,7 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
       }
     }
     __syncthreads();
-#ifdef QQQ_HANDOFF_ACQUIRE_FENCE  // debugging switch: the formal agent-scope acquire in front of the fold (~3 us per finisher)
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#endif
+    if (qqq_formal_acquire(hflags)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (off by default, ~3 us per finisher: qqq_common.hip.h)
     QQQ_TR(5);
     // No acquire fence here: at agent scope it is a `buffer_inv sc1` over the whole L2, measured at ~3 us of the finisher's
     // critical path (tools/trace_panel.py).  The deposits are read with agent-scope loads instead (`load16_agent`, sc1),

@@ -26,8 +26,11 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * (2 / NB) * 64) void 
     const int8_t* __restrict__ A, const unsigned char* __restrict__ B, int32_t* __restrict__ C,
     _Float16* __restrict__ D, const float* __restrict__ s1, const float* __restrict__ s2,
     const _Float16* __restrict__ s3, int32_t* __restrict__ acc_out,
-    const _Float16* __restrict__ bias, const int M, const int N, const int K, const int ksplit,
+    const _Float16* __restrict__ bias, const int M, const int N, const int K, const int ksplit_hf,
     const int tiles_m, const int tiles_n, int* __restrict__ tickets, const int nslots, const int PW) {
+  // (hand-off switches ride in the upper half of the K-split argument -- tune.fused bits 2 / 3: 1 = the formal agent-scope ACQUIRE
+  // fence in front of the fold, 2 = agent-scope RELEASE on the depositor's completion count; see qqq_common.hip.h)
+  const int ksplit = ksplit_hf & 0xffff, hflags = ksplit_hf >> 16;
   // wave tile: MTW m-tiles of 32 tokens x JW column tiles (jt) x NB column halves (b).  NB == 1: the two
   // b halves of a packed word go to two different waves (per-group mode: every weight is re-quantised
   // by exactly one wave of the workgroup).
@@ -586,9 +589,7 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * (2 / NB) * 64) void 
         }
       }
       __syncthreads();  // no acquire fence (an L2-wide invalidate at agent scope): add_slot reads with agent-scope loads
-#ifdef QQQ_HANDOFF_ACQUIRE_FENCE
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#endif
+      if (qqq_formal_acquire(hflags)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (off by default: qqq_common.hip.h)
     };
     auto add_slot = [&](const int s_) {
       const __amdgpu_buffer_rsrc_t view = agent_view(slot_base(s_));
@@ -637,7 +638,10 @@ __global__ __launch_bounds__((BM / (32 * MTW)) * (4 / JW) * (2 / NB) * 64) void 
             }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();  // every wave's part of the deposit has reached memory
-      if (tid == 0) __hip_atomic_store(tk + 1 + slot, gen + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0) {
+        if (hflags & 2) __hip_atomic_store(tk + 1 + slot, gen + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        else __hip_atomic_store(tk + 1 + slot, gen + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       return;
     }
     if (tid <= used) __hip_atomic_store(tk + tid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // workspace zero on return

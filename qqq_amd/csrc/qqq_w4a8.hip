@@ -128,6 +128,7 @@ struct LaunchArgs {
   int* tickets;
   const _Float16* bias;
   int M, N, K;
+  int hflags;  // in-launch split-K hand-off switches (tune.fused bits 2 / 3): 1 = formal acquire fence, 2 = release on publish
   hipStream_t stream;
 };
 
@@ -220,7 +221,7 @@ static hipError_t launch_panel_t(const LaunchArgs& a, int ksplit) {
   }
   dim3 grid((a.N + BN - 1) / BN, ksplit, (a.M + ROWS - 1) / ROWS);
   hipLaunchKernelGGL(kern, grid, dim3(64 * WN * KG), LDS, a.stream, a.A, a.B, a.C, a.D, a.s1, a.s2, a.s3, a.acc_out,
-                     a.tickets, a.bias, a.M, a.N, a.K, ksplit);
+                     a.tickets, a.bias, a.M, a.N, a.K, ksplit | (a.hflags << 16));
   return hipGetLastError();
 }
 
@@ -282,7 +283,7 @@ static hipError_t launch_tiled_t(const LaunchArgs& a, int ksplit, int nslots, in
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + 255) / 256;
   dim3 grid(tiles_m * tiles_n, ksplit, 1);
   hipLaunchKernelGGL(kern, grid, dim3(NT), LDS, a.stream, a.A, a.B, a.C, a.D, a.s1, a.s2, a.s3,
-                     a.acc_out, a.bias, a.M, a.N, a.K, ksplit, tiles_m, tiles_n, a.tickets, nslots, pw);
+                     a.acc_out, a.bias, a.M, a.N, a.K, ksplit | (a.hflags << 16), tiles_m, tiles_n, a.tickets, nslots, pw);
   return hipGetLastError();
 }
 
@@ -375,7 +376,7 @@ static hipError_t launch_wide_t(const LaunchArgs& a, int pw, int ksplit) {
   const int tiles_m = (a.M + ROWS - 1) / ROWS, tiles_n = (a.N + BN - 1) / BN;
   const int grid = CHAIN ? (device_cus() & ~7) : tiles_m * tiles_n * ksplit;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, a.stream, a.A, a.B, a.C, a.D, a.s1, a.s2, a.s3,
-                     a.acc_out, a.tickets, a.bias, a.M, a.N, a.K, tiles_m, tiles_n, pw, ksplit);
+                     a.acc_out, a.tickets, a.bias, a.M, a.N, a.K, tiles_m, tiles_n, pw, ksplit | (a.hflags << 16));
   return hipGetLastError();
 }
 
@@ -617,10 +618,11 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
       const double e_wide = (M > 256) ? wide_estimate(M, N, K, grouped, have_scratch && have_ws, cap_rows, cap_tk, &wks, &wmt, &wbn) : 1e30;
       if (e_wide < e_panel && e_wide < e_stream && e_wide < e_tiled) {
         kernel = 5;
-        if (t.ksplit <= 0) t.ksplit = wks;
+        // (the K split was costed for the model's own tile shape: a caller who pins mt / bm gets one slice unless it asks)
         if (t.mt == 0 && t.bm == 0) {
           t.mt = wmt;
           t.bm = wbn;
+          if (t.ksplit <= 0) t.ksplit = wks;
         }
       } else if (e_panel <= e_stream && e_panel <= e_tiled) {
         kernel = 4;
@@ -762,7 +764,7 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
   const long long cap_ints = cap_rows * (long long)N;
   const long long cap_tickets = workspace ? (long long)(N / 128) * (max_par > 0 ? max_par : 0) : 0;
   auto slot_count = [&](int rows, int ks) -> int {
-    if (!have_scratch || ks < 2 || t.fused == 2) return 0;
+    if (!have_scratch || ks < 2 || (t.fused & 3) == 2) return 0;
     const long long tl = (long long)((M + rows - 1) / rows) * strips;
     long long S = cap_ints / (tl * rows * 256);
     if (S > ks - 1) S = ks - 1;
@@ -772,7 +774,7 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
   int bm = t.bm;
   if (bm != 64 && bm != 128 && bm != 256 && bm != 258 && bm != 259 && bm != 130 && bm != 131) {
     int best_ks = 1;
-    (void)tiled_estimate(M, N, K, grouped, have_scratch, cap_rows, cap_tickets, t.fused == 2, &bm, &best_ks);
+    (void)tiled_estimate(M, N, K, grouped, have_scratch, cap_rows, cap_tickets, (t.fused & 3) == 2, &bm, &best_ks);
     if (t.ksplit <= 0) t.ksplit = best_ks;
   }
   // glds: 2 = register-staged, 1 = LDS-DMA ring with `stages` buffers; auto: the DMA ring pays at the
@@ -875,6 +877,7 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
   a.N = N;
   a.K = K;
   a.stream = static_cast<hipStream_t>(stream);
+  a.hflags = (pl.kernel == 2 || pl.kernel == 4 || pl.kernel == 5) ? ((t.fused >> 2) & 3) : 0;
 
   DeviceGuard guard(dev);
   hipError_t e = hipSuccess;

@@ -144,7 +144,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int8_t* __restrict__ A, const unsigned char* __restrict__ B, int32_t* __restrict__ C, _Float16* __restrict__ D,
     const float* __restrict__ s1, const float* __restrict__ s2, const _Float16* __restrict__ s3,
     int32_t* __restrict__ acc_out, int* __restrict__ tickets, const _Float16* __restrict__ bias, const int M, const int N,
-    const int K, const int tiles_m, const int tiles_n, const int PW, const int ksplit) {
+    const int K, const int tiles_m, const int tiles_n, const int PW, const int ksplit_hf) {
+  // (hand-off switches ride in the upper half of the K-split argument -- tune.fused bits 2 / 3: 1 = the formal agent-scope ACQUIRE
+  // fence in front of the fold, 2 = agent-scope RELEASE on the depositor's completion count; see qqq_common.hip.h)
+  const int ksplit = ksplit_hf & 0xffff, hflags = ksplit_hf >> 16;
   static_assert(MT == 16 || MT == 8, "m-tiles of 16 tokens per wave (= per workgroup): 256 or 128 tokens");
   static_assert(HW == 2 || HW == 1, "a wave owns both 32-column halves of a 64-column group, or (128-column tiles) one");
   constexpr int ROWS = 16 * MT;
@@ -873,7 +876,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();  // every wave's part of the deposit has reached memory
-      if (tid == 0) __hip_atomic_fetch_add(tk + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0) qqq_publish_add(tk + 1, hflags);
       return;
     }
   }
@@ -956,9 +959,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
     }
     __syncthreads();
-#ifdef QQQ_HANDOFF_ACQUIRE_FENCE  // debugging switch: the formal agent-scope acquire in front of the fold
-    if (pass == 0 && fold) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#endif
+    if (pass == 0 && fold && qqq_formal_acquire(hflags)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (off by default: qqq_common.hip.h)
     if (pass == 0) {  // (the pin: behind the first image's LDS writes, which cover the loads' round trip)
 #pragma unroll
       for (int p2 = 0; p2 < ROWS / EPR; ++p2)

@@ -89,16 +89,19 @@ class ShardedGemm:
     """
 
     def __init__(self, gemm_fn: Callable, group: Optional[dist.ProcessGroup] = None, chunks: Optional[int] = None,
-                 comm_stream: Optional["torch.cuda.Stream"] = None):
+                 comm_stream: Optional["torch.cuda.Stream"] = None, K: int = 21760):
         self.gemm_fn = gemm_fn
         self.group = group
-        self.chunks = chunks  # None: pick_chunks(M, N, world) per call
+        self.chunks = chunks  # None: pick_chunks(M, N, world, K) per call
+        self.K = K            # the layer's reduction depth: the GEMM side of the chunk cost model scales with N * K (a 4096-deep
+                              # layer's GEMM is 5x shorter than the BASELINE layer's, i.e. communication-bound sooner); spans() and
+                              # __call__ must agree on the chunk count, hence stored here rather than passed per call
         self.comm_stream = comm_stream
         self._tail = None  # scratch slab of a ragged last super-block
 
     def spans(self, M_total: int, N: int) -> List[Tuple[int, int]]:
         world = dist.get_world_size(self.group)
-        chunks = self.chunks if self.chunks else pick_chunks(M_total, N, world)
+        chunks = self.chunks if self.chunks else pick_chunks(M_total, N, world, self.K)
         return row_spans(M_total, world, dist.get_rank(self.group), chunks)
 
     def __call__(self, A: torch.Tensor, s1: torch.Tensor, M_total: int, N: int,
@@ -108,7 +111,7 @@ class ShardedGemm:
         to the overlapped total); the result is only meaningful with both."""
         world = dist.get_world_size(self.group)
         rank = dist.get_rank(self.group)
-        chunks = self.chunks if self.chunks else pick_chunks(M_total, N, world)
+        chunks = self.chunks if self.chunks else pick_chunks(M_total, N, world, self.K)
         spans = row_spans(M_total, world, rank, chunks)
         if local:
             A_local, s1_local = A, s1

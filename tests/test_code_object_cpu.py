@@ -156,6 +156,15 @@ def test_wide_kernel_hand_counted_waits_replayed_on_the_compiled_code():
                 second = ("rr" if grouped else "") + per_step if hw == 2 else "r" + ("rr" if grouped else "") + "D" * (mt // 4)
                 per_step = per_step + second
                 assert at_barrier == [per_step] * 4, (name, at_barrier)
+                # what hipcc's own bookkeeping cannot see around the inline asm (tools/check_vmem.py): M0 is written nowhere but
+                # in front of the LDS-DMA that reads it (hipcc reserves M0 -- a clobber is refused as "reserved register" -- so the
+                # discipline is checked on the code instead), and no vector-memory instruction reads an SGPR inside the 5 wait
+                # states behind a VALU write of it
+                import check_vmem
+
+                ins = check_vmem.parse(text)
+                assert not check_vmem.m0_discipline(ins, None), name
+                assert not check_vmem.sgpr_vmem_hazards(ins), (name, check_vmem.sgpr_vmem_hazards(ins)[:3])
 
 
 def test_check_waits_flags_planted_faults():

@@ -339,7 +339,19 @@ def test_maximum_batch_and_grouped_llama_shape(dev):
         assert not np.isnan(D.astype(np.float32)).any()
 
 
-def test_inlaunch_splitk_stress_two_streams(dev):
+HANDOFFS = pytest.mark.parametrize("hand", [0, 4, 8, 12], ids=["as-shipped", "acquire-fence", "release-publish", "both"])
+
+
+def _with_handoff(tune, hand):
+    """tune.fused bits 2 / 3: the formal ends of the in-launch split-K hand-off (qqq_common.hip.h) -- an agent-scope acquire fence in
+    front of the fold, an agent-scope release on the depositor's completion count.  The same library runs every variant."""
+    t = dict(tune)
+    t["fused"] = (t.get("fused", 1) & 3) | hand
+    return t
+
+
+@HANDOFFS
+def test_inlaunch_splitk_stress_two_streams(dev, hand):
     """The slot / ticket hand-off of the tiled kernel's in-launch split-K under load: two layers (own scratch each, as
     two QuantLinear modules would have) hammered back to back from two streams, 300 calls with varying m and K
     splits; every result must equal the unsplit kernel's bit for bit and the workspaces must end all-zero."""
@@ -375,7 +387,7 @@ def test_inlaunch_splitk_stress_two_streams(dev):
                         dict(kernel=2, bm=64, ksplit=2 + it % 3)][it % 4]
                 D = torch.empty((M, N), dtype=torch.float16, device=dev)
                 with torch.cuda.stream(streams[li]):
-                    ops.qqq_gemm_ex(A, h.B, h.C, D, s1, h.s2, h.s3, h.ws, -1, -1, -1, 16, tune=tune)
+                    ops.qqq_gemm_ex(A, h.B, h.C, D, s1, h.s2, h.s3, h.ws, -1, -1, -1, 16, tune=(_with_handoff(tune, hand) if tune else tune))
                 outs.append((li, M, D, tune))
         torch.cuda.synchronize()
         for li, M, D, tune in outs:
@@ -384,7 +396,8 @@ def test_inlaunch_splitk_stress_two_streams(dev):
             assert int(h.ws.abs().sum().item()) == 0
 
 
-def test_panel_inlaunch_splitk_stress_two_streams(dev):
+@HANDOFFS
+def test_panel_inlaunch_splitk_stress_two_streams(dev, hand):
     """The panel kernel's ticket / slot hand-off under load: two layers (own scratch each) hammered from two streams, varying m
     (one to three m-blocks), K splits and shapes; every result must equal the unsplit stream kernel's bit for bit, the
     workspaces must end all-zero, and the poisoned reduce buffer must never leak into an output."""
@@ -424,7 +437,7 @@ def test_panel_inlaunch_splitk_stress_two_streams(dev):
                         dict(kernel=4, waves=4, ksplit=3, pf=3, mt=2)][it % 7]
                 D = torch.empty((M, N), dtype=torch.float16, device=dev)
                 with torch.cuda.stream(streams[li]):
-                    ops.qqq_gemm_ex(A, h.B, h.C, D, s1, h.s2, h.s3, h.ws, -1, -1, -1, 16, tune=tune)
+                    ops.qqq_gemm_ex(A, h.B, h.C, D, s1, h.s2, h.s3, h.ws, -1, -1, -1, 16, tune=(_with_handoff(tune, hand) if tune else tune))
                 outs.append((li, M, D, tune))
         torch.cuda.synchronize()
         for li, M, D, tune in outs:
@@ -433,7 +446,8 @@ def test_panel_inlaunch_splitk_stress_two_streams(dev):
         assert int(h.ws.abs().sum().item()) == 0
 
 
-def test_wide_inlaunch_splitk_stress_two_streams(dev):
+@HANDOFFS
+def test_wide_inlaunch_splitk_stress_two_streams(dev, hand):
     """The wide kernel's ticket / slot hand-off under load (row-major partial tiles written through to C, folded by the last
     arrival with agent-scope loads, no acquire fence): two layers with their own scratch hammered from two streams, both tile
     heights, 2-3 K slices, ragged m; every result equal to the unsplit stream kernel's bit for bit, workspaces all-zero after."""
@@ -471,7 +485,7 @@ def test_wide_inlaunch_splitk_stress_two_streams(dev):
                         dict(kernel=5, ksplit=2, pw=4), dict(kernel=5, bm=128, ksplit=2)][it % 6]
                 D = torch.empty((M, N), dtype=torch.float16, device=dev)
                 with torch.cuda.stream(streams[li]):
-                    ops.qqq_gemm_ex(A, h.B, h.C, D, s1, h.s2, h.s3, h.ws, -1, -1, -1, 16, tune=tune)
+                    ops.qqq_gemm_ex(A, h.B, h.C, D, s1, h.s2, h.s3, h.ws, -1, -1, -1, 16, tune=(_with_handoff(tune, hand) if tune else tune))
                 outs.append((li, M, D, tune))
         torch.cuda.synchronize()
         for li, M, D, tune in outs:
@@ -621,7 +635,8 @@ def test_every_variant_under_load(dev):
             assert int(h.ws.abs().max()) == 0 and int(bg.ws.abs().max()) == 0
 
 
-def test_splitk_deposits_with_three_workgroups_per_cu(dev):
+@HANDOFFS
+def test_splitk_deposits_with_three_workgroups_per_cu(dev, hand):
     """The reproducer of the missing-s_nop bug (inline-asm 16-byte deposit stores whose data registers hipcc re-used before
     the store had read them): light 4-wave panel workgroups, three to a CU, the same split-K launch hammered from two
     streams.  Failed 25-40 % of the calls at m = 33 / 64 before the fix, on every box; idle-chip tests never did."""
@@ -654,7 +669,7 @@ def test_splitk_deposits_with_three_workgroups_per_cu(dev):
                     A, s1 = toks[M]
                     D = torch.empty((M, N), dtype=torch.float16, device=dev)
                     with torch.cuda.stream(streams[li]):
-                        ops.qqq_gemm_ex(A, h.B, h.C, D, s1, h.s2, h.s3, h.ws, -1, -1, -1, 16, tune=tune)
+                        ops.qqq_gemm_ex(A, h.B, h.C, D, s1, h.s2, h.s3, h.ws, -1, -1, -1, 16, tune=(_with_handoff(tune, hand) if tune else tune))
                     outs.append((li, M, D))
             torch.cuda.synchronize()
             bad = [(li, M) for li, M, D in outs if not torch.equal(D.view(torch.int16), want[(li, M)].view(torch.int16))]

@@ -27,7 +27,16 @@ for k, cs in sorted(agg.items()):
     g = m.get("GRBM_GUI_ACTIVE")
     wc = m.get("SQ_WAVE_CYCLES")
     if g and dur.get(k):
-        print(f"   -> effective clock ~ {g / 8 / (sum(dur[k])/len(dur[k])) / 1e3:.2f} GHz (GRBM_GUI_ACTIVE / 8 XCDs / duration)")
+        # GRBM_GUI_ACTIVE counts from before the first wave to after the last one (command processor, cache write-back): for a
+        # launch of a few tens of microseconds that window is much longer than the kernel's own timestamps, and the ratio came
+        # out ABOVE the part's 2.4 GHz maximum (2.7 - 7.6 "GHz" for the panel / stream / column / reduce kernels in round 3).
+        # It is a usable clock estimate only for long launches, and never above the maximum.
+        mean_us = sum(dur[k]) / len(dur[k])
+        ghz = g / 8 / mean_us / 1e3
+        if mean_us >= 100.0 and ghz <= 2.4:
+            print(f"   -> effective clock ~ {ghz:.2f} GHz (GRBM_GUI_ACTIVE / 8 XCDs / duration)")
+        else:
+            print(f"   -> effective clock: n/a (launch of {mean_us:.0f} us: the GRBM_GUI_ACTIVE window is not the kernel's; bench.py `clocks` has rocm-smi's reading)")
     if wc:
         for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_VALU"):
             if c in m:
