@@ -128,7 +128,7 @@ struct LaunchArgs {
   int* tickets;
   const _Float16* bias;
   int M, N, K;
-  int hflags;  // in-launch split-K hand-off switches (tune.fused bits 2 / 3): 1 = formal acquire fence, 2 = release on publish
+  int hflags;  // in-launch split-K hand-off switches (tune.fused bits 2 / 3 / 4): 1 = formal acquire fence, 2 = release on publish, 4 = never L2-local deposits
   hipStream_t stream;
 };
 
@@ -534,7 +534,8 @@ static double panel_estimate(int M, int N, int K, bool grouped, bool have_scratc
 //   256 x 128 (mt 16, bn 128): fixed 7, 0.72 (0.96) per stage: a weight operand still feeds 256 tokens, twice the LDS traffic
 //                              per MFMA -- the shape that fills the chip from ~600 tokens, and per-group on 4096-wide layers;
 //   128 x 256 (mt 8,  bn 256): fixed 7, 0.71 (1.17): twice the unpack / re-quantise work per MFMA.
-// Two K slices (256-token tiles): hand-off 20 us per 256 KiB of partial tile (written through, folded by the last arrival).
+// Two K slices (256-token tiles): hand-off 15 us per 256 KiB of partial tile (kept in the XCD's L2 when its slices share one -- round 4 --,
+// folded by the last arrival; 20 us written through).
 static double wide_estimate(int M, int N, int K, bool grouped, bool have_scratch, long long cap_rows, long long cap_tickets, int* ks_out,
                             int* mt_out, int* bn_out) {
   *ks_out = 1;
@@ -560,7 +561,8 @@ static double wide_estimate(int M, int N, int K, bool grouped, bool have_scratch
       const double rounds = x <= 1.0 ? 1.0 : cx - 0.3 * (cx - x);
       const double lo = grouped ? 0.85 : 0.80, rel = x <= 0.5 ? 0.0 : (x - 0.5) / 0.5;
       const double load = x <= 1.0 ? lo + (1.0 - lo) * rel * rel : 1.0;
-      const double handoff = ks > 1 ? 20.0 * (double)(rows * bn) / 65536.0 : 0.0;
+      // (15 us per 256 KiB of partial tile since the deposits stay in the XCD's L2, 20-23 written through: profiles/r04_wide_xcd_local_deposits.txt)
+      const double handoff = ks > 1 ? 15.0 * (double)(rows * bn) / 65536.0 : 0.0;
       const double us = 3.7 + rounds * (fixed + handoff + ((double)NST / ks) * t_stage * load);
       if (us < best) {
         best = us;
@@ -602,8 +604,10 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
     // activations (per-lane 16-byte loads of 16 rows), so beyond m = 8 it only wins while m*K stays small -- but then
     // up to 32 tokens (two 16-token tiles per wave), where it saves the stream kernel's reduce launch
     const long long mk = (long long)M * K;
-    const bool column = column_ok && N / 32 >= 64 &&
-                        (M <= 8 || (M <= 32 && N / 32 <= 512 && mk <= (grouped ? (M <= 16 ? 360000 : 140000) : 200000)));
+    // (beyond 512 column workgroups -- two rounds of the chip -- the stream kernel's one round of K slices wins even at decode:
+    // N = 28672, K = 8192: 23.0 vs 25.3 us per-channel, 29.1 vs 30.4 per-group, profiles/r04_dispatch_check_shapes_before.txt)
+    const bool column = column_ok && N / 32 >= 64 && N / 32 <= (M <= 8 ? 768 : 512) &&
+                        (M <= 8 || (M <= 32 && mk <= (grouped ? (M <= 16 ? 360000 : 140000) : 200000)));
     if (column) kernel = 3;
     else kernel = (M <= 128 || (K % 128) != 0) ? 1 : 2;
     // Above the decode regime the family is picked by the three cost models.  The panel kernel is also the MFMA path
@@ -877,7 +881,7 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
   a.N = N;
   a.K = K;
   a.stream = static_cast<hipStream_t>(stream);
-  a.hflags = (pl.kernel == 2 || pl.kernel == 4 || pl.kernel == 5) ? ((t.fused >> 2) & 3) : 0;
+  a.hflags = (pl.kernel == 2 || pl.kernel == 4 || pl.kernel == 5) ? ((t.fused >> 2) & 7) : 0;
 
   DeviceGuard guard(dev);
   hipError_t e = hipSuccess;

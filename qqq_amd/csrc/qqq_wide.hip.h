@@ -214,6 +214,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       locate(lin, tile_m, tile_n);
     }
   }
+  // ---- K split: which XCD am I on?  Published into the tile's arrival word right away (a nibble per slice: valid bit + XCC id),
+  // read back with the arrival ticket after the main loop.  Slices that find each other on ONE XCD hand their partial tiles over
+  // through that XCD's L2 (plain write-back stores; the finisher's agent-scope loads miss L1 and hit the L2 line) instead of
+  // writing them through to memory -- see the deposit below for why the decision is consistent on both ends.
+  unsigned my_xcc = 0;
+  if (!CHAIN && ksplit > 1) {
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc));
+    my_xcc &= 7u;
+    if (tid == 0 && ksplit <= 6)
+      __hip_atomic_fetch_or(tickets + 2 * (size_t)tile_lin, (int)((8u | my_xcc) << (8 + 4 * sp)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   const int mbase = tile_m * ROWS;
   const int ngroups = N >> 6;
   const int cb = tile_n * 4 + wn;        // this wave's block of 32 HW columns: a 64-column group, or (HW = 1) half cb & 1 of group cb >> 1
@@ -834,7 +845,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int ej = lane & 15, ecp = lane >> 4;
   const int egrp = HW == 2 ? wn : (wn >> 1), ehalf = wn & 1;  // the wave's 64-column group of the strip (and, HW = 1, its half)
   constexpr int EP_ITEMS = EPR * (BN / 8), EP_PASSES = EP_ITEMS / NT;  // 16 rows per thread and pass
-  auto image = [&](const int pass) {  // this wave's accumulators of EPR rows -> the row-major LDS image
+  // this wave's accumulators of EPR rows -> the row-major LDS image.  (always_inline: called from three places since the deposit
+  // has two store policies, hipcc would otherwise leave it out of line and take the accumulators by ADDRESS -- i.e. keep all
+  // 256 of them in scratch: 4 accumulation registers and 2900 scratch instructions in the first build)
+  auto image = [&](const int pass) __attribute__((always_inline)) {
 #pragma unroll
     for (int jm = 0; jm < EPR / 16; ++jm)
 #pragma unroll
@@ -855,27 +869,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     int* xch = ep + EPR * EP_STRIDE;  // one word behind the image (a second __shared__ object would de-pipeline the main loop)
     if (tid == 0) *xch = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    arrival = __builtin_amdgcn_readfirstlane(*xch);
+    const unsigned word = (unsigned)__builtin_amdgcn_readfirstlane(*xch);
+    arrival = (int)(word & 0xffu);
     const size_t slot_ints = (size_t)ROWS * BN;
     if (arrival < ksplit - 1) {
+      // Same XCD for every slice of this tile, as far as the arrival word shows at MY arrival?  Then the deposit may stay in
+      // this XCD's L2.  The set of published nibbles only grows, and the finisher takes its ticket after every depositor: it
+      // sees at least what I see.  So if I deposit L2-only, the finisher (and every other slice) is on my XCD and finds my
+      // lines in the L2 we share; if any slice is elsewhere -- or has not even started -- I write through, and a write-through
+      // store is right for a reader anywhere.  The finisher's loads are the same either way (agent scope: an L1 miss, an L2 hit
+      // where the line is, memory otherwise).  hflags & 4 (tune.fused bit 4) forces the write-through path, for A/B timing.
+      bool local = ksplit <= 6 && !(hflags & 4);
+      for (int j = 0; j < ksplit; ++j) local = local && ((word >> (8 + 4 * j)) & 15u) == (8u | my_xcc);
       const __amdgpu_buffer_rsrc_t sv = wide_view(C + ((size_t)tile_lin * (ksplit - 1) + arrival) * slot_ints);
+      auto deposit = [&](auto auxc) __attribute__((always_inline)) {
+        constexpr int aux = decltype(auxc)::value;
 #pragma unroll
-      for (int pass = 0; pass < ROWS / EPR; ++pass) {
-        __syncthreads();
-        image(pass);
-        __syncthreads();
+        for (int pass = 0; pass < ROWS / EPR; ++pass) {
+          __syncthreads();
+          image(pass);
+          __syncthreads();
 #pragma unroll
-        for (int ps = 0; ps < EP_PASSES; ++ps) {
-          const int row = er0 + RST * ps;
-          const unsigned off = (unsigned)(((pass * EPR + row) * BN + c8 * 8) * 4);
-          const v4i lo = *reinterpret_cast<const v4i*>(ep + row * EP_STRIDE + c8 * 8);
-          const v4i hi4 = *reinterpret_cast<const v4i*>(ep + row * EP_STRIDE + c8 * 8 + 4);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, lo), sv, off, 0, /*sc0 sc1*/ 17);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, hi4), sv, off + 16, 0, /*sc0 sc1*/ 17);
+          for (int ps = 0; ps < EP_PASSES; ++ps) {
+            const int row = er0 + RST * ps;
+            const unsigned off = (unsigned)(((pass * EPR + row) * BN + c8 * 8) * 4);
+            const v4i lo = *reinterpret_cast<const v4i*>(ep + row * EP_STRIDE + c8 * 8);
+            const v4i hi4 = *reinterpret_cast<const v4i*>(ep + row * EP_STRIDE + c8 * 8 + 4);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, lo), sv, off, 0, aux);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, hi4), sv, off + 16, 0, aux);
+          }
         }
-      }
+      };
+      if (local) deposit(std::integral_constant<int, 0>{});            // write-back: the line lives in this XCD's L2
+      else deposit(std::integral_constant<int, /*sc0 sc1*/ 17>{});     // written through to memory
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();  // every wave's part of the deposit has reached memory
+      __syncthreads();  // every wave's part of the deposit is where the finisher will look for it
       if (tid == 0) qqq_publish_add(tk + 1, hflags);
       return;
     }

@@ -339,12 +339,13 @@ def test_maximum_batch_and_grouped_llama_shape(dev):
         assert not np.isnan(D.astype(np.float32)).any()
 
 
-HANDOFFS = pytest.mark.parametrize("hand", [0, 4, 8, 12], ids=["as-shipped", "acquire-fence", "release-publish", "both"])
+HANDOFFS = pytest.mark.parametrize("hand", [0, 4, 8, 12, 16], ids=["as-shipped", "acquire-fence", "release-publish", "both", "write-through-only"])
 
 
 def _with_handoff(tune, hand):
-    """tune.fused bits 2 / 3: the formal ends of the in-launch split-K hand-off (qqq_common.hip.h) -- an agent-scope acquire fence in
-    front of the fold, an agent-scope release on the depositor's completion count.  The same library runs every variant."""
+    """tune.fused bits 2 / 3 / 4: the formal ends of the in-launch split-K hand-off (qqq_common.hip.h) -- an agent-scope acquire fence
+    in front of the fold, an agent-scope release on the depositor's completion count -- and the wide kernel's XCD-local deposits
+    switched off (every deposit written through, as in round 3).  The same library runs every variant."""
     t = dict(tune)
     t["fused"] = (t.get("fused", 1) & 3) | hand
     return t

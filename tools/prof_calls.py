@@ -11,13 +11,15 @@ ap.add_argument("--ms", default="1,16,128,1024,4096")
 ap.add_argument("--mode", default="pc")
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--tune", default="{}")
+ap.add_argument("--nk", default=f"{Bn.N_FULL},{Bn.K_FULL}")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
-layer = Bn.Layer(dev, grouped=(args.mode == "g128"))
+NN, KK = [int(x) for x in args.nk.split(",")]
+layer = Bn.Layer(dev, grouped=(args.mode == "g128"), N=NN, K=KK)
 tune = json.loads(args.tune) or None
 for M in [int(x) for x in args.ms.split(",")]:
-    A, s1 = Bn.make_tokens(dev, M, M)
-    D = torch.empty((M, Bn.N_FULL), dtype=torch.float16, device=dev)
+    A, s1 = Bn.make_tokens(dev, M, M, K=KK)
+    D = torch.empty((M, NN), dtype=torch.float16, device=dev)
     layer.time_calls(A, s1, D, 3, tune=tune)
     t = layer.time_calls(A, s1, D, args.iters, tune=tune) * 1e3
     print(f"M={M} mean {t.mean():.1f} us  min {t.min():.1f}  tune={tune}")
