@@ -200,9 +200,9 @@ def test_dispatch_of_the_baseline_sweep(L):
     p = _lib.plan(128, N, K, -1, 16)
     assert (p["kernel"], p["mt"], p["ksplit"]) == (4, 8, 4)
     # 320 - 512 tokens: 256 x 128 tiles of the wide kernel in two K slices (2 m-tiles x 64 strips x 2 = one round), both modes;
-    # 640 - 1024 tokens: per-channel its 128-token tiles (one round of 128 x 256 tiles, no split); per-group its 256 x 128
-    # tiles, unsplit (the re-quantiser wants 256 tokens per weight operand; 4 m-tiles x 64 strips = one round)
-    # (profiles/r03_dispatch_check_wide3.txt)
+    # 640 - 1024 tokens: per-channel its 128-token tiles (one round of 128 x 256 tiles, no split); per-group 256 x 256 tiles in
+    # two K slices since round 4 (the deposits stay in the XCD's L2: 150.6 / 148.7 / 167.2 us against 155.9 / 152.7 / 167.1 for the
+    # unsplit 256 x 128 tiles of round 3; profiles/r04_dispatch_check_mid.txt)
     for m in (320, 512):
         for gs in (-1, 128):
             p = _lib.plan(m, N, K, gs, 16)
@@ -210,7 +210,7 @@ def test_dispatch_of_the_baseline_sweep(L):
     for m in (640, 768, 1024):
         p, g = _lib.plan(m, N, K, -1, 16), _lib.plan(m, N, K, 128, 16)
         assert (p["kernel"], p["mt"], p["bm"], p["ksplit"]) == (5, 8, 256, 1), (m, p)
-        assert (g["kernel"], g["mt"], g["bm"], g["ksplit"]) == (5, 16, 128, 1), (m, g)
+        assert (g["kernel"], g["mt"], g["bm"], g["ksplit"]) == (5, 16, 256, 2), (m, g)
     p = _lib.plan(1024, N, K, -1, 16, tune=dict(kernel=4, bm=256, mt=8, pw=2))  # the round-2 choice stays available
     assert (p["kernel"], p["bm"], p["mt"], p["pw"], p["ksplit"]) == (4, 256, 8, 2, 1), p
     # from ~1.5 K tokens (>= 3/4 of a round of 256 x 256 tiles) the wide kernel, both modes (round 3:
@@ -219,6 +219,15 @@ def test_dispatch_of_the_baseline_sweep(L):
         for gs in (-1, 128):
             p = _lib.plan(m, N, K, gs, 16)
             assert (p["kernel"], p["mt"], p["bm"], p["ksplit"], p["pf"], p["stages"], p["pw"]) == (5, 16, 256, 1, 4 if gs < 0 else 8, 1, 8), (m, gs, p)
+    # the persistent tile walk (round 4, glds == 2 in the plan): automatic on 4096 / 5120-deep layers with more than one 256 x 256
+    # tile per CU, never at K = 21760 unless forced, never with a K split, and only from 8 stages of K up
+    assert _lib.plan(8192, 4096, 4096, -1, 16)["glds"] == 2 and _lib.plan(8192, 11008, 4096, 128, 16)["glds"] == 2
+    assert _lib.plan(4096, 4096, 4096, -1, 16)["glds"] == 1 and _lib.plan(8192, 4096, 11008, -1, 16)["glds"] == 1   # one tile per CU; K too long
+    assert _lib.plan(8192, N, K, -1, 16)["glds"] == 1 and _lib.plan(8192, N, K, -1, 16, tune=dict(kernel=5, glds=2))["glds"] == 2
+    assert _lib.plan(8192, 4096, 4096, -1, 16, tune=dict(kernel=5, glds=1))["glds"] == 1
+    p = _lib.plan(2048, N, K, -1, 128, tune=dict(kernel=5, glds=2, ksplit=2))  # (max_par 128: room in C for 256 deposits)
+    assert p["ksplit"] == 2 and p["glds"] == 1, p
+    assert _lib.plan(8192, 4096, 896, -1, 16, tune=dict(kernel=5, glds=2))["glds"] == 1
     assert _lib.plan(1024, N, K, -1, 16, tune=dict(kernel=5, bm=128))["bm"] == 128 and _lib.plan(1024, N, K, -1, 16, tune=dict(kernel=5, mt=8, bm=128))["bm"] == 256
     assert _lib.plan(4096, N, K, -1, 16, tune=dict(kernel=5, pf=8))["pf"] == 8 and _lib.plan(4096, N, K, 128, 16, tune=dict(kernel=5, pf=4))["pf"] == 4
     assert _lib.plan(4096, N, K, -1, 16, tune=dict(kernel=5, stages=3))["stages"] == 1  # LDS-DMA staging: one lead, a full stage
