@@ -1,7 +1,9 @@
 """Thread-level functional model of the REFERENCE kernel's own reads (test infrastructure, CPU only).
 
-`Marlin<>` (/root/reference/csrc/qqq_gemm.cu:240-820) is followed thread by thread for ONE threadblock (gridDim.x == 1: one
-stripe that walks every column slice, slice_count == 1, so no global reduce): every index expression below is the kernel's
+`Marlin<>` (/root/reference/csrc/qqq_gemm.cu:240-820) is followed thread by thread -- for ONE threadblock (`marlin_one_block`: gridDim.x
+== 1, one stripe that walks every column slice, slice_count == 1, no global reduce) and, since round 4, for a GRID of threadblocks
+(`marlin_grid`: the striped partition `:261-338`, stripes that start in the middle of a column slice, `global_reduce` through the int32
+buffer C in lock order `:606-676, :792-812`; all four tile configurations incl. the two 128-thread ones, `:935-945`): every index expression below is the kernel's
 own, with its line cited -- which 16-byte piece of A / B / s2 / s3 a thread copies to which shared-memory slot
 (:351-407, :468-497), which slot it reads back (`ldmatrix`, `frag_b_quant`, `frag_s3`; :510-522), how the registers are
 interpreted by `mma.m16n8k16` (PTX fragment layouts for .s8), how the four k-slices of a tile meet (:555-596) and how the
@@ -23,7 +25,7 @@ def ceildiv(a, b):
     return -(-a // b)
 
 
-def marlin_one_block(A, B, s1, s2, s3=None, thread_m_blocks=1, thread_n_blocks=8, thread_k_blocks=8, threads=256):
+def marlin_one_block(A, B, s1, s2, s3=None, thread_m_blocks=1, thread_n_blocks=8, thread_k_blocks=8, threads=256, grid=1):
     """(D fp16 [m,n], acc int32 [m,n]) as ONE threadblock of Marlin<threads, thread_m_blocks, thread_n_blocks,
     thread_k_blocks, 4, group_blocks> computes them.  A int8 [m,k]; B int32 [k/16, 2n]; s1 f32 [m]; s2 f32 [n] (stored
     order); s3 fp16 [k/128, n] (stored order) or None."""
@@ -87,11 +89,13 @@ def marlin_one_block(A, B, s1, s2, s3=None, thread_m_blocks=1, thread_n_blocks=8
     lane, warp = tid % 32, tid // 32
     nwarps = threads // 32
 
-    for slice_col in range(n_tiles):  # gridDim.x == 1: the block walks the column slices in order (:792-812)
-        a_gl_rd = a_gl_stride * (tid // a_gl_rd_delta_o) + (tid % a_gl_rd_delta_o)                      # :369 (slice_row = 0)
-        b_gl_rd = b_gl_stride * (tid // b_sh_stride) + (tid % b_sh_stride) + b_sh_stride * slice_col    # :378-380
+    def slice_pass(slice_col, slice_row, slice_iters):
+        """the main loop over `slice_iters` k-tiles of column slice `slice_col` starting at tile row `slice_row` (:729-760), then
+        thread_block_reduce (:555-596): the fragments of the threads tid < b_sh_stride, [b_sh_stride, thread_m_blocks, 4, 2, 4]"""
+        a_gl_rd = a_gl_stride * (tid // a_gl_rd_delta_o) + (tid % a_gl_rd_delta_o)                      # :369; the slice_row term (:370) is `kt` below
+        b_gl_rd = b_gl_stride * (tid // b_sh_stride) + (tid % b_sh_stride) + b_sh_stride * slice_col    # :378-379; :380 likewise
         frag_c = np.zeros((threads, thread_m_blocks, 4, 2, 4), np.int64)
-        for kt in range(k_tiles):
+        for kt in range(slice_row, slice_row + slice_iters):
             # ---- fetch_to_shared (:468-497): tile kt of this slice into its pipeline stage ----
             sh_a = np.zeros((a_sh_stage, 16), np.int8)
             for i in range(a_sh_wr_iters):
@@ -139,7 +143,9 @@ def marlin_one_block(A, B, s1, s2, s3=None, thread_m_blocks=1, thread_n_blocks=8
         # ---- thread_block_reduce (:555-596): the threads/b_sh_stride k-slices of the tile meet in shared memory; thread t of the
         # first slice ends up with the sum over the threads t + b_sh_stride * r (same fragment slots: red_sh_rd keeps t % b_sh_stride)
         red = threads // b_sh_stride
-        fc = frag_c.reshape(red, b_sh_stride, thread_m_blocks, 4, 2, 4).sum(axis=0)  # valid for tid < b_sh_stride
+        return frag_c.reshape(red, b_sh_stride, thread_m_blocks, 4, 2, 4).sum(axis=0)  # valid for tid < b_sh_stride
+
+    def write_out(slice_col, fc):
         # ---- scales for the write-out (:766-792) ----
         sh_s1 = {}
         for t in range(min(threads, prob_m)):                          # s1_sh_wr_pred = tid < prob_m; s1_gl_rd = tid
@@ -177,7 +183,87 @@ def marlin_one_block(A, B, s1, s2, s3=None, thread_m_blocks=1, thread_n_blocks=8
             ACC4[d_gl_wr[ok]] = sh_i.reshape(-1, 8)[d_sh_rd[ok]]
             d_gl_wr = d_gl_wr + d_gl_wr_delta
             d_sh_rd = d_sh_rd + d_sh_rd_delta
+
+    if grid == 1:
+        for slice_col in range(n_tiles):  # gridDim.x == 1: the block walks the column slices in order (:792-812)
+            write_out(slice_col, slice_pass(slice_col, 0, k_tiles))
+        return D4.reshape(prob_m, prob_n), ACC4.reshape(prob_m, prob_n)
+
+    # ---- a grid of threadblocks: the striped partition (:261-338) ----
+    # (parallel == 1: prob_m <= 16 * thread_m_blocks is asserted above, so slice_col_par == slice_col and no pointer offsets)
+    iters = ceildiv(k_tiles * n_tiles, grid)                                                            # :280
+    if group_blocks != -1:
+        iters = (group_blocks // thread_k_blocks) * ceildiv(iters, group_blocks // thread_k_blocks)     # :284-285
+    work = {}   # column slice -> [(slice_idx, slice_count, block, fragments)]
+    covered = np.zeros((n_tiles, k_tiles), np.int32)
+    for b in range(grid):
+        slice_row = (iters * b) % k_tiles                                                               # :287
+        slice_col = (iters * b) // k_tiles                                                              # :288-289
+        while True:
+            # init_slice (:305-337)
+            slice_iters = iters * (b + 1) - (k_tiles * slice_col + slice_row)
+            if slice_iters < 0 or slice_col >= n_tiles:
+                slice_iters = 0
+            if slice_iters == 0:
+                break
+            if slice_row + slice_iters > k_tiles:
+                slice_iters = k_tiles - slice_row
+            slice_count, slice_idx = 1, 0
+            col_first = iters * ceildiv(k_tiles * slice_col, iters)
+            if col_first <= k_tiles * (slice_col + 1):
+                col_off = col_first - k_tiles * slice_col
+                slice_count = ceildiv(k_tiles - col_off, iters)
+                if col_off > 0:
+                    slice_count += 1
+                delta_first = iters * b - col_first
+                if delta_first < 0 or (col_off == 0 and delta_first == 0):
+                    slice_idx = slice_count - 1
+                else:
+                    slice_idx = slice_count - 1 - delta_first // iters
+                    if col_off > 0:
+                        slice_idx -= 1
+            covered[slice_col, slice_row:slice_row + slice_iters] += 1
+            work.setdefault(slice_col, []).append((slice_idx, slice_count, b, slice_pass(slice_col, slice_row, slice_iters)))
+            slice_row, slice_col = 0, slice_col + 1                                                     # :806-809
+    assert (covered == 1).all(), "the stripes must cover every (column slice, k-tile) exactly once"
+    # ---- global_reduce (:606-676) in lock order (barrier_acquire(&locks[slice_col], slice_idx), :213-237, :800-803): the block
+    # with slice_idx 0 only writes its fragments to C, the others first add what C holds, all but the last write back ----
+    C4 = np.full((16 * thread_m_blocks * prob_n // 4, 4), 0x7B7B7B7B, np.int64)   # int4 units of the int32 reduce buffer; poisoned
+    active = 32 * thread_n_blocks // 4
+    t = np.arange(active)
+    c_gl_stride = prob_n // 4
+    c_gl_wr_delta_o, c_gl_wr_delta_i = 8 * c_gl_stride, 8 * (active // 32)
+    row = (t % 32) // 4
+    for slice_col, parts in sorted(work.items()):
+        parts.sort(key=lambda x: x[0])
+        assert [p[0] for p in parts] == list(range(parts[0][1])) and all(p[1] == parts[0][1] for p in parts), (slice_col, [(p[0], p[1], p[2]) for p in parts])
+        c_gl_wr = c_gl_stride * row + 8 * (t // 32) + (t % 4) * 2 + (4 * thread_n_blocks) * slice_col   # :618-619
+        for slice_idx, slice_count, b, fc in parts:
+            first, last = slice_idx == 0, slice_idx == slice_count - 1
+            if slice_count == 1:
+                write_out(slice_col, fc)
+                continue
+            # frag_c as the flat int array the kernel indexes: [thread_m_blocks][4][2][4] -> 32 ints per m-block
+            flat = fc[:active].reshape(active, thread_m_blocks * 32).copy()
+            for i in range(thread_m_blocks * 4):
+                ok = np.full(active, True) if i < (thread_m_blocks - 1) * 4 else (8 * (i // 2) + row < prob_m)   # :627, :640
+                addr = c_gl_wr + c_gl_wr_delta_o * (i // 2) + c_gl_wr_delta_i * (i % 2)
+                for half in range(2):      # d_red1 / d_red2 (:642-655), d1 / d2 (:657-670)
+                    idx = 4 * 2 * 4 * (i // 4) + 4 * (np.arange(4) + 4 * half) + (i % 4)
+                    if not first:
+                        flat[np.ix_(ok, idx)] += C4[addr[ok] + half]
+                    if not last:
+                        C4[addr[ok] + half] = flat[np.ix_(ok, idx)]
+            fc = fc.copy()
+            fc[:active] = flat.reshape(active, thread_m_blocks, 4, 2, 4)
+            if last:
+                write_out(slice_col, fc)
     return D4.reshape(prob_m, prob_n), ACC4.reshape(prob_m, prob_n)
+
+
+def marlin_grid(A, B, s1, s2, s3=None, grid=3, thread_m_blocks=1, thread_n_blocks=8, thread_k_blocks=8, threads=256):
+    """as marlin_one_block, for `grid` threadblocks: striped partition, partial column slices, global_reduce"""
+    return marlin_one_block(A, B, s1, s2, s3, thread_m_blocks, thread_n_blocks, thread_k_blocks, threads, grid=grid)
 
 
 def _mma_m16n8k16(fa, fb, nwarps):
