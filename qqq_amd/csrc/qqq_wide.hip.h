@@ -74,6 +74,9 @@ __device__ __forceinline__ v4u wide_load16(__amdgpu_buffer_rsrc_t view, const un
 // Measurement / tuning: QQQ_WIDE_SLOTMAP=1 keeps the unpack items of the per-channel 256-token shape out of the slots that
 // already carry a memory instruction (fragment re-read, staging write / reload, ring refill): a memory instruction takes
 // more than one issue slot, and with a VALU item behind it the slot overruns its MFMA's 16 cycles.
+#ifndef QQQ_WIDE_FLUSH_AUX
+#define QQQ_WIDE_FLUSH_AUX 0  // cache policy of the tile walk's D stores (buffer aux bits: 1 sc0, 2 nt, 16 sc1); measurement builds set it
+#endif
 #ifndef QQQ_WIDE_SLOTMAP
 #define QQQ_WIDE_SLOTMAP 5  // bit 0: per-channel, bit 1: per-group, bit 2: the 128-token shape too
 #endif
@@ -650,12 +653,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if constexpr (HW == 2) {  // column sets in column order: q = 0, 2, 1, 3
           const h8 lo8 = {o[0][0], o[0][1], o[0][2], o[0][3], o[2][0], o[2][1], o[2][2], o[2][3]};
           const h8 hi8 = {o[1][0], o[1][1], o[1][2], o[1][3], o[3][0], o[3][1], o[3][2], o[3][3]};
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, lo8), dview, dr + (unsigned)cl * 2u, 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, hi8), dview, dr + (unsigned)cl * 2u + 16u, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, lo8), dview, dr + (unsigned)cl * 2u, 0, QQQ_WIDE_FLUSH_AUX);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, hi8), dview, dr + (unsigned)cl * 2u + 16u, 0, QQQ_WIDE_FLUSH_AUX);
         } else {
           typedef unsigned v2u __attribute__((ext_vector_type(2)));
 #pragma unroll
-          for (int q = 0; q < NQ; ++q) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, o[q]), dview, dr + (unsigned)dl[q] * 2u, 0, 0);
+          for (int q = 0; q < NQ; ++q) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, o[q]), dview, dr + (unsigned)dl[q] * 2u, 0, QQQ_WIDE_FLUSH_AUX);
         }
       }
       __builtin_amdgcn_sched_barrier(0);  // m-tile by m-tile: the seam must not ask for more registers than the loop leaves free
