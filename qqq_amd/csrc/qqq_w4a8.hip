@@ -475,6 +475,15 @@ static double stream_estimate(int M, int N, int K, bool grouped) {
   // (n = 11008: 86 strips x 3) is a second round
   double us = ((mblocks == 2 || mblocks == 3) ? 10.6 : 9.0 + 2.0 * mblocks) + per_block * passes;
   if ((long long)((N + 127) / 128) * mblocks > 256) us *= 1.35;
+  if (mblocks == 1 && M > 32) {
+    // 33 ... 64 tokens, refitted over ten layer shapes in both modes (round 4, profiles/r04_dispatch_check_final*.txt, r04_dispatch_check_m64.txt:
+    // 11.8 ... 43.1 us): per token count a line in the weight bytes (no floor: the 8 MB layers sit ON the line) -- fixed part 10.3 -> 12.2 us and
+    // 0.93 -> 1.11 weight passes from 40 to 64 tokens, with a step where the fourth 16-token tile starts (49 tokens); per-group x1.125 / x1.06
+    const double pb = (double)N * K / 2.0 / 5.0e6;
+    const bool four = M > 48;
+    const double fixed = 8.0 + 0.0575 * M + (four ? 0.5 : 0.0), passes64 = 0.75 + 0.0045 * M + (four ? 0.07 : 0.0);
+    return grouped ? 1.125 * fixed + 1.06 * pb * passes64 : fixed + pb * passes64;
+  }
   return grouped ? us * 1.15 : us;
 }
 
@@ -495,7 +504,17 @@ static double panel_estimate(int M, int N, int K, bool grouped, bool have_scratc
       if (ks > 1 && (!have_scratch || 2 * tl > cap_tickets || tl * rows * bn * (ks - 1) > cap_rows * (long long)N || ks > NST / 4)) break;  // slots: tiles x (ks-1) x rows x bn ints inside C
       static const double tail[5] = {0.0, 0.0, 5.0, 6.5, 8.5};  // (fold by sc1 loads, no acquire fence: profiles/r02_panel_handoff.txt)
       const double wg_us = 8.7 + tail[ks] + ((double)NST / ks) * t_stage;
-      const double us = (double)((tl * ks + 255) / 256) * wg_us;
+      double us = (double)((tl * ks + 255) / 256) * wg_us;
+      if (mt == 4 && bn == 128) {
+        // 64-token m-blocks x 128 columns, refitted over ten layer shapes in both modes (round 4, profiles/r04_dispatch_check_final*.txt;
+        // the form above was 2 ... 5 us high on every layer smaller than the BASELINE one): 11.5 us of launch / fill / hand-off / epilogue
+        // whatever the number of slices (10 unsplit; per-group + 0.4), 0.316 us per 128-k stage (per-group 0.52), and never faster than the weight matrix
+        // at 5.3 TB/s (per-group: x1.45 -- the re-quantiser and the stream do not overlap fully)
+        const double rounds = (double)((tl * ks + 255) / 256);
+        const double stage_us = rounds * ((double)NST / ks) * (grouped ? 0.52 : 0.316);
+        const double bytes_us = (double)N * K / 2.0 / 5.3e6 * (grouped ? 1.45 : 1.0);
+        us = rounds * ((ks == 1 ? 10.0 : 11.5) + (grouped ? 0.4 : 0.0)) + (stage_us > bytes_us ? stage_us : bytes_us);
+      }
       if (us < best) {
         best = us;
         *bn_out = bn;

@@ -245,8 +245,15 @@ def test_dispatch_of_the_baseline_sweep(L):
     assert (p["pf"], p["stages"]) == (4, 2)
     assert _lib.plan(128, N, K, -1, 16, tune=dict(kernel=4, stages=4))["stages"] == 4
     # the stream kernel never asks for a 257th workgroup (one 8-wave workgroup per CU): 86 strips x 3 slices -> 2 slices
-    p = _lib.plan(64, 11008, 4096, -1, 16)
+    p = _lib.plan(64, 11008, 4096, -1, 16, tune=dict(kernel=1))
     assert p["kernel"] == 1 and p["ksplit"] == 2
+    # 64 tokens on mid-size layers (round-4 refit over ten shapes, profiles/r04_dispatch_check_final*.txt): the panel kernel where its
+    # K slices stay short (16.3 vs 17.7 us here, 14.4 vs 15.8 at 5120 x 5120), the stream kernel where K is long and n small
+    # (4096 x 11008: 17.4 vs 18.3) and per-group on the very large layers (28672 x 8192: 41.6 vs 43.8)
+    p = _lib.plan(64, 11008, 4096, -1, 16)
+    assert (p["kernel"], p["ksplit"], p["bm"]) == (4, 2, 128), p
+    assert _lib.plan(64, 5120, 5120, -1, 16)["kernel"] == 4 and _lib.plan(64, 4096, 11008, -1, 16)["kernel"] == 1
+    assert _lib.plan(64, 28672, 8192, 128, 16)["kernel"] == 1 and _lib.plan(64, 8192, 28672, 128, 16)["kernel"] == 1
     p = _lib.plan(192, 4096, 4096, -1, 16, tune=dict(kernel=1))
     assert p["ksplit"] * 3 * 32 <= 256
     # short-K layers at large m: the wide kernel since its uniform schedule (profiles/r03_wide_uniform_schedule.txt: 11008 x 4096,
