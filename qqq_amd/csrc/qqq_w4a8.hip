@@ -41,6 +41,7 @@
 // byte) and pack() has pre-divided s_channel by 16; per-group weights are re-quantised to int8
 // with ONE packed-fp16 FMA exactly like dequant_per_group (csrc/qqq_gemm.cu:167-210).
 
+#include <cmath>
 #include <thread>
 #include <type_traits>
 #include <utility>
@@ -460,6 +461,27 @@ static double tiled_estimate(int M, int N, int K, bool grouped, bool have_scratc
   return best;
 }
 
+// 9 ... 32 tokens: the column kernel (one launch; every 32-column workgroup re-reads the m x K activations) against the stream kernel (K slices +
+// reduce launch).  Both fitted on ten layer shapes x {9, 12, 16, 24, 32} tokens x both modes on one box (round 4, profiles/r04_dispatch_check_m16.txt;
+// the rule they replace -- a bound on m * K -- was 20 ... 35 % behind on 8192 x 8192 at 24 / 32 tokens):
+//   column, per-channel: the decode time of the layer (4.7 us + weights at 8.8 TB/s -- the fit's slope, not a bandwidth claim) + 25 ns per 1000 bytes
+//   of activations a workgroup reads, per round of 256 workgroups;  per-group: bound by the re-quantiser -- 4.2 us + 0.907 us per 1000 k per round,
+//   flat up to 16 tokens, + 0.46 us per 1000 k for the second 16-token tile (growing as ((m - 16) / 16)^0.75);
+//   stream: 8.6 us + 0.72 weight passes at 5 TB/s up to 16 tokens, 9.1 + (m - 24) / 16 us + 0.90 passes from 17 (per-group x 1.13).
+static double column_small_estimate(int M, int N, int K, bool grouped) {
+  const int wgs = N / 32, rounds = (wgs + 255) / 256;
+  if (!grouped) return 4.7 + 0.113 * ((double)N * K / 2.0e6) + 2.5e-5 * (double)K * M * rounds;
+  const double r = rounds == 1 ? 1.0 : 0.92 * rounds;
+  double us = 4.2 + 9.07e-4 * K * r;
+  if (M > 16) us += 4.6e-4 * K * r * pow((M - 16) / 16.0, 0.75);
+  return us;
+}
+static double stream_small_estimate(int M, int N, int K, bool grouped) {
+  const double pb = (double)N * K / 2.0 / 5.0e6;
+  const double us = M <= 16 ? 8.6 + 0.72 * pb : 9.1 + (M - 24) / 16.0 + 0.90 * pb;
+  return grouped ? 1.13 * us : us;
+}
+
 // stream: every 64-token m-block streams the whole weight matrix (the first from HBM, the others mostly from L2 /
 // Infinity Cache), plus launch, LDS reduce and the separate split-K reduce launch
 static double stream_estimate(int M, int N, int K, bool grouped) {
@@ -620,13 +642,12 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
   const bool column_ok = (N % 64) == 0 && (K % 64) == 0;
   if (kernel == 0) {
     // measured (profiles/r01_tune_decode.txt, r02_decode_sweep.txt): every column workgroup re-reads the m x K
-    // activations (per-lane 16-byte loads of 16 rows), so beyond m = 8 it only wins while m*K stays small -- but then
-    // up to 32 tokens (two 16-token tiles per wave), where it saves the stream kernel's reduce launch
-    const long long mk = (long long)M * K;
+    // activations (per-lane 16-byte loads of 16 rows), so beyond m = 8 it only wins while that stays cheap -- but then
+    // up to 32 tokens (two 16-token tiles per wave), where it saves the stream kernel's reduce launch: the two small cost models above
     // (beyond 512 column workgroups -- two rounds of the chip -- the stream kernel's one round of K slices wins even at decode:
     // N = 28672, K = 8192: 23.0 vs 25.3 us per-channel, 29.1 vs 30.4 per-group, profiles/r04_dispatch_check_shapes_before.txt)
     const bool column = column_ok && N / 32 >= 64 && N / 32 <= (M <= 8 ? 768 : 512) &&
-                        (M <= 8 || (M <= 32 && mk <= (grouped ? (M <= 16 ? 360000 : 140000) : 200000)));
+                        (M <= 8 || (M <= 32 && column_small_estimate(M, N, K, grouped) < stream_small_estimate(M, N, K, grouped)));
     if (column) kernel = 3;
     else kernel = (M <= 128 || (K % 128) != 0) ? 1 : 2;
     // Above the decode regime the family is picked by the three cost models.  The panel kernel is also the MFMA path

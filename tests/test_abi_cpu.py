@@ -197,6 +197,12 @@ def test_dispatch_of_the_baseline_sweep(L):
     N, K = 8192, 21760
     assert _lib.plan(1, N, K, -1, 16)["kernel"] == 3 and _lib.plan(8, N, K, 128, 16)["kernel"] == 3
     assert _lib.plan(16, N, K, -1, 16)["kernel"] == 1
+    # 9 ... 32 tokens: column kernel vs stream kernel by two small cost models (round 4, profiles/r04_dispatch_check_m16.txt; the bound on m * K they
+    # replace sent 8192 x 8192 at 24 / 32 tokens to the stream kernel, 16.0 vs 13.4 us per-channel, 18.4 vs 13.6 per-group); BASELINE decisions unchanged
+    assert _lib.plan(16, N, K, 128, 16)["kernel"] == 3 and _lib.plan(24, N, K, 128, 16)["kernel"] == 1 and _lib.plan(32, N, K, -1, 16)["kernel"] == 1
+    assert _lib.plan(32, 8192, 8192, -1, 16)["kernel"] == 3 and _lib.plan(24, 8192, 8192, 128, 16)["kernel"] == 3
+    assert _lib.plan(32, 5120, 5120, 128, 16)["kernel"] == 3 and _lib.plan(32, 4096, 11008, -1, 16)["kernel"] == 1
+    assert _lib.plan(9, 28672, 8192, -1, 16)["kernel"] == 1   # more than 512 column workgroups: never beyond 8 tokens
     p = _lib.plan(128, N, K, -1, 16)
     assert (p["kernel"], p["mt"], p["ksplit"]) == (4, 8, 4)
     # 320 - 512 tokens: 256 x 128 tiles of the wide kernel in two K slices (2 m-tiles x 64 strips x 2 = one round), both modes;
