@@ -80,7 +80,7 @@ typedef struct qqq_tune {
                   wide: 2 = persistent tile walk wherever it applies (one workgroup per CU walks its run of tiles, the next
                   tile's first stages are fetched under the current tile's last ones, LDS-free flush at the seam; needs
                   ksplit = 1, K >= 1024 and at least one tile per CU), 1 = one tile per workgroup, 0 = automatic
-                  (the walk for K <= 6144 when there is more than one 256 x 256 tile per CU)                      */
+                  (the walk for K <= 8192 when there is more than one 256 x 256 tile per CU)                      */
   int pf;      /* stream: prefetch depth in 4 KiB steps per wave (3, 5, 7); column: 1 KiB steps per wave
                   (2..12); panel: weight ring depth in 128-k stages (2, 3, 4; 8 for mt <= 4); wide: weight ring depth in
                   64-k steps (4, 8); 0 auto                                                                  */

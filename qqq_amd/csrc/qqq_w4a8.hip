@@ -396,10 +396,12 @@ static hipError_t launch_wide_chain(const LaunchArgs& a, bool grouped, int mt, i
 // Automatic choice (profiles/r04_tile_walk_sweep.txt: plain vs walk over nine layer shapes x five token counts x both modes).
 // A seam costs 5.5 us (per-group 7) where the plain grid pays 9 us between two tiles of a CU (epilogue 6.3 + relaunch 0.2 +
 // prologue 2.6), and the walk's stage loop pays ~2-3 % for its per-stage bookkeeping: it wins where tiles are short and every CU
-// gets more than one -- K <= 6144 (4096 / 5120-deep layers: +4 ... +8 % from two tiles per CU on), is neutral around K = 8192
-// and loses 2-6 % at K = 21760.  256 x 256 tiles only: the 128-column shape loses with it, the 128-token shape gains less.
+// gets more than one -- K <= 6144 (4096 / 5120-deep layers: +4 ... +8 % from two tiles per CU on; +9 ... +15 % on a slow box,
+// profiles/r04_walk_zero_operands.txt).  At K = 8192 the sweep's box read it neutral (-1.4 ... +1.7 %), three other boxes +1 ... +6 %
+// (profiles/r04_dispatch_check_mid_shapes.txt, r04_walk_larger_k.txt): on, since the end of round 4.  K = 11008: -3.6 ... +2 % box to box,
+// K = 21760: -6 ... +1 %: off.  256 x 256 tiles only: the 128-column shape loses with it, the 128-token shape gains less.
 static bool wide_chain_pays(long long tiles, int K, int mt, int bn) {
-  return mt == 16 && bn == 256 && K / 128 <= 48 && tiles > (long long)(device_cus() & ~7);
+  return mt == 16 && bn == 256 && K / 128 <= 64 && tiles > (long long)(device_cus() & ~7);
 }
 static hipError_t launch_wide(const LaunchArgs& a, bool grouped, int mt, int bn, int pf, int pw, int ksplit, bool chain = false) {
   if (chain) return launch_wide_chain(a, grouped, mt, bn, pw);

@@ -229,6 +229,7 @@ def test_dispatch_of_the_baseline_sweep(L):
     # tile per CU, never at K = 21760 unless forced, never with a K split, and only from 8 stages of K up
     assert _lib.plan(8192, 4096, 4096, -1, 16)["glds"] == 2 and _lib.plan(8192, 11008, 4096, 128, 16)["glds"] == 2
     assert _lib.plan(4096, 4096, 4096, -1, 16)["glds"] == 1 and _lib.plan(8192, 4096, 11008, -1, 16)["glds"] == 1   # one tile per CU; K too long
+    assert _lib.plan(4096, 8192, 8192, -1, 16)["glds"] == 2 and _lib.plan(8192, 8192, 8192, 128, 16)["glds"] == 2    # K = 8192: on (r04_walk_larger_k.txt)
     assert _lib.plan(8192, N, K, -1, 16)["glds"] == 1 and _lib.plan(8192, N, K, -1, 16, tune=dict(kernel=5, glds=2))["glds"] == 2
     assert _lib.plan(8192, 4096, 4096, -1, 16, tune=dict(kernel=5, glds=1))["glds"] == 1
     p = _lib.plan(2048, N, K, -1, 128, tune=dict(kernel=5, glds=2, ksplit=2))  # (max_par 128: room in C for 256 deposits)
