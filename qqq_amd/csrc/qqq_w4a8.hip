@@ -527,7 +527,9 @@ static double panel_estimate(int M, int N, int K, bool grouped, bool have_scratc
     for (int ks = 1; ks <= 4; ++ks) {
       if (ks > 1 && (!have_scratch || 2 * tl > cap_tickets || tl * rows * bn * (ks - 1) > cap_rows * (long long)N || ks > NST / 4)) break;  // slots: tiles x (ks-1) x rows x bn ints inside C
       static const double tail[5] = {0.0, 0.0, 5.0, 6.5, 8.5};  // (fold by sc1 loads, no acquire fence: profiles/r02_panel_handoff.txt)
-      const double wg_us = 8.7 + tail[ks] + ((double)NST / ks) * t_stage;
+      // (one unsplit round of 128-token m-blocks: 7.4 -- 4096 / 5120-square layers at 768 tokens measured 23.5 / 27.5 us per-channel, 30.4 / 36.7 per-group,
+      // profiles/r04_dispatch_check_mid_shapes.txt)
+      const double wg_us = ((mt == 8 && ks == 1 && tl <= 256) ? 7.4 : 8.7) + tail[ks] + ((double)NST / ks) * t_stage;
       double us = (double)((tl * ks + 255) / 256) * wg_us;
       if (mt == 4 && bn == 128) {
         // 64-token m-blocks x 128 columns, refitted over ten layer shapes in both modes (round 4, profiles/r04_dispatch_check_final*.txt;
@@ -574,9 +576,11 @@ static double panel_estimate(int M, int N, int K, bool grouped, bool have_scratc
 // (profiles/r03_dispatch_check_wide3.txt): time = 3.7 + rounds * (fixed + hand-off + stages * t_stage * load), with
 //   256 x 256 (mt 16, bn 256): fixed 12 us (first operands from HBM with every CU in its prologue at once ~4, epilogue ~7),
 //                              1.25 us per 128-k stage (per-group 1.635: the re-quantiser of a lone wave is issue-bound);
-//   256 x 128 (mt 16, bn 128): fixed 7, 0.72 (0.96) per stage: a weight operand still feeds 256 tokens, twice the LDS traffic
+//   256 x 128 (mt 16, bn 128): fixed 7, 0.70 (0.96) per stage: a weight operand still feeds 256 tokens, twice the LDS traffic
 //                              per MFMA -- the shape that fills the chip from ~600 tokens, and per-group on 4096-wide layers;
-//   128 x 256 (mt 8,  bn 256): fixed 7, 0.71 (1.17): twice the unpack / re-quantise work per MFMA.
+//   128 x 256 (mt 8,  bn 256): fixed 7, 0.725 (1.17): twice the unpack / re-quantise work per MFMA.  (Round 4, cold A/B on six layer shapes at
+//                              640 ... 2048 tokens, profiles/r04_wide_w8_vs_w128.txt: 256 x 128 is 1 ... 4.5 % ahead of 128 x 256 per-channel wherever the
+//                              tile counts do not decide -- 0.72 / 0.71 had it the other way round.)
 // Two K slices (256-token tiles): hand-off 15 us per 256 KiB of partial tile (kept in the XCD's L2 when its slices share one -- round 4 --,
 // folded by the last arrival; 20 us written through).
 static double wide_estimate(int M, int N, int K, bool grouped, bool have_scratch, long long cap_rows, long long cap_tickets, int* ks_out,
@@ -591,7 +595,7 @@ static double wide_estimate(int M, int N, int K, bool grouped, bool have_scratch
     const int mt = shape == 2 ? 8 : 16, bn = shape == 1 ? 128 : 256;
     const int rows = 16 * mt;
     const long long tl = (long long)((M + rows - 1) / rows) * ((N + bn - 1) / bn);
-    const double t_stage = shape == 0 ? (grouped ? 1.635 : 1.25) : shape == 1 ? (grouped ? 0.96 : 0.72) : (grouped ? 1.17 : 0.71);
+    const double t_stage = shape == 0 ? (grouped ? 1.635 : 1.25) : shape == 1 ? (grouped ? 0.96 : 0.70) : (grouped ? 1.17 : 0.725);
     const double fixed = shape == 0 ? 12.0 : 7.0;
     for (int ks = 1; ks <= (mt == 16 ? 2 : 1); ++ks) {
       // one slot of rows x bn ints per tile and depositing slice inside C, two ticket words per tile
