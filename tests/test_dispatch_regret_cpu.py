@@ -1,0 +1,34 @@
+"""The dispatcher against this repository's own hardware measurements, without a GPU: every committed `tools/dispatch_check.py`
+output of round 4 (automatic choice and every forced family, timed interleaved on an MI355X) is replayed against the plans of the
+CURRENT library (`qqq_w4a8_plan` is pure host logic).  A change to a cost model that sends some measured point to a clearly slower
+family fails here; the bounds are what the final library of round 4 reaches on these files plus a little room (the measurements
+carry their box's noise: 3-5 % at the 10-20 us points)."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+# file -> (least number of points, most points above 3 %, worst regret allowed)
+FILES = {
+    "r04_dispatch_check_final.txt": (75, 6, 0.09),          # BASELINE + Llama-2-7B layers, 1 ... 8192 tokens
+    "r04_dispatch_check_final_shapes.txt": (80, 11, 0.09),  # six other layer shapes
+    "r04_dispatch_check_mid_shapes.txt": (130, 14, 0.11),   # nine shapes at 96 ... 4096 tokens, every wide variant
+    "r04_dispatch_check_m64.txt": (80, 6, 0.09),            # ten shapes at 40 ... 64 tokens
+    "r04_dispatch_check_m16.txt": (100, 6, 0.08),           # ten shapes at 9 ... 32 tokens
+    "r04_dispatch_check_mid.txt": (15, 3, 0.06),            # BASELINE layer at 320 ... 3072 tokens
+}
+
+
+@pytest.mark.parametrize("name", sorted(FILES))
+def test_planned_family_is_close_to_the_best_measured_one(name):
+    import dispatch_regret as R
+
+    rows = R.regrets(os.path.join(ROOT, "profiles", name))
+    n, above, worst = R.summary(rows)
+    need, most, bound = FILES[name]
+    bad = sorted(rows, key=lambda r: r[6] / r[5])[:5]
+    assert n >= need, (name, n)
+    assert above <= most and worst <= bound, (name, n, above, worst, bad)
