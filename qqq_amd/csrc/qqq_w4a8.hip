@@ -499,6 +499,10 @@ static double stream_estimate(int M, int N, int K, bool grouped) {
   // (n = 11008: 86 strips x 3) is a second round
   double us = ((mblocks == 2 || mblocks == 3) ? 10.6 : 9.0 + 2.0 * mblocks) + per_block * passes;
   if ((long long)((N + 127) / 128) * mblocks > 256) us *= 1.35;
+  // narrow layers (N <= 2048) at 129 ... 256 tokens: few strips, so the 64-token m-blocks x K slices of this kernel still fill the chip where the
+  // 128-token panel shapes cannot (N = 1024, K = 4096 at 256 tokens: 13.7 us against 16.6 panel / 19.2 tiled, per-group 15.1 against 18.0;
+  // profiles/r04_dispatch_check_merged.txt) -- the line above, fitted on the BASELINE layer, read 25 us there
+  if (N <= 2048 && mblocks >= 3) us = 11.0 + (double)N * K / 2.0 / 5.0e6 * passes;
   if (mblocks == 1 && M > 32) {
     // 33 ... 64 tokens, refitted over ten layer shapes in both modes (round 4, profiles/r04_dispatch_check_final*.txt, r04_dispatch_check_m64.txt:
     // 11.8 ... 43.1 us): per token count a line in the weight bytes (no floor: the 8 MB layers sit ON the line) -- fixed part 10.3 -> 12.2 us and
@@ -652,7 +656,10 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
     // up to 32 tokens (two 16-token tiles per wave), where it saves the stream kernel's reduce launch: the two small cost models above
     // (beyond 512 column workgroups -- two rounds of the chip -- the stream kernel's one round of K slices wins even at decode:
     // N = 28672, K = 8192: 23.0 vs 25.3 us per-channel, 29.1 vs 30.4 per-group, profiles/r04_dispatch_check_shapes_before.txt)
-    const bool column = column_ok && N / 32 >= 64 && N / 32 <= (M <= 8 ? 768 : 512) &&
+    // (narrow layers -- N = 1024, the k / v projections of grouped-query attention: 32 column workgroups, 6.3 vs 8.8 us at decode,
+    // 6.8 vs 9.0 at 16 tokens, profiles/r04_dispatch_check_merged.txt; below that not measured)
+    // (per-group up to 16 tokens the cap of three rounds holds as at decode: N = 22016, K = 4096 at 16 tokens 15.0 vs 17.3 us)
+    const bool column = column_ok && N / 32 >= 32 && N / 32 <= ((M <= 8 || (grouped && M <= 16)) ? 768 : 512) &&
                         (M <= 8 || (M <= 32 && column_small_estimate(M, N, K, grouped) < stream_small_estimate(M, N, K, grouped)));
     if (column) kernel = 3;
     else kernel = (M <= 128 || (K % 128) != 0) ? 1 : 2;

@@ -203,6 +203,11 @@ def test_dispatch_of_the_baseline_sweep(L):
     assert _lib.plan(32, 8192, 8192, -1, 16)["kernel"] == 3 and _lib.plan(24, 8192, 8192, 128, 16)["kernel"] == 3
     assert _lib.plan(32, 5120, 5120, 128, 16)["kernel"] == 3 and _lib.plan(32, 4096, 11008, -1, 16)["kernel"] == 1
     assert _lib.plan(9, 28672, 8192, -1, 16)["kernel"] == 1   # more than 512 column workgroups: never beyond 8 tokens
+    # narrow layers (the k / v projections of grouped-query attention, profiles/r04_dispatch_check_merged.txt): decode on N = 1024 is the column
+    # kernel's (32 workgroups, 6.3 vs 8.8 us); 256 tokens on N <= 2048 the stream kernel's (13.7 vs 16.6 panel / 19.2 tiled)
+    assert _lib.plan(1, 1024, 4096, -1, 16)["kernel"] == 3 and _lib.plan(16, 1024, 4096, 128, 16)["kernel"] == 3
+    assert _lib.plan(256, 1024, 4096, -1, 16)["kernel"] == 1 and _lib.plan(256, 1024, 4096, 128, 16)["kernel"] == 1
+    assert _lib.plan(16, 22016, 4096, 128, 16)["kernel"] == 3 and _lib.plan(16, 22016, 4096, -1, 16)["kernel"] == 1
     p = _lib.plan(128, N, K, -1, 16)
     assert (p["kernel"], p["mt"], p["ksplit"]) == (4, 8, 4)
     # 320 - 512 tokens: 256 x 128 tiles of the wide kernel in two K slices (2 m-tiles x 64 strips x 2 = one round), both modes;

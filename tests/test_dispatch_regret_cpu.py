@@ -19,6 +19,7 @@ FILES = {
     "r04_dispatch_check_m64.txt": (80, 6, 0.09),            # ten shapes at 40 ... 64 tokens
     "r04_dispatch_check_m16.txt": (100, 6, 0.08),           # ten shapes at 9 ... 32 tokens
     "r04_dispatch_check_mid.txt": (15, 3, 0.06),            # BASELINE layer at 320 ... 3072 tokens
+    "r04_dispatch_check_merged.txt": (90, 5, 0.08),         # merged projections (N = 12288 / 22016) and narrow layers (N = 2048 / 1024)
 }
 
 
