@@ -510,7 +510,8 @@ static double stream_estimate(int M, int N, int K, bool grouped) {
     const double pb = (double)N * K / 2.0 / 5.0e6;
     const bool four = M > 48;
     const double fixed = 8.0 + 0.0575 * M + (four ? 0.5 : 0.0), passes64 = 0.75 + 0.0045 * M + (four ? 0.07 : 0.0);
-    return grouped ? 1.125 * fixed + 1.06 * pb * passes64 : fixed + pb * passes64;
+    // (+3 % from 49 tokens: where the two estimates tie the panel kernel is the one ahead -- 3584 x 3584 at 64 tokens 13.1 vs 15.2 us)
+    return (grouped ? 1.125 * fixed + 1.06 * pb * passes64 : fixed + pb * passes64) * (four ? 1.03 : 1.0);
   }
   return grouped ? us * 1.15 : us;
 }
@@ -656,11 +657,14 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
     // up to 32 tokens (two 16-token tiles per wave), where it saves the stream kernel's reduce launch: the two small cost models above
     // (beyond 512 column workgroups -- two rounds of the chip -- the stream kernel's one round of K slices wins even at decode:
     // N = 28672, K = 8192: 23.0 vs 25.3 us per-channel, 29.1 vs 30.4 per-group, profiles/r04_dispatch_check_shapes_before.txt)
-    // (narrow layers -- N = 1024, the k / v projections of grouped-query attention: 32 column workgroups, 6.3 vs 8.8 us at decode,
-    // 6.8 vs 9.0 at 16 tokens, profiles/r04_dispatch_check_merged.txt; below that not measured)
+    // (narrow layers -- the k / v projections of grouped-query attention, N = 1024 / 512: 32 / 16 column workgroups, 6.3 vs 8.8 us and 6.2 vs 9.4 us
+    // at decode, profiles/r04_dispatch_check_merged.txt, r04_dispatch_check_qwen_mistral.txt; below that not measured)
     // (per-group up to 16 tokens the cap of three rounds holds as at decode: N = 22016, K = 4096 at 16 tokens 15.0 vs 17.3 us)
-    const bool column = column_ok && N / 32 >= 32 && N / 32 <= ((M <= 8 || (grouped && M <= 16)) ? 768 : 512) &&
-                        (M <= 8 || (M <= 32 && column_small_estimate(M, N, K, grouped) < stream_small_estimate(M, N, K, grouped)));
+    // Per-group the column kernel is bound by its re-quantiser (time ~ K per round), so on long-K layers the stream kernel's K slices win even
+    // at decode (N = 3584, K = 18944: 15.4 vs 19.4 us; N = 4096, K = 14336: 13.5 vs 15.8): the two small models decide from one token on.
+    const bool col_cheaper = column_small_estimate(M, N, K, grouped) < stream_small_estimate(M, N, K, grouped);
+    const bool column = column_ok && N / 32 >= 16 && N / 32 <= ((M <= 8 || (grouped && M <= 16)) ? 768 : 512) &&
+                        (grouped ? (M <= 32 && col_cheaper) : (M <= 8 || (M <= 32 && col_cheaper)));
     if (column) kernel = 3;
     else kernel = (M <= 128 || (K % 128) != 0) ? 1 : 2;
     // Above the decode regime the family is picked by the three cost models.  The panel kernel is also the MFMA path
@@ -794,6 +798,9 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
       ksplit = (int)((256 + base / 2) / base);
       // 8-wave bodies run one workgroup per CU: a 257th workgroup is a second round (n = 11008: 86 strips x 3 slices)
       if (mt >= 2 && ksplit > 1 && base * ksplit > 256) --ksplit;
+      // up to 16 tokens (4-wave bodies): 128 workgroups or more already pull the weights at the HBM's pace, a second K slice only adds the reduce
+      // launch (N = 18944, K = 3584 at 16 tokens: 10.9 us unsplit, 14.9 in two slices; N = 16384, K = 4096: 11.5 / 12.7; profiles/r04_stream_ksplit_wide_n.txt)
+      if (mt == 1 && base >= 128) ksplit = 1;
       ksplit = clampi(ksplit, 1, KS / (2 * waves) > 0 ? KS / (2 * waves) : 1);
     }
     ksplit = clampi(ksplit, 1, KS);

@@ -208,6 +208,11 @@ def test_dispatch_of_the_baseline_sweep(L):
     assert _lib.plan(1, 1024, 4096, -1, 16)["kernel"] == 3 and _lib.plan(16, 1024, 4096, 128, 16)["kernel"] == 3
     assert _lib.plan(256, 1024, 4096, -1, 16)["kernel"] == 1 and _lib.plan(256, 1024, 4096, 128, 16)["kernel"] == 1
     assert _lib.plan(16, 22016, 4096, 128, 16)["kernel"] == 3 and _lib.plan(16, 22016, 4096, -1, 16)["kernel"] == 1
+    # N = 512 (16 column workgroups) still decodes on the column kernel; per-group decode on long-K layers is the stream kernel's (re-quantiser-bound
+    # column kernel: N = 3584, K = 18944 15.4 vs 19.4 us, profiles/r04_dispatch_check_qwen_mistral.txt); wide layers stay unsplit up to 16 tokens
+    assert _lib.plan(1, 512, 3584, -1, 16)["kernel"] == 3 and _lib.plan(1, 3584, 18944, 128, 16)["kernel"] == 1 and _lib.plan(1, 3584, 18944, -1, 16)["kernel"] == 3
+    p = _lib.plan(16, 18944, 3584, -1, 16)
+    assert (p["kernel"], p["ksplit"]) == (1, 1), p
     p = _lib.plan(128, N, K, -1, 16)
     assert (p["kernel"], p["mt"], p["ksplit"]) == (4, 8, 4)
     # 320 - 512 tokens: 256 x 128 tiles of the wide kernel in two K slices (2 m-tiles x 64 strips x 2 = one round), both modes;

@@ -20,6 +20,9 @@ FILES = {
     "r04_dispatch_check_m16.txt": (100, 6, 0.08),           # ten shapes at 9 ... 32 tokens
     "r04_dispatch_check_mid.txt": (15, 3, 0.06),            # BASELINE layer at 320 ... 3072 tokens
     "r04_dispatch_check_merged.txt": (90, 5, 0.08),         # merged projections (N = 12288 / 22016) and narrow layers (N = 2048 / 1024)
+    # Qwen2-7B / Mistral-7B layers; the 26 % point (N = 18944 at 16 tokens) is the stream kernel measured with the two K slices it no longer uses there
+    # (profiles/r04_stream_ksplit_wide_n.txt: 10.9 us unsplit against the 14.6 in this file; the column kernel's 11.6 is the "best" it is held against)
+    "r04_dispatch_check_qwen_mistral.txt": (140, 20, 0.27),
 }
 
 
