@@ -481,7 +481,18 @@ static double column_small_estimate(int M, int N, int K, bool grouped) {
 static double stream_small_estimate(int M, int N, int K, bool grouped) {
   const double pb = (double)N * K / 2.0 / 5.0e6;
   const double us = M <= 16 ? 8.6 + 0.72 * pb : 9.1 + (M - 24) / 16.0 + 0.90 * pb;
-  return grouped ? 1.13 * us : us;
+  if (!grouped) return us;
+  // per-group a slice is also bound by its re-quantiser: 9.7 us + 2.1 us per 1000 k of the slice -- what a wide layer's unsplit strips pay
+  // (N = 20480, K = 7168: 24.9 us against the column kernel's 21.1; profiles/r04_stream_ksplit_wide_n.txt).  The K split as make_plan picks it:
+  const long long base = (long long)((N + 127) / 128) * (M <= 16 ? 1 : (M + 31) / 32);
+  int ks = (int)((256 + base / 2) / base);
+  if (ks > 1 && base * ks > 256) --ks;
+  if (M <= 16 && base >= 128) ks = 1;
+  const int cap = K / 64 / (M <= 16 ? 8 : 16);
+  if (ks > cap) ks = cap;
+  if (ks < 1) ks = 1;
+  const double requant = 9.7 + 2.1e-3 * (double)K / ks;
+  return 1.13 * us > requant ? 1.13 * us : requant;
 }
 
 // stream: every 64-token m-block streams the whole weight matrix (the first from HBM, the others mostly from L2 /
@@ -796,8 +807,9 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
       // one workgroup per CU: (strips x m-blocks x K-slices) ~ 256, at least 2 steps per wave
       const long long base = (long long)strips * mblocks;
       ksplit = (int)((256 + base / 2) / base);
-      // 8-wave bodies run one workgroup per CU: a 257th workgroup is a second round (n = 11008: 86 strips x 3 slices)
-      if (mt >= 2 && ksplit > 1 && base * ksplit > 256) --ksplit;
+      // a 257th workgroup is a second round (n = 11008: 86 strips x 3 slices) -- for the 4-wave bodies of <= 16 tokens as well (N = 7168, K = 20480:
+      // 56 strips x 5 slices 25.5 us, x 4 slices 18.9; profiles/r04_stream_ksplit_wide_n.txt)
+      if (ksplit > 1 && base * ksplit > 256) --ksplit;
       // up to 16 tokens (4-wave bodies): 128 workgroups or more already pull the weights at the HBM's pace, a second K slice only adds the reduce
       // launch (N = 18944, K = 3584 at 16 tokens: 10.9 us unsplit, 14.9 in two slices; N = 16384, K = 4096: 11.5 / 12.7; profiles/r04_stream_ksplit_wide_n.txt)
       if (mt == 1 && base >= 128) ksplit = 1;

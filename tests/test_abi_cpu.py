@@ -213,6 +213,11 @@ def test_dispatch_of_the_baseline_sweep(L):
     assert _lib.plan(1, 512, 3584, -1, 16)["kernel"] == 3 and _lib.plan(1, 3584, 18944, 128, 16)["kernel"] == 1 and _lib.plan(1, 3584, 18944, -1, 16)["kernel"] == 3
     p = _lib.plan(16, 18944, 3584, -1, 16)
     assert (p["kernel"], p["ksplit"]) == (1, 1), p
+    # ... and never ask for a 257th workgroup, the 4-wave bodies of <= 16 tokens included (N = 7168, K = 20480: 56 strips x 4 slices, 18.9 us against 25.5
+    # with 5); per-group decode on a wide layer is the column kernel's (N = 20480, K = 7168: 21.1 vs 24.9 us -- the unsplit stream slice is re-quantiser-bound)
+    p = _lib.plan(16, 7168, 20480, -1, 16)
+    assert (p["kernel"], p["ksplit"]) == (1, 4), p
+    assert _lib.plan(1, 20480, 7168, 128, 16)["kernel"] == 3
     p = _lib.plan(128, N, K, -1, 16)
     assert (p["kernel"], p["mt"], p["ksplit"]) == (4, 8, 4)
     # 320 - 512 tokens: 256 x 128 tiles of the wide kernel in two K slices (2 m-tiles x 64 strips x 2 = one round), both modes;

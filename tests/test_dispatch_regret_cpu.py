@@ -23,6 +23,9 @@ FILES = {
     # Qwen2-7B / Mistral-7B layers; the 26 % point (N = 18944 at 16 tokens) is the stream kernel measured with the two K slices it no longer uses there
     # (profiles/r04_stream_ksplit_wide_n.txt: 10.9 us unsplit against the 14.6 in this file; the column kernel's 11.6 is the "best" it is held against)
     "r04_dispatch_check_qwen_mistral.txt": (140, 20, 0.27),
+    # Yi-34B / Phi-3 / Llama-70B k,v / Qwen2-72B layers; the 29-37 % points (N = 7168, K = 20480 at <= 16 tokens) are the stream kernel measured with the five
+    # K slices (280 workgroups) it no longer uses there (r04_stream_ksplit_wide_n.txt: 18.9 / 22.2 us with four against the 22.7 / 28.6 in this file)
+    "r04_dispatch_check_more_models.txt": (155, 22, 0.38),
 }
 
 
