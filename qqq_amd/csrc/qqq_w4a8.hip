@@ -495,12 +495,41 @@ static double stream_small_estimate(int M, int N, int K, bool grouped) {
   return 1.13 * us > requant ? 1.13 * us : requant;
 }
 
+// stream, 65 ... 256 tokens (two to four 64-token m-blocks) on layers up to ~40 MB: the loop, not the weight stream, sets the time.  Fitted on eight layer
+// shapes x {64, 128, 256} tokens x both modes x K splits 1 ... 8 (round 4, profiles/r04_stream_panel_ksplit.txt; 10 % mean error, the right split at 44 of 48
+// points, never more than 5 % off the best one): 8.65 us + 0.153 us per 64-k step of a slice (per-group x 1.235), per round of 256 workgroups (x 1.2 from the
+// second round on), + for a K split the slabs and the reduce launch: 2 us + 0.4 us per MB of int32 slabs.  Returns the time and the split it is reached with --
+// "fill 256 workgroups" (the rule for <= 64 tokens) splits short-K layers that are better left whole (N = 8192, K = 3072 at 128 tokens: 19.4 us in two
+// slices, 15.7 unsplit).
+static double stream_mid_estimate(int M, int N, int K, bool grouped, int ks_cap, int* ks_out) {
+  const long long base = (long long)((N + 127) / 128) * ((M + 63) / 64);
+  const int KS = K / 64;
+  double best = 1e30;
+  *ks_out = 1;
+  for (int ks = 1; ks <= 8 && ks <= ks_cap; ++ks) {
+    if (ks > 1 && KS / ks < 8) break;  // (8-wave bodies: at least a step per wave)
+    const double rounds = (double)((base * ks + 255) / 256);
+    const double loop = rounds * (rounds > 1.0 ? 1.2 : 1.0) * 0.153 * (grouped ? 1.235 : 1.0) * KS / ks;
+    const double slabs = ks > 1 ? 2.0 + 0.4 * ((double)M * N * 4.0 * ks / 1.0e6) : 0.0;
+    const double us = 8.65 + loop + slabs;
+    if (us < best) {
+      best = us;
+      *ks_out = ks;
+    }
+  }
+  return best;
+}
+
 // stream: every 64-token m-block streams the whole weight matrix (the first from HBM, the others mostly from L2 /
 // Infinity Cache), plus launch, LDS reduce and the separate split-K reduce launch
 static double stream_estimate(int M, int N, int K, bool grouped) {
   double per_block = (double)N * K / 2.0 / 5.0e6;  // the weight matrix at ~5 TB/s
   if (per_block < 2.5) per_block = 2.5;
   const int mblocks = (M + 63) / 64;
+  if (mblocks >= 2 && mblocks <= 4 && (double)N * K / 2.0 / 5.0e6 < 8.0) {
+    int ks;
+    return stream_mid_estimate(M, N, K, grouped, 8, &ks);
+  }
   // measured: 2 / 3 / 4 m-blocks take 1.85 / 3.2 / 3.3 weight passes
   // (one m-block: 16 / 32 / 48 / 64 tokens measured at 0.6 / 0.8 / 1.0 / 1.2 -- the 16-token tiles of a block share the weights
   //  in registers but not the MFMA / VALU time)
@@ -510,10 +539,6 @@ static double stream_estimate(int M, int N, int K, bool grouped) {
   // (n = 11008: 86 strips x 3) is a second round
   double us = ((mblocks == 2 || mblocks == 3) ? 10.6 : 9.0 + 2.0 * mblocks) + per_block * passes;
   if ((long long)((N + 127) / 128) * mblocks > 256) us *= 1.35;
-  // narrow layers (N <= 2048) at 129 ... 256 tokens: few strips, so the 64-token m-blocks x K slices of this kernel still fill the chip where the
-  // 128-token panel shapes cannot (N = 1024, K = 4096 at 256 tokens: 13.7 us against 16.6 panel / 19.2 tiled, per-group 15.1 against 18.0;
-  // profiles/r04_dispatch_check_merged.txt) -- the line above, fitted on the BASELINE layer, read 25 us there
-  if (N <= 2048 && mblocks >= 3) us = 11.0 + (double)N * K / 2.0 / 5.0e6 * passes;
   if (mblocks == 1 && M > 32) {
     // 33 ... 64 tokens, refitted over ten layer shapes in both modes (round 4, profiles/r04_dispatch_check_final*.txt, r04_dispatch_check_m64.txt:
     // 11.8 ... 43.1 us): per token count a line in the weight bytes (no floor: the 8 MB layers sit ON the line) -- fixed part 10.3 -> 12.2 us and
@@ -814,6 +839,8 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
       // launch (N = 18944, K = 3584 at 16 tokens: 10.9 us unsplit, 14.9 in two slices; N = 16384, K = 4096: 11.5 / 12.7; profiles/r04_stream_ksplit_wide_n.txt)
       if (mt == 1 && base >= 128) ksplit = 1;
       ksplit = clampi(ksplit, 1, KS / (2 * waves) > 0 ? KS / (2 * waves) : 1);
+      // 65 ... 256 tokens on layers up to ~40 MB: the split the loop model is fastest with (see stream_mid_estimate)
+      if (mt == 4 && mblocks >= 2 && mblocks <= 4 && (double)N * K / 2.0 / 5.0e6 < 8.0) stream_mid_estimate(M, N, K, grouped, KS / (2 * waves) > 0 ? KS / (2 * waves) : 1, &ksplit);
     }
     ksplit = clampi(ksplit, 1, KS);
     if (!have_scratch) ksplit = 1;

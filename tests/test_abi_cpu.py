@@ -217,6 +217,12 @@ def test_dispatch_of_the_baseline_sweep(L):
     # with 5); per-group decode on a wide layer is the column kernel's (N = 20480, K = 7168: 21.1 vs 24.9 us -- the unsplit stream slice is re-quantiser-bound)
     p = _lib.plan(16, 7168, 20480, -1, 16)
     assert (p["kernel"], p["ksplit"]) == (1, 4), p
+    # 65 ... 256 tokens on layers up to ~40 MB: the stream kernel's split comes from its loop model, not from "fill 256 workgroups" -- short-K layers stay whole
+    # (N = 8192, K = 3072 at 128 tokens: 15.7 us unsplit against 19.4 in two slices, profiles/r04_stream_panel_ksplit.txt), long-K ones are still split
+    p = _lib.plan(128, 8192, 3072, -1, 16)
+    assert (p["kernel"], p["ksplit"]) == (1, 1), p
+    p = _lib.plan(128, 8192, 8192, -1, 16)
+    assert (p["kernel"], p["ksplit"]) == (1, 2), p
     assert _lib.plan(1, 20480, 7168, 128, 16)["kernel"] == 3
     p = _lib.plan(128, N, K, -1, 16)
     assert (p["kernel"], p["mt"], p["ksplit"]) == (4, 8, 4)
