@@ -90,7 +90,11 @@ typedef struct qqq_tune {
   int pw;      /* tiled, wide: weight strips per XCD panel of the tile order (4, 8, 16, 32); panel (bm = 256, mt = 8):
                   32-column sets per wave (1, or 2 = 4 waves x 64 columns x 2 k-groups); 0 auto            */
   int nslots;  /* out (qqq_w4a8_plan only): tile-sized slots of C used by the tiled in-launch split-K  */
-  int reserved[1];
+  int split_m; /* M split (automatic dispatch only; rows are independent): a token count one past a whole number of tiles / rounds of the wide
+                  kernel is run as two launches on the same stream -- rows [0, split_m), then the remainder as a call of its own -- when the
+                  cost models price the pair at least 7 % below the single launch (N = 8192, K = 21760: 4097 tokens 624 -> 464 us).
+                  in: -1 = never split this call, 0 = automatic.  out (qqq_w4a8_plan): the first launch's rows, 0 = one launch;
+                  the other out fields then describe the plan of the WHOLE call, which is not the one that runs           */
 } qqq_tune_t;
 
 /* As qqq_w4a8_gemm; `tune` may be NULL; if `acc_out` != NULL the raw int32 accumulators

@@ -16,7 +16,7 @@ class QQQTune(ctypes.Structure):
         ("kernel", ctypes.c_int), ("ksplit", ctypes.c_int), ("waves", ctypes.c_int),
         ("fused", ctypes.c_int), ("bm", ctypes.c_int), ("glds", ctypes.c_int),
         ("pf", ctypes.c_int), ("stages", ctypes.c_int), ("mt", ctypes.c_int), ("pw", ctypes.c_int),
-        ("nslots", ctypes.c_int), ("reserved", ctypes.c_int * 1),
+        ("nslots", ctypes.c_int), ("split_m", ctypes.c_int),
     ]
 
 

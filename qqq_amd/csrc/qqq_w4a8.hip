@@ -675,9 +675,10 @@ struct Plan {
 };
 
 static Plan make_plan(const int M, const int N, const int K, const bool grouped, const int max_par,
-                      const bool have_C, const bool have_ws, qqq_tune_t t) {
+                      const bool have_C, const bool have_ws, qqq_tune_t t, double* est_out = nullptr) {
   Plan pl;
   memset(&pl, 0, sizeof(pl));
+  double est = -1.0;  // the chosen family's modelled time (us) when the choice is the models' (automatic dispatch); -1 otherwise
   const long long cap_rows = (long long)(max_par > 0 ? max_par : 0) * 64;  // rows of C we may use
   const bool have_scratch = have_C && cap_rows > 0;
   const void* workspace = have_ws ? reinterpret_cast<const void*>(1) : nullptr;
@@ -703,6 +704,7 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
                         (grouped ? (M <= 32 && col_cheaper) : (M <= 8 || (M <= 32 && col_cheaper)));
     if (column) kernel = 3;
     else kernel = (M <= 128 || (K % 128) != 0) ? 1 : 2;
+    if (column_ok && M <= 32) est = column ? column_small_estimate(M, N, K, grouped) : stream_small_estimate(M, N, K, grouped);
     // Above the decode regime the family is picked by the three cost models.  The panel kernel is also the MFMA path
     // with LDS-shared activations for K % 128 == 64 at any m (the tiled kernel needs 128-k blocks).
     if (column_ok && !column && M > 32) {
@@ -713,6 +715,9 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
       const double e_tiled = ((K % 128) == 0 && M > 64) ? tiled_estimate(M, N, K, grouped, have_scratch, cap_rows, cap_tk, false, &tbm, &tks) : 1e30;
       int wks = 1, wmt = 16, wbn = 256;
       const double e_wide = (M > 256) ? wide_estimate(M, N, K, grouped, have_scratch && have_ws, cap_rows, cap_tk, &wks, &wmt, &wbn) : 1e30;
+      est = e_wide < e_panel ? e_wide : e_panel;
+      if (e_stream < est) est = e_stream;
+      if (e_tiled < est) est = e_tiled;
       if (e_wide < e_panel && e_wide < e_stream && e_wide < e_tiled) {
         kernel = 5;
         // (the K split was costed for the model's own tile shape: a caller who pins mt / bm gets one slice unless it asks)
@@ -731,6 +736,7 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
       }
     }
   }
+  if (est_out) *est_out = est;
   if ((kernel == 3 || kernel == 4 || kernel == 5) && !column_ok) kernel = 1;
   if (kernel == 5 && (K % 128) != 0) kernel = 4;                        // whole 128-k stages only
   if (kernel == 5 && (long long)N * K / 2 >= (1ll << 32)) kernel = 2;  // 32-bit offsets into the packed weights
@@ -911,6 +917,38 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
   return pl;
 }
 
+// ---- M split (rows are independent).  A token count one past a whole number of rounds of 256 x 256 tiles costs a partial extra round of the wide
+// kernel: N = 8192, K = 21760: 4096 tokens 451 us, 4097 tokens 624 us -- and 464 us as 4096 + 1 tokens in two launches on the same stream; 2049 tokens
+// 341 -> 240 us; N = 4096, K = 11008 at 4100 tokens 188 -> 134 us (profiles/r04_ragged_m.txt).  For the automatic dispatch, when the whole call is the
+// wide kernel's: the rows that fill whole tiles (or whole rounds) go first, the remainder (at most 512 tokens) follows as a call of its own, if the
+// models price the pair at least 7 % below the single launch.  Returns the first launch's rows, 0 = no split.
+static int choose_split(const int M, const int N, const int K, const bool grouped, const int max_par, const bool have_C, const bool have_ws,
+                        const qqq_tune_t& t, const Plan& pl, const double est_whole) {
+  if (t.split_m < 0 || t.kernel != 0 || t.mt != 0 || t.bm != 0 || t.ksplit > 0 || pl.kernel != 5 || est_whole <= 0.0) return 0;
+  const int rows = 16 * pl.mt;
+  const long long tiles_n = (N + pl.bm - 1) / pl.bm;
+  const int cus = device_cus() > 0 ? device_cus() : 256;
+  int cand[2] = {(M / rows) * rows, 0};
+  const long long tiles = (long long)((M + rows - 1) / rows) * tiles_n;
+  if (tiles > cus) cand[1] = (int)((tiles / cus) * cus / tiles_n) * rows;  // the m-blocks that whole rounds cover
+  int best_m0 = 0;
+  double best = 0.93 * est_whole;
+  qqq_tune_t tn = t;
+  tn.split_m = -1;
+  for (int c = 0; c < 2; ++c) {
+    const int M0 = cand[c];
+    if (M0 <= 0 || M0 >= M || M - M0 > 512 || (c == 1 && M0 == cand[0])) continue;
+    double e0 = -1.0, er = -1.0;
+    (void)make_plan(M0, N, K, grouped, max_par, have_C, have_ws, tn, &e0);
+    (void)make_plan(M - M0, N, K, grouped, max_par, have_C, have_ws, tn, &er);
+    if (e0 > 0.0 && er > 0.0 && e0 + er < best) {
+      best = e0 + er;
+      best_m0 = M0;
+    }
+  }
+  return best_m0;
+}
+
 extern "C" int qqq_w4a8_plan(int prob_m, int prob_n, int prob_k, int groupsize, int max_par, int have_scratch,
                              int have_workspace, const qqq_tune_t* tune, qqq_tune_t* plan_out) {
   g_err[0] = 0;
@@ -921,8 +959,10 @@ extern "C" int qqq_w4a8_plan(int prob_m, int prob_n, int prob_k, int groupsize, 
   qqq_tune_t t;
   memset(&t, 0, sizeof(t));
   if (tune) t = *tune;
-  const Plan pl = make_plan(prob_m, prob_n, prob_k, groupsize != -1, max_par, have_scratch != 0, have_workspace != 0, t);
+  double est = -1.0;
+  const Plan pl = make_plan(prob_m, prob_n, prob_k, groupsize != -1, max_par, have_scratch != 0, have_workspace != 0, t, &est);
   memset(plan_out, 0, sizeof(*plan_out));
+  plan_out->split_m = choose_split(prob_m, prob_n, prob_k, groupsize != -1, max_par, have_scratch != 0, have_workspace != 0, t, pl, est);
   plan_out->kernel = pl.kernel;
   plan_out->ksplit = pl.ksplit;
   plan_out->fused = pl.fused;
@@ -963,7 +1003,20 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
   memset(&t, 0, sizeof(t));
   if (tune) t = *tune;
   const int M = prob_m, N = prob_n, K = prob_k;
-  const Plan pl = make_plan(M, N, K, grouped, max_par, C != nullptr, workspace != nullptr, t);
+  double est = -1.0;
+  const Plan pl = make_plan(M, N, K, grouped, max_par, C != nullptr, workspace != nullptr, t, &est);
+  if (const int M0 = choose_split(M, N, K, grouped, max_par, C != nullptr, workspace != nullptr, t, pl, est)) {
+    // two launches on the same stream, C / workspace shared (each launch leaves the workspace zero); K % 64 == 0 and N % 64 == 0 keep every
+    // offset pointer 16-byte aligned
+    qqq_tune_t tn = t;
+    tn.split_m = -1;
+    const int rc0 = qqq_w4a8_gemm_ex(A, B, C, D, s1, s2, s3, M0, N, K, workspace, groupsize, dev, stream, thread_k, thread_n, sms, max_par, &tn,
+                                     acc_out, bias);
+    if (rc0 != QQQ_OK) return rc0;
+    return qqq_w4a8_gemm_ex(static_cast<const int8_t*>(A) + (size_t)M0 * K, B, C, static_cast<_Float16*>(D) + (size_t)M0 * N,
+                            static_cast<const float*>(s1) + M0, s2, s3, M - M0, N, K, workspace, groupsize, dev, stream, thread_k, thread_n, sms,
+                            max_par, &tn, acc_out ? acc_out + (size_t)M0 * N : nullptr, bias);
+  }
 
   LaunchArgs a;
   a.A = static_cast<const int8_t*>(A);

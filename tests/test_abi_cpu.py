@@ -221,6 +221,12 @@ def test_dispatch_of_the_baseline_sweep(L):
     # (N = 8192, K = 3072 at 128 tokens: 15.7 us unsplit against 19.4 in two slices, profiles/r04_stream_panel_ksplit.txt), long-K ones are still split
     p = _lib.plan(128, 8192, 3072, -1, 16)
     assert (p["kernel"], p["ksplit"]) == (1, 1), p
+    # M split (rows are independent; profiles/r04_ragged_m.txt): a token count one past whole tiles / rounds of the wide kernel runs as two launches --
+    # 4097 tokens 624 us in one launch, 464 us as 4096 + 1 -- where the models price the pair 7 % below the single launch, and only there
+    assert [_lib.plan(m, N, K, -1, 16)["split_m"] for m in (4096, 4097, 4224, 4352, 2049, 1025, 8200, 5000)] == [0, 4096, 4096, 4096, 2048, 1024, 8192, 0]
+    assert _lib.plan(4097, N, K, 128, 16)["split_m"] == 4096 and _lib.plan(4097, N, K, -1, 16, tune=dict(split_m=-1))["split_m"] == 0
+    assert _lib.plan(8200, 11008, 4096, -1, 16)["split_m"] == 0 and _lib.plan(4100, 4096, 11008, -1, 16)["split_m"] == 4096   # 43 strips: no whole rounds to keep
+    assert _lib.plan(4097, N, K, -1, 16, tune=dict(kernel=5))["split_m"] == 0                                                # a forced family is never split
     p = _lib.plan(128, 8192, 8192, -1, 16)
     assert (p["kernel"], p["ksplit"]) == (1, 2), p
     assert _lib.plan(1, 20480, 7168, 128, 16)["kernel"] == 3

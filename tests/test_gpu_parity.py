@@ -590,6 +590,39 @@ def test_tile_walk_three_tiles_per_workgroup_every_stage_phase(dev):
                 assert ulp_distance(Db, eDb) == 0, (grouped, K, tune)
 
 
+def test_m_split_of_ragged_token_counts(dev):
+    """A token count one past a whole number of tiles / rounds of the wide kernel runs as TWO launches (rows [0, split_m) by the wide kernel, the
+    remainder as a call of its own -- column, stream or panel kernel --; include/qqq_amd.h `split_m`): int32 accumulators and fp16 outputs (with a bias)
+    against the oracle over all rows, bit-identical to the unsplit launch of the same call, workspace zero afterwards; the plan must really be split."""
+    from oracle import c_oracle as C
+    from oracle import qqq_ref as R
+    from qqq_amd import _lib
+
+    rng = np.random.default_rng(11)
+    for (M, N, K, grouped) in ((4099, 4096, 1024, False), (4200, 4096, 2048, True), (1030, 8192, 2048, False), (2051, 8192, 1024, True)):
+        gs = 128 if grouped else -1
+        pl = _lib.plan(M, N, K, gs, 16)
+        assert pl["kernel"] == 5 and 0 < pl["split_m"] < M and pl["split_m"] % 256 == 0, pl
+        assert _lib.plan(M, N, K, gs, 16, tune=dict(split_m=-1))["split_m"] == 0
+        codes = rng.integers(0 if grouped else -8, 16 if grouped else 8, size=(K, N)).astype(np.int8)
+        B = R.pack_codes(codes, grouped)
+        s2 = rng.random((1, N), dtype=np.float32) * 2e-4 + 1e-5
+        s3 = (rng.random((K // 128, N), dtype=np.float32) * 15 + 0.5).astype(np.float16) if grouped else None
+        bias = (rng.standard_normal(N) * 0.1).astype(np.float16)
+        h = GemmHarness(B, s2, s3, dev)
+        A = rng.integers(-128, 128, size=(M, K), dtype=np.int8)
+        s1 = rng.random((M, 1), dtype=np.float32) * 0.05 + 0.001
+        eD, eacc = C.qqq_gemm(A, B, s1, s2, s3, return_acc=True)
+        eDb = (torch.from_numpy(eD.copy()) + torch.from_numpy(bias)).numpy()
+        D, acc = h.run(A, s1, None)                        # automatic dispatch: the split
+        assert np.array_equal(acc, eacc), (M, N, K, grouped)
+        assert ulp_distance(D, eD) == 0, (M, N, K, grouped)
+        Db, _ = h.run(A, s1, None, want_acc=False, bias=bias)
+        assert ulp_distance(Db, eDb) == 0, (M, N, K, grouped)
+        D1, acc1 = h.run(A, s1, dict(split_m=-1))          # the same call in one launch
+        assert np.array_equal(acc1, eacc) and np.array_equal(D1.view(np.uint16), D.view(np.uint16)), (M, N, K, grouped)
+
+
 def test_every_variant_under_load(dev):
     """Every tuning variant, repeatedly, while a second stream keeps the chip busy with other GEMMs of mixed weight (so
     that workgroups of different kernels share CUs and the waves of a workgroup drift apart): results must equal the
