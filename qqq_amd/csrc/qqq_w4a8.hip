@@ -920,8 +920,17 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
 // ---- M split (rows are independent).  A token count one past a whole number of rounds of 256 x 256 tiles costs a partial extra round of the wide
 // kernel: N = 8192, K = 21760: 4096 tokens 451 us, 4097 tokens 624 us -- and 464 us as 4096 + 1 tokens in two launches on the same stream; 2049 tokens
 // 341 -> 240 us; N = 4096, K = 11008 at 4100 tokens 188 -> 134 us (profiles/r04_ragged_m.txt).  For the automatic dispatch, when the whole call is the
-// wide kernel's: the rows that fill whole tiles (or whole rounds) go first, the remainder (at most 512 tokens) follows as a call of its own, if the
+// wide kernel's: the rows that fill whole tiles (or whole rounds) go first, the remainder (at most 2048 tokens) follows as a call of its own, if the
 // models price the pair at least 7 % below the single launch.  Returns the first launch's rows, 0 = no split.
+// (the largest remainder that is tried; QQQ_AMD_SPLIT_CAP overrides it for measurements -- 512 against 4096 on five layer shapes, profiles/r04_ragged_m.txt:
+// the larger remainders gain 5 ... 13 % wherever the models choose them and lose nowhere)
+static int split_remainder_cap() {
+  static const int cap = [] {
+    const char* e = getenv("QQQ_AMD_SPLIT_CAP");
+    return e ? atoi(e) : 2048;
+  }();
+  return cap;
+}
 static int choose_split(const int M, const int N, const int K, const bool grouped, const int max_par, const bool have_C, const bool have_ws,
                         const qqq_tune_t& t, const Plan& pl, const double est_whole) {
   if (t.split_m < 0 || t.kernel != 0 || t.mt != 0 || t.bm != 0 || t.ksplit > 0 || pl.kernel != 5 || est_whole <= 0.0) return 0;
@@ -937,7 +946,7 @@ static int choose_split(const int M, const int N, const int K, const bool groupe
   tn.split_m = -1;
   for (int c = 0; c < 2; ++c) {
     const int M0 = cand[c];
-    if (M0 <= 0 || M0 >= M || M - M0 > 512 || (c == 1 && M0 == cand[0])) continue;
+    if (M0 <= 0 || M0 >= M || M - M0 > split_remainder_cap() || (c == 1 && M0 == cand[0])) continue;
     double e0 = -1.0, er = -1.0;
     (void)make_plan(M0, N, K, grouped, max_par, have_C, have_ws, tn, &e0);
     (void)make_plan(M - M0, N, K, grouped, max_par, have_C, have_ws, tn, &er);
