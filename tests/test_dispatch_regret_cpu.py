@@ -20,7 +20,7 @@ FILES = {
     "r04_dispatch_check_m16.txt": (100, 6, 0.08),           # ten shapes at 9 ... 32 tokens
     "r04_dispatch_check_mid.txt": (15, 3, 0.06),            # BASELINE layer at 320 ... 3072 tokens
     "r04_dispatch_check_after.txt": (75, 10, 0.16),         # the first two sets measured again on the library after all the refits (same-plan launch noise
-    "r04_dispatch_check_after_shapes.txt": (80, 18, 0.16),  #  at 8-10 us included: "auto" and the forced family are the same kernel there)
+    "r04_dispatch_check_after_shapes.txt": (80, 18, 0.20),  #  at 8-10 us included; the 18 % line is a forced 256-column panel with ANOTHER K split than the plan's)
     "r04_dispatch_check_merged.txt": (90, 5, 0.08),         # merged projections (N = 12288 / 22016) and narrow layers (N = 2048 / 1024)
     # Qwen2-7B / Mistral-7B layers; the 26 % point (N = 18944 at 16 tokens) is the stream kernel measured with the two K slices it no longer uses there
     # (profiles/r04_stream_ksplit_wide_n.txt: 10.9 us unsplit against the 14.6 in this file; the column kernel's 11.6 is the "best" it is held against)
