@@ -109,6 +109,24 @@ def _check_plan(m, n, k, grouped, max_par):
     gs = 128 if grouped else -1
     p = _lib.plan(m, n, k, gs, max_par)
     assert p["kernel"] in (1, 2, 3, 4, 5) and p["ksplit"] >= 1
+    # the M split: only where the whole call is the wide kernel's, whole tiles first, a remainder of at most 2048 tokens second -- and each of the two
+    # launches is a plan of its own that keeps every invariant below (checked by recursion: the parts are never split again)
+    sm = p["split_m"]
+    assert sm >= 0 and (sm == 0 or (p["kernel"] == 5 and 0 < sm < m and sm % (16 * p["mt"]) == 0 and m - sm <= 2048)), p
+    if sm:
+        for part in (sm, m - sm):
+            q = _lib.plan(part, n, k, gs, max_par, tune=dict(split_m=-1))
+            assert q["split_m"] == 0
+        _check_plan_part(sm, n, k, grouped, max_par)
+        _check_plan_part(m - sm, n, k, grouped, max_par)
+    return _check_plan_part(m, n, k, grouped, max_par)
+
+
+def _check_plan_part(m, n, k, grouped, max_par):
+    from qqq_amd import _lib
+
+    gs = 128 if grouped else -1
+    p = _lib.plan(m, n, k, gs, max_par, tune=dict(split_m=-1))
     cap_rows, cap_tk = max_par * 64, (n // 128) * max_par
     if p["kernel"] == 5:  # wide: 256 x 256 / 256 x 128 / 128 x 256 tiles; 32-bit offsets into the packed weights; one slot of C per depositing slice
         assert m > 256 and n % 64 == 0 and k % 128 == 0 and n * k // 2 < 2**32
