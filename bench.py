@@ -380,6 +380,113 @@ def cpu_model_name():
     return "unknown"
 
 
+def _r(x, sig=5):
+    """floats to `sig` significant digits (the printed line is bounded; the side file keeps full precision)"""
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, float):
+        return float(f"{x:.{sig}g}")
+    if isinstance(x, dict):
+        return {k: _r(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, sig) for v in x]
+    return x
+
+
+LINE_LIMIT = 4000  # bytes; the driver keeps an 8 KB stdout tail and parses the LAST line (round 4's 21 KB line was unreadable)
+
+
+def compact_line(result):
+    """The ONE JSON line printed on stdout: the contract's keys, `roofline` / `roofline_hbm` / `cpu_baseline` with numbers only,
+    one (us_median, roof_frac_median, speedup) triple per sweep point and mode, the configs[3] sums.  Everything else (per-layer
+    Llama table, probe rungs, notes, clocks' raw text, spreads) goes to the side file named in `detail`."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "timed_region_ms", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data")
+    out = {k: result[k] for k in keep if k in result}
+    cfg = result.get("config", {})
+    out["config"] = {"workload": "qqq_gemm per-channel sweep M in {1,16,128,1024,4096} N=8192 K=21760 (configs[1]); step = the 5 calls",
+                     "weights": cfg.get("weights_short", "5 rotating 89 MB int4 buffers, GPTQ-style N(0,0.02^2)"),
+                     "launch": cfg.get("launch_short", "eager"), "parallelism": cfg.get("parallelism_short", cfg.get("parallelism", ""))}
+    for key in ("roofline", "roofline_hbm"):
+        r = result.get(key)
+        if r:
+            out[key] = {k: r.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes", "avg_launch_us")}
+            if key == "roofline" and isinstance(r.get("sustained_on_random_int8"), dict):
+                out[key]["sustained_16x16x64_tops"] = r["sustained_on_random_int8"].get("mfma_16x16x64_only_tops")
+    for key in ("per_m", "per_m_g128"):
+        pm = result.get(key)
+        if isinstance(pm, dict) and "error" not in pm:
+            out[key] = {m: {"us": e.get("us_median"), "frac": e.get("roof_frac_median"), "roof": e.get("roof"), "kernel": e.get("kernel"),
+                            "ksplit": e.get("ksplit"), "x_fp16": e.get("speedup_vs_fp16")} for m, e in pm.items()}
+        elif pm:
+            out[key] = pm
+    ll = result.get("llama7b")
+    if isinstance(ll, dict):
+        if "error" in ll:
+            out["llama7b"] = ll
+        else:
+            o = {}
+            for blk, short in (("sum_of_7_linears", "sum7"), ("sum_of_4_merged_linears", "sum4_merged")):
+                for mode, per in (ll.get(blk) or {}).items():
+                    o.setdefault(short, {})[mode] = {m: {"us": e["quantlinear_us"], "x_fp16": e["speedup"]} for m, e in per.items()}
+            q = {}
+            for mode, layers in (ll.get("layers") or {}).items():
+                e = layers.get("q_proj", {}).get("1024")
+                if e:
+                    q[mode] = {"quantlinear_us": e["quantlinear_us"], "gemm_only_us": e["gemm_only_us"], "fp16_us": e["fp16_linear_us"]}
+            if q:
+                o["q_proj_1024"] = q
+            if ll.get("skipped"):
+                o["skipped"] = len(ll["skipped"])
+            out["llama7b"] = o
+    cb = result.get("cpu_baseline")
+    if cb:
+        out["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind")}
+        out["cpu_baseline"]["sample"] = "C oracle (OpenMP) M=64 N=8192 K=21760 per-channel, <= 12 s"
+        out["cpu_baseline"]["cpu_model"] = cb.get("cpu_model")
+        f = cb.get("torch_fp16_cpu_gemm", {})
+        if "per_m" in f:
+            out["cpu_baseline"]["torch_fp16_cpu_gemm_ms"] = {m: e["ms"] for m, e in f["per_m"].items()}
+            out["cpu_baseline"]["torch_threads"] = f.get("threads")
+    if "eager" in result:
+        out["eager_ms_per_step"] = result["eager"]["ms_per_step"]
+    if "step_us" in result:
+        out["step_us_median"] = result["step_us"]["median"]
+    ck = result.get("clocks")
+    if isinstance(ck, dict):
+        out["clocks_mhz"] = {"max": ck.get("max_mhz"), "busy": (ck.get("busy_sclk") or {}).get("mhz")}
+    mg = result.get("multi_gpu")
+    if mg:
+        out["multi_gpu"] = mg
+    for k in ("device", "detail"):
+        if k in result:
+            out[k] = result[k]
+    out = _r(out)
+    line = json.dumps(out, separators=(",", ":"))
+    if len(line) > LINE_LIMIT:  # never let an optional block make the line unreadable again: drop them in order of dispensability
+        for k in ("llama7b", "per_m_g128", "multi_gpu", "clocks_mhz", "per_m"):
+            if k in out:
+                out[k] = {"dropped": "see detail file"}
+                line = json.dumps(out, separators=(",", ":"))
+                if len(line) <= LINE_LIMIT:
+                    break
+    return line
+
+
+def write_detail(result):
+    """full result (every field of earlier rounds' line) -> gpurun_out/bench_detail.json (falls back to /tmp); returns the path"""
+    for d in (os.path.join(ROOT, "gpurun_out"), "/tmp"):
+        try:
+            os.makedirs(d, exist_ok=True)
+            path = os.path.join(d, f"bench_detail_n{result.get('n_gpus', 1)}.json")
+            with open(path, "w") as f:
+                json.dump(result, f, indent=1)
+            return os.path.relpath(path, ROOT) if path.startswith(ROOT) else path
+        except OSError:
+            continue
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -634,6 +741,9 @@ def main():
             "launch": (f"hipGraph replay: a one-step graph opens the timed region, then {spg} step(s) per graph (each sweep point bound to one of the rotating "
                        "weight buffers: a buffer is re-read only after the other four, 356 MB, have passed through the 256 MiB "
                        "Infinity Cache)") if graph is not None else "eager",
+            "weights_short": f"{NBUF} rotating 89 MB int4 buffers (cold Infinity Cache), " + ("GPTQ-style N(0,0.02^2)" if os.environ.get("QQQ_BENCH_WEIGHTS", "gptq") != "uniform" else "uniform int4 codes"),
+            "launch_short": (f"hipGraph replay, 1-step opener then {spg} steps/graph" if graph is not None and world == 1 else n_launch),
+            "parallelism_short": "single GPU" if world == 1 else f"M-sharded over {world} GPUs + RCCL all-gather (M >= {64*world})",
             "parallelism": "single GPU" if world == 1 else f"M-sharded over {world} GPUs + RCCL all-gather of fp16 shards (points with M >= {64*world}); step launch: {n_launch}",
         },
     }
@@ -780,7 +890,9 @@ def main():
         result["device"] = torch.cuda.get_device_name(dev)
 
     if rank == 0:
-        print(json.dumps(result))
+        result["detail"] = write_detail(result)
+        sys.stdout.flush()
+        print(compact_line(result), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
