@@ -34,7 +34,8 @@ def test_bench_two_ranks_one_gpu_gloo(dev):
     assert all(mg[k] > 0 for k in ("gemm_only_us", "allgather_only_us", "overlapped_us"))
     # what lets a reader verify an N > 1 line: the collective really spanned N ranks, over which backend, and how the step was launched
     assert out["multi_gpu"]["world_seen"] == 2 and out["multi_gpu"]["backend"] == "gloo" and out["multi_gpu"]["launch"] == "eager"
-    assert "step launch: eager" in out["config"]["parallelism"]
+    assert out["config"]["launch"] == "eager" and "M-sharded over 2 GPUs" in out["config"]["parallelism"]
+    assert len(line) < 4000  # the N > 1 line is bounded like the N = 1 one (the driver keeps an 8 KB tail)
 
 
 def test_bench_two_ranks_rccl_when_two_gpus():
