@@ -147,6 +147,16 @@ class Layer:
         return np.array(out[:], dtype=np.float64)
 
 
+FAMILY = {1: "stream", 2: "tiled", 3: "column", 4: "panel", 5: "wide"}
+
+
+def plan_label(pln):
+    """kernel family of a plan as a label; a call the library splits along M (plan field split_m: rows of the first of two launches) says so --
+    the other plan fields then describe the unsplit call, which is not what runs"""
+    name = FAMILY[pln["kernel"]]
+    return name if not pln.get("split_m") else f"{name}, two launches ({pln['split_m']} rows + the rest)"
+
+
 def graph_schedule(steps, spg):
     """Sizes (in steps) of the hipGraphs replayed in the timed region, in order: a one-step opener, the remainder of
     (steps - 1) % spg, then spg steps per graph; they add up to EXACTLY `steps`."""
@@ -785,7 +795,7 @@ def main():
                 "outliers_dropped": int(len(cold) - len(keep)),
                 "tops": algorithmic_ops(M, N_FULL, K_FULL) / us / 1e6,
                 "gbs": algorithmic_bytes(M, N_FULL, K_FULL) / us / 1e3,
-                "kernel": {1: "stream", 2: "tiled", 3: "column", 4: "panel", 5: "wide"}[pln["kernel"]], "ksplit": pln["ksplit"],
+                "kernel": plan_label(pln), "ksplit": pln["ksplit"],
             }
             # the roof that binds this point: HBM below the ridge (~629 op/B), MFMA above
             hbm_us = algorithmic_bytes(M, N_FULL, K_FULL) / PEAK_HBM_GBS / 1e3
@@ -807,7 +817,7 @@ def main():
         live, traffic_note = ({}, "skipped (--no-pmc)") if args.no_pmc else live_traffic()
         a = per_m["4096"]
         sus = sustained_matrix_rate(dev)
-        fam = a["kernel"]  # the family the dispatcher runs at M=4096 ("wide" since round 3; "panel" / "tiled" before)
+        fam = FAMILY[_L.plan(4096, N_FULL, K_FULL, -1, MAX_PAR)["kernel"]]  # the family the dispatcher runs at M=4096 ("wide" since round 3; "panel" / "tiled" before)
         result["roofline"] = {
             "kernel": f"qqq_{fam}_kernel (M=4096)", "bound": "mfma",
             # average launch duration: the MEDIAN of the event-timed launches (a trimmed mean reads a few % better; both are in per_m)
@@ -858,7 +868,7 @@ def main():
                 pln = _L.plan(M, N_FULL, K_FULL, 128, MAX_PAR)
                 pg[str(M)] = {"us": us, "us_median": float(np.median(cold)), "tops": algorithmic_ops(M, N_FULL, K_FULL) / us / 1e6,
                               "gbs": algorithmic_bytes(M, N_FULL, K_FULL, True) / us / 1e3,
-                              "kernel": {1: "stream", 2: "tiled", 3: "column", 4: "panel", 5: "wide"}[pln["kernel"]], "ksplit": pln["ksplit"],
+                              "kernel": plan_label(pln), "ksplit": pln["ksplit"],
                               "roof": "hbm" if hbm_us >= mfma_us else "mfma", "roof_frac": max(hbm_us, mfma_us) / us,
                               "roof_frac_median": max(hbm_us, mfma_us) / float(np.median(cold))}
                 if "fp16_gemm_us" in per_m[str(M)]:

@@ -8,8 +8,8 @@
  * All device pointers must be resident on device `dev`; every call only ENQUEUES work on
  * `stream` (a hipStream_t passed as void*; NULL = the legacy default stream) and returns without
  * synchronising -- the same contract as the reference (csrc/qqq_gemm.cu:1089).
- * The library allocates nothing, keeps no state between calls and frees nothing
- * (reference ownership rules: qlinear_marlin.py:97-133).
+ * The library allocates no device memory, frees nothing and keeps no state between calls (reference ownership rules:
+ * qlinear_marlin.py:97-133) -- except one CU-masked stream + two events per (device, sms) once a caller passes an `sms` cap.
  */
 #ifndef QQQ_AMD_H_
 #define QQQ_AMD_H_
@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define QQQ_AMD_ABI_VERSION 2
+#define QQQ_AMD_ABI_VERSION 3
 
 /* return codes; 0/1/2 are the reference's (csrc/qqq_gemm.cu:947-948, :1002-1003) */
 #define QQQ_OK 0
@@ -45,7 +45,9 @@ extern "C" {
  *   thread_k, thread_n, sms, max_par: reference tuning knobs (qqq_gemm.h:32-35).  thread_k/thread_n
  *       are validated exactly like the reference (is_valid_config, .cu:867-897; CALL_IF table
  *       :935-945) so the same calls fail with the same code, but they do not select CDNA4 tiles;
- *       sms is ignored; max_par bounds the rows of C that may be used (max_par*64).
+ *       sms (reference: the number of persistent threadblocks, -1 = every SM; csrc/qqq_gemm.cu:998) is a CU cap: with 0 < sms < the device's
+ *       CU count the call's kernels run on a library-owned CU-masked stream (sms CUs, spread over the XCDs) forked from / joined into `stream`
+ *       (INTEGRATION.md 3); max_par bounds the rows of C that may be used (max_par*64).
  * D[i,j] = fp16_rn( (f32_rn(sum_k A[i,k]*Wq[k,j]) * s2[j]) * s1[i] ), Wq as the reference kernel
  * forms it (csrc/qqq_gemm.cu:146-151, :167-210, :695-700).  int32 accumulators are bit-exact.
  */
@@ -95,6 +97,10 @@ typedef struct qqq_tune {
                   cost models price the pair at least 7 % below the single launch (N = 8192, K = 21760: 4097 tokens 624 -> 464 us).
                   in: -1 = never split this call, 0 = automatic.  out (qqq_w4a8_plan): the first launch's rows, 0 = one launch;
                   the other out fields then describe the plan of the WHOLE call, which is not the one that runs           */
+  int skew;    /* panel / wide, in-launch split-K: uneven K slices -- the LAST slice gets this many 128-k stages more than an even share (the
+                  others share what is left evenly), so that it arrives last and finds the other slices' deposits already in memory
+                  instead of waiting a hand-off latency for them (arrival order still decides who folds: a matter of time, never of
+                  correctness).  in: -1 = even slices, 0 = automatic, 1..63 stages.  out (qqq_w4a8_plan): the stages used.  ABI 3. */
 } qqq_tune_t;
 
 /* As qqq_w4a8_gemm; `tune` may be NULL; if `acc_out` != NULL the raw int32 accumulators

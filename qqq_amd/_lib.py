@@ -8,7 +8,7 @@ import os
 from . import build as _build
 
 _lib = None
-ABI_VERSION = 2  # QQQ_AMD_ABI_VERSION in include/qqq_amd.h
+ABI_VERSION = 3  # QQQ_AMD_ABI_VERSION in include/qqq_amd.h
 
 
 class QQQTune(ctypes.Structure):
@@ -16,7 +16,7 @@ class QQQTune(ctypes.Structure):
         ("kernel", ctypes.c_int), ("ksplit", ctypes.c_int), ("waves", ctypes.c_int),
         ("fused", ctypes.c_int), ("bm", ctypes.c_int), ("glds", ctypes.c_int),
         ("pf", ctypes.c_int), ("stages", ctypes.c_int), ("mt", ctypes.c_int), ("pw", ctypes.c_int),
-        ("nslots", ctypes.c_int), ("split_m", ctypes.c_int),
+        ("nslots", ctypes.c_int), ("split_m", ctypes.c_int), ("skew", ctypes.c_int),
     ]
 
 

@@ -42,6 +42,8 @@
 // with ONE packed-fp16 FMA exactly like dequant_per_group (csrc/qqq_gemm.cu:167-210).
 
 #include <cmath>
+#include <map>
+#include <mutex>
 #include <thread>
 #include <type_traits>
 #include <utility>
@@ -117,6 +119,41 @@ static int ref_shape_check(int m, int n, int k, int groupsize, int thread_k, int
   return QQQ_OK;
 }
 
+// `sms` as a CU cap (the reference launches `sms` persistent threadblocks, csrc/qqq_gemm.cu:998, :1016-1036): the call's kernels run on a
+// library-owned stream created with a CU mask of `sms` CUs (spread evenly over the CU index space, hence over the XCDs), forked from and
+// joined back into the caller's stream with two events -- the caller sees the usual stream order and `sms` CUs' worth of occupancy, the
+// other CUs stay free for whatever else it runs (RCCL's kernels in the sharded sweep).  One stream + two events per (device, sms), created
+// on first use and kept for the life of the process; the fork / launch / join sequence of a call holds the entry's lock.
+// (Inside a hipGraph capture the fork / join are captured like any cross-stream dependency, but kernel nodes carry no CU mask: a
+// replayed graph is not capped.)
+struct MaskedStream {
+  hipStream_t s = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  std::mutex mu;
+};
+static MaskedStream* masked_stream(int dev, int sms, int cus) {
+  static std::mutex mu;
+  static std::map<std::pair<int, int>, MaskedStream*> cache;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = cache.find({dev, sms});
+  if (it != cache.end()) return it->second;
+  uint32_t mask[16] = {};
+  for (int i = 0, on = 0; i < cus && i < 512; ++i)  // CU i is enabled when the running share crosses an integer: `sms` of `cus`, evenly spread
+    if ((long long)(i + 1) * sms / cus > on) {
+      mask[i >> 5] |= 1u << (i & 31);
+      ++on;
+    }
+  MaskedStream* m = new MaskedStream;
+  if (hipExtStreamCreateWithCUMask(&m->s, (uint32_t)((cus + 31) / 32), mask) != hipSuccess ||
+      hipEventCreateWithFlags(&m->fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&m->join, hipEventDisableTiming) != hipSuccess) {
+    delete m;  // (a stream or event that was created stays with the runtime: this path is an out-of-resources error)
+    return nullptr;
+  }
+  cache[{dev, sms}] = m;
+  return m;
+}
+
 struct LaunchArgs {
   const int8_t* A;
   const unsigned char* B;
@@ -129,6 +166,7 @@ struct LaunchArgs {
   int* tickets;
   const _Float16* bias;
   int M, N, K;
+  int skew;    // panel: 128-k stages the last K slice gets on top of an even share (0 = even slices)
   int hflags;  // in-launch split-K hand-off switches (tune.fused bits 2 / 3 / 4): 1 = formal acquire fence, 2 = release on publish, 4 = never L2-local deposits
   hipStream_t stream;
 };
@@ -222,7 +260,7 @@ static hipError_t launch_panel_t(const LaunchArgs& a, int ksplit) {
   }
   dim3 grid((a.N + BN - 1) / BN, ksplit, (a.M + ROWS - 1) / ROWS);
   hipLaunchKernelGGL(kern, grid, dim3(64 * WN * KG), LDS, a.stream, a.A, a.B, a.C, a.D, a.s1, a.s2, a.s3, a.acc_out,
-                     a.tickets, a.bias, a.M, a.N, a.K, ksplit | (a.hflags << 16));
+                     a.tickets, a.bias, a.M, a.N, a.K, ksplit | ((a.hflags & 0xff) << 16) | ((ksplit > 1 ? a.skew & 0x3f : 0) << 24));
   return hipGetLastError();
 }
 
@@ -230,6 +268,9 @@ template <int MT, bool GROUPED, int PFS, int XL>
 static hipError_t launch_panel_shape(const LaunchArgs& a, int bn, int waves, int cw, int ksplit) {
   if constexpr (MT == 8 && PFS >= 3 && (PFS == XL || (PFS == 4 && XL == 2))) {  // 64 columns per wave (two k-groups of 4 waves)
     if (bn == 256 && cw == 2) return launch_panel_t<MT, GROUPED, 4, 2, PFS, XL, 2>(a, ksplit);
+    // (128-column strips as four waves x 64 columns x two k-groups -- one wave per SIMD, half the fragment reads and unpack work per MFMA --
+    //  were instantiated and measured in round 5: 46.1 vs 37.3 us at 128 tokens, 21.7 vs 16.5 on 4096 x 4096: nobody hides a lone
+    //  wave's stalls.  Not kept; profiles/r05_uneven_k_slices.txt has the lines.)
   }
   if (bn == 256) return launch_panel_t<MT, GROUPED, 8, 1, PFS, XL>(a, ksplit);
   if (waves == 4) return launch_panel_t<MT, GROUPED, 4, 1, PFS, XL>(a, ksplit);
@@ -339,17 +380,25 @@ static hipError_t launch_tiled(const LaunchArgs& a, bool grouped, int bm, int st
                  : launch_tiled_bm<false>(a, bm, stages, ksplit, nslots, pw);
 }
 
-// compute units of the current device (the persistent tile walk launches one workgroup per CU), cached per device
-static int device_cus() {
+// compute units of device `dev` (queried for THAT device, cached)
+static int device_cus_of(int dev) {
   static int cus[64] = {};
-  int cur = 0;
-  (void)hipGetDevice(&cur);
-  if (cur >= 0 && cur < 64 && cus[cur] > 0) return cus[cur];
+  if (dev >= 0 && dev < 64 && cus[dev] > 0) return cus[dev];
   int n = 0;
-  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, cur) != hipSuccess || n <= 0) n = 256;
-  if (cur >= 0 && cur < 64) cus[cur] = n;
+  if (dev < 0 || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  if (dev >= 0 && dev < 64) cus[dev] = n;
   return n;
 }
+// The CU count plans and launches of THIS call work with: qqq_w4a8_gemm_ex sets it from the device it was given (capped by the
+// reference's `sms` argument) before it plans, so the plan and the launch grid can never disagree; qqq_w4a8_plan -- pure host
+// logic, no HIP call -- plans for the MI355X's 256 (the persistent tile walk launches one workgroup per CU).
+static thread_local int t_call_cus = 256;
+static int device_cus() { return t_call_cus; }
+struct CallCus {
+  int prev;
+  explicit CallCus(int n) : prev(t_call_cus) { t_call_cus = n > 0 ? n : 256; }
+  ~CallCus() { t_call_cus = prev; }
+};
 
 // the persistent tile walk needs whole tiles (no K split), a K range longer than its prefetch leads and at least one tile per
 // workgroup of its grid (a multiple of 8: workgroup b lands on XCD b % 8)
@@ -377,7 +426,8 @@ static hipError_t launch_wide_t(const LaunchArgs& a, int pw, int ksplit) {
   const int tiles_m = (a.M + ROWS - 1) / ROWS, tiles_n = (a.N + BN - 1) / BN;
   const int grid = CHAIN ? (device_cus() & ~7) : tiles_m * tiles_n * ksplit;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, a.stream, a.A, a.B, a.C, a.D, a.s1, a.s2, a.s3,
-                     a.acc_out, a.tickets, a.bias, a.M, a.N, a.K, tiles_m, tiles_n, pw, ksplit | (a.hflags << 16));
+                     a.acc_out, a.tickets, a.bias, a.M, a.N, a.K, tiles_m, tiles_n, pw,
+                     ksplit | ((a.hflags & 0xff) << 16) | ((!CHAIN && ksplit > 1 ? a.skew & 0x3f : 0) << 24));
   return hipGetLastError();
 }
 
@@ -522,13 +572,14 @@ static double stream_mid_estimate(int M, int N, int K, bool grouped, int ks_cap,
 
 // stream: every 64-token m-block streams the whole weight matrix (the first from HBM, the others mostly from L2 /
 // Infinity Cache), plus launch, LDS reduce and the separate split-K reduce launch
-static double stream_estimate(int M, int N, int K, bool grouped) {
+static double stream_estimate(int M, int N, int K, bool grouped, bool have_scratch = true, long long cap_rows = 1 << 30) {
   double per_block = (double)N * K / 2.0 / 5.0e6;  // the weight matrix at ~5 TB/s
   if (per_block < 2.5) per_block = 2.5;
   const int mblocks = (M + 63) / 64;
   if (mblocks >= 2 && mblocks <= 4 && (double)N * K / 2.0 / 5.0e6 < 8.0) {
-    int ks;
-    return stream_mid_estimate(M, N, K, grouped, 8, &ks);
+    // (only splits the plan can realise: slabs need C, and ksplit x M rows of it)
+    int ks, ks_cap = have_scratch ? (int)(cap_rows / M < 8 ? cap_rows / M : 8) : 1;
+    return stream_mid_estimate(M, N, K, grouped, ks_cap < 1 ? 1 : ks_cap, &ks);
   }
   // measured: 2 / 3 / 4 m-blocks take 1.85 / 3.2 / 3.3 weight passes
   // (one m-block: 16 / 32 / 48 / 64 tokens measured at 0.6 / 0.8 / 1.0 / 1.2 -- the 16-token tiles of a block share the weights
@@ -663,6 +714,24 @@ static double wide_estimate(int M, int N, int K, bool grouped, bool have_scratch
   return best;
 }
 
+// panel, split K: stages the last slice gets on top of an even share (tune.skew = 0).  Measured (profiles/r05_uneven_k_slices.txt: N = 8192, K = 21760 at
+// 64 / 128 / 256 tokens, both modes, and 4096 x 4096 at 128 / 256): the best skew makes the last slice's extra loop time -- skew stages, plus the
+// skew / (ks - 1) stages every other slice is shorter by -- about the latency of a deposit (write-through drain + publish: ~1.6 us, + ~1.2 us per
+// 64 KiB of partial tile): 4 stages at 128 tokens (37.3 -> 36.1 us; per-group 3: 45.5 -> 43.4), 3 in two slices (256 tokens: 56.9 -> 54.4).  Less than
+// that is slower than even slices (the last slice arrives last but still waits), more only lengthens the longest slice.
+static int panel_auto_skew(int mt, int bn, bool grouped, int NST, int ksplit) {
+  (void)NST;
+  const double t_stage = ((mt == 8 && bn == 128) ? 0.506 : 0.13 + 0.042 * mt) * (bn == 256 ? 1.9 : 1.0) * (grouped ? (mt == 8 ? 1.45 : 1.6) : 1.0);
+  const double latency = 1.6 + 1.2 * (16.0 * mt * bn) / 16384.0;
+  const int sk = (int)(latency / (t_stage * ksplit / (ksplit - 1.0)) + 0.5);
+  return sk < 1 ? 1 : sk;
+}
+// wide, split K (256 KiB deposits, kept in the XCD's L2 when the slices share one): not measured yet -> even slices
+static int wide_auto_skew(int mt, int bn, bool grouped, int NST, int ksplit) {
+  (void)mt; (void)bn; (void)grouped; (void)NST; (void)ksplit;
+  return 0;
+}
+
 // The dispatch decision of one call, as plain data (pure host logic: also exported as qqq_w4a8_plan so
 // that it can be inspected and tested without a GPU).
 struct Plan {
@@ -672,6 +741,7 @@ struct Plan {
   int mt, waves, pf;      // stream
   int bm, stages, nslots, pw; // tiled
   int chain;                  // wide: 1 = persistent tile walk (one workgroup per CU walks its run of tiles)
+  int skew;                   // panel: extra 128-k stages of the last K slice
 };
 
 static Plan make_plan(const int M, const int N, const int K, const bool grouped, const int max_par,
@@ -709,16 +779,18 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
     // with LDS-shared activations for K % 128 == 64 at any m (the tiled kernel needs 128-k blocks).
     if (column_ok && !column && M > 32) {
       const long long cap_tk = have_ws ? (long long)(N / 128) * (max_par > 0 ? max_par : 0) : 0;
-      int pbn = 128, pks = 1, pcw = 1, tbm = 0, tks = 1;
+      int pbn = 128, pks = 1, pcw = 1;
       const double e_panel = ((long long)(M + 127) / 128 <= 65535) ? panel_estimate(M, N, K, grouped, have_scratch && have_ws, cap_rows, cap_tk, &pbn, &pks, &pcw) : 1e30;
-      const double e_stream = (M <= 256) ? stream_estimate(M, N, K, grouped) : 1e30;
-      const double e_tiled = ((K % 128) == 0 && M > 64) ? tiled_estimate(M, N, K, grouped, have_scratch, cap_rows, cap_tk, false, &tbm, &tks) : 1e30;
+      const double e_stream = (M <= 256) ? stream_estimate(M, N, K, grouped, have_scratch, cap_rows) : 1e30;
+      // (the tiled family -- round 1's LDS-tiled 32x32x32 kernel -- is no longer a candidate of the automatic dispatch: in the 903 measured
+      // dispatch points of round 4 it never won one (M = 4096: 585.9 vs 449.2 us).  It stays reachable through tune.kernel = 2 -- the
+      // differential fuzzers' independent reference -- and as the fallback for packed weights beyond 4 GB, where the wide kernel's 32-bit
+      // offsets end.)
       int wks = 1, wmt = 16, wbn = 256;
       const double e_wide = (M > 256) ? wide_estimate(M, N, K, grouped, have_scratch && have_ws, cap_rows, cap_tk, &wks, &wmt, &wbn) : 1e30;
       est = e_wide < e_panel ? e_wide : e_panel;
       if (e_stream < est) est = e_stream;
-      if (e_tiled < est) est = e_tiled;
-      if (e_wide < e_panel && e_wide < e_stream && e_wide < e_tiled) {
+      if (e_wide < e_panel && e_wide < e_stream) {
         kernel = 5;
         // (the K split was costed for the model's own tile shape: a caller who pins mt / bm gets one slice unless it asks)
         if (t.mt == 0 && t.bm == 0) {
@@ -726,13 +798,13 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
           t.bm = wbn;
           if (t.ksplit <= 0) t.ksplit = wks;
         }
-      } else if (e_panel <= e_stream && e_panel <= e_tiled) {
+      } else if (e_panel <= e_stream) {
         kernel = 4;
         if (t.bm == 0 && t.pw == 0 && t.mt == 0 && pcw == 2) t.pw = 2;
         if (t.bm == 0) t.bm = pbn;
         if (t.ksplit <= 0) t.ksplit = pks;
       } else {
-        kernel = (e_stream <= e_tiled) ? 1 : 2;
+        kernel = 1;
       }
     }
   }
@@ -758,12 +830,21 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
     const long long tl = (long long)((M + rows - 1) / rows) * ((N + pl.bm - 1) / pl.bm);
     ksplit = t.ksplit > 0 ? t.ksplit : 1;
     ksplit = clampi(ksplit, 1, (K / 128) / 4 > 0 ? (K / 128) / 4 : 1);
+    if (ksplit > 255) ksplit = 255;  // the arrival word's ticket field is 8 bits (the XCC nibbles sit above it; they are used up to 6 slices)
     if (!have_scratch || workspace == nullptr) ksplit = 1;
     const long long cap_tk = (long long)(N / 128) * (max_par > 0 ? max_par : 0);
     if (2 * tl > cap_tk) ksplit = 1;
     while (ksplit > 1 && tl * rows * pl.bm * (ksplit - 1) > cap_rows * (long long)N) --ksplit;
     pl.ksplit = ksplit;
     pl.fused = 1;
+    pl.skew = 0;
+    if (ksplit > 1) {  // uneven K slices (tune.skew: -1 never, 0 automatic, else stages): every slice keeps at least 4 stages
+      int sk = t.skew > 0 ? t.skew : (t.skew == 0 ? wide_auto_skew(pl.mt, pl.bm, grouped, K / 128, ksplit) : 0);
+      const int room = K / 128 - 4 * ksplit;
+      if (sk > room) sk = room;
+      if (sk > 63) sk = 63;
+      pl.skew = sk > 0 ? sk : 0;
+    }
     // the persistent tile walk (t.glds: 1 = never, 2 = whenever it applies, 0 = automatic); its ring depth is the mode's default
     pl.chain = (t.glds != 1 && wide_chain_ok(M, N, K, rows, pl.bm, ksplit) && (t.glds == 2 || wide_chain_pays(tl, K, pl.mt, pl.bm))) ? 1 : 0;
     if (pl.chain) pl.pf = grouped ? 8 : 4;
@@ -804,6 +885,15 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
     pl.pw = (cw2 && pl.pf >= 3 && pl.pf <= 4 && (pl.stages == pl.pf || (pl.pf == 4 && pl.stages == 2))) ? 2 : 1;
     pl.ksplit = ksplit;
     pl.fused = 1;
+    // uneven K slices (tune.skew: -1 never, 0 automatic, else stages): every slice keeps at least 4 stages
+    pl.skew = 0;
+    if (ksplit > 1) {
+      int sk = t.skew > 0 ? t.skew : (t.skew == 0 ? panel_auto_skew(mt, bn, grouped, NST, ksplit) : 0);
+      const int room = NST - 4 * ksplit;
+      if (sk > room) sk = room;
+      if (sk > 63) sk = 63;
+      pl.skew = sk > 0 ? sk : 0;
+    }
     return pl;
   }
 
@@ -852,7 +942,7 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
     if (!have_scratch) ksplit = 1;
     if (ksplit > 1 && (long long)ksplit * M > cap_rows) ksplit = (int)(cap_rows / M);
     if (ksplit < 1) ksplit = 1;
-    int fused = t.fused;
+    int fused = t.fused & 3;  // (bits 2.. are the in-launch hand-off switches of the other families)
     if (fused == 0) fused = 2;  // separate reduce launch measured ~2 us faster than the in-launch ticket path
     // tickets: one int per (m-block, strip); the reference guarantees n/128*max_par ints
     if ((fused == 1 || fused == 3) && (workspace == nullptr || (long long)mblocks * strips > (long long)(N / 128) * max_par))
@@ -927,9 +1017,21 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
 static int split_remainder_cap() {
   static const int cap = [] {
     const char* e = getenv("QQQ_AMD_SPLIT_CAP");
-    return e ? atoi(e) : 2048;
+    if (!e) return 2048;
+    char* end = nullptr;
+    const long v = strtol(e, &end, 10);
+    return (end == e || *end != 0 || v <= 0 || v > (1 << 20)) ? 2048 : (int)v;  // not a positive number: the default, not "never split"
   }();
   return cap;
+}
+// process-wide switches read once from the environment: bit 4 = QQQ_AMD_NO_LOCAL_DEPOSITS=1 (as tune.fused | 16: split-K deposits are always
+// written through -- the kill switch for the XCD-local hand-off, should a driver or partition mode change what HW_REG_XCC_ID / the L2 do)
+static int handoff_env_flags() {
+  static const int f = [] {
+    const char* e = getenv("QQQ_AMD_NO_LOCAL_DEPOSITS");
+    return (e && e[0] == '1') ? 4 : 0;
+  }();
+  return f;
 }
 static int choose_split(const int M, const int N, const int K, const bool grouped, const int max_par, const bool have_C, const bool have_ws,
                         const qqq_tune_t& t, const Plan& pl, const double est_whole) {
@@ -983,6 +1085,7 @@ extern "C" int qqq_w4a8_plan(int prob_m, int prob_n, int prob_k, int groupsize, 
   plan_out->glds = pl.kernel == 2 ? (pl.stages == 0 ? 2 : 1) : pl.kernel == 5 ? (pl.chain ? 2 : 1) : 0;
   plan_out->nslots = pl.nslots;
   plan_out->pw = pl.pw;
+  plan_out->skew = pl.skew;
   return QQQ_OK;
 }
 
@@ -991,7 +1094,6 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
                                 void* workspace, int groupsize, int dev, void* stream, int thread_k,
                                 int thread_n, int sms, int max_par, const qqq_tune_t* tune,
                                 int32_t* acc_out, const void* bias) {
-  (void)sms;
   g_err[0] = 0;
   const int rc = ref_shape_check(prob_m, prob_n, prob_k, groupsize, thread_k, thread_n);
   if (rc != QQQ_OK) return rc;
@@ -1012,6 +1114,14 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
   memset(&t, 0, sizeof(t));
   if (tune) t = *tune;
   const int M = prob_m, N = prob_n, K = prob_k;
+  // the device this call runs on decides the CU count the plan and the launch work with (not "the current device"); `sms`
+  // (reference: the number of persistent threadblocks, -1 = every SM) caps it
+  int cur_dev = dev;
+  if (dev < 0) (void)hipGetDevice(&cur_dev);
+  const int cus_dev = device_cus_of(cur_dev);
+  const bool capped = sms > 0 && sms < cus_dev;
+  CallCus call_cus(capped ? sms : cus_dev);
+  if (handoff_env_flags() & 4) t.fused |= 16;  // QQQ_AMD_NO_LOCAL_DEPOSITS=1: every split-K deposit is written through
   double est = -1.0;
   const Plan pl = make_plan(M, N, K, grouped, max_par, C != nullptr, workspace != nullptr, t, &est);
   if (const int M0 = choose_split(M, N, K, grouped, max_par, C != nullptr, workspace != nullptr, t, pl, est)) {
@@ -1042,6 +1152,7 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
   a.N = N;
   a.K = K;
   a.stream = static_cast<hipStream_t>(stream);
+  a.skew = pl.skew;
   a.hflags = (pl.kernel == 2 || pl.kernel == 4 || pl.kernel == 5) ? ((t.fused >> 2) & 7) : 0;
 
   DeviceGuard guard(dev);
@@ -1050,6 +1161,20 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
   if ((pl.kernel == 1 || pl.kernel == 3 || pl.kernel == 4) && (M + 16 * pl.mt - 1) / (16 * pl.mt) > 65535) {
     snprintf(g_err, sizeof(g_err), "m=%d exceeds the grid of the small-m kernels (forced by tune)", M);
     return QQQ_ERR_ARG;
+  }
+  // sms < CUs: the kernels of this call go to the CU-masked stream of (device, sms), between a fork from and a join into `stream`
+  MaskedStream* ms = nullptr;
+  std::unique_lock<std::mutex> ms_lock;
+  if (capped) {
+    ms = masked_stream(cur_dev, sms, cus_dev);
+    if (!ms) {
+      snprintf(g_err, sizeof(g_err), "sms=%d: could not create a CU-masked stream", sms);
+      return QQQ_ERR_HIP;
+    }
+    ms_lock = std::unique_lock<std::mutex>(ms->mu);
+    if ((e = hipEventRecord(ms->fork, a.stream)) != hipSuccess || (e = hipStreamWaitEvent(ms->s, ms->fork, 0)) != hipSuccess)
+      return fail_hip(e, "fork into the CU-masked stream");
+    a.stream = ms->s;
   }
   if (pl.kernel == 5) {
     e = launch_wide(a, grouped, pl.mt, pl.bm, pl.pf, pl.pw, pl.ksplit, pl.chain != 0);
@@ -1080,6 +1205,11 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
                        a.acc_out, a.bias, M, N, pl.ksplit);
     e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "qqq_reduce_kernel launch");
+  }
+  if (ms) {
+    hipStream_t caller = static_cast<hipStream_t>(stream);
+    if ((e = hipEventRecord(ms->join, ms->s)) != hipSuccess || (e = hipStreamWaitEvent(caller, ms->join, 0)) != hipSuccess)
+      return fail_hip(e, "join from the CU-masked stream");
   }
   return QQQ_OK;
 }

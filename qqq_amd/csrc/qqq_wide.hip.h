@@ -150,7 +150,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int K, const int tiles_m, const int tiles_n, const int PW, const int ksplit_hf) {
   // (hand-off switches ride in the upper half of the K-split argument -- tune.fused bits 2 / 3: 1 = the formal agent-scope ACQUIRE
   // fence in front of the fold, 2 = agent-scope RELEASE on the depositor's completion count; see qqq_common.hip.h)
-  const int ksplit = ksplit_hf & 0xffff, hflags = ksplit_hf >> 16;
+  // (bits 24..29: `skew`, the 128-k stages the LAST K slice gets on top of an even share, as in the panel kernel)
+  const int ksplit = ksplit_hf & 0xffff, hflags = (ksplit_hf >> 16) & 0xff, skew = (ksplit_hf >> 24) & 0x3f;
   static_assert(MT == 16 || MT == 8, "m-tiles of 16 tokens per wave (= per workgroup): 256 or 128 tokens");
   static_assert(HW == 2 || HW == 1, "a wave owns both 32-column halves of a 64-column group, or (128-column tiles) one");
   constexpr int ROWS = 16 * MT;
@@ -237,8 +238,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const unsigned rowbytes = (unsigned)N * 8u;
 
   // K slice [st0, st0 + NST) in 128-k stages (K % 128 == 0); steps and stages below are relative to it
-  const int st0 = (int)(((long long)(K >> 7) * sp) / ksplit);
-  const int NST = (int)(((long long)(K >> 7) * (sp + 1)) / ksplit) - st0;
+  // (uneven slices: the last one is `skew` stages longer, so that it arrives last and finds the other deposits complete)
+  const int NSE = (K >> 7) - skew;
+  const int st0 = (int)(((long long)NSE * sp) / ksplit);
+  const int NST = (sp == ksplit - 1 ? (K >> 7) : (int)(((long long)NSE * (sp + 1)) / ksplit)) - st0;
   const int KS = 2 * NST;                // 64-k steps
 
   // ---- per-lane sources ----

@@ -118,7 +118,7 @@ def qqq_gemm_ex(A, B, C, D, s1, s2, s3, workspace, thread_k=-1, thread_n=-1, sms
                 tune: Optional[dict] = None, acc_out: Optional[torch.Tensor] = None,
                 bias: Optional[torch.Tensor] = None) -> None:
     """qqq_gemm with tuning / debug hooks (tests, bench) and the fused fp16 bias epilogue.
-    `tune` keys: kernel, ksplit, waves, fused, bm, glds, pf, stages, mt, pw, split_m (include/qqq_amd.h)."""
+    `tune` keys: kernel, ksplit, waves, fused, bm, glds, pf, stages, mt, pw, split_m, skew (include/qqq_amd.h)."""
     L = _lib.lib()
     prob_m, prob_n, prob_k, groupsize = _check_common(A, B, C, D, s1, s2, s3, workspace, max_par)
     tn = None

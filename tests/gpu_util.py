@@ -79,13 +79,18 @@ def variants(M, K, N):
                   dict(kernel=4, bm=256, mt=8, pw=2, ksplit=2), dict(kernel=4, bm=256, mt=8, pw=2, stages=4, ksplit=2)]
         if nst >= 3:
             v += [dict(kernel=4, ksplit=3, mt=1), dict(kernel=4, bm=256, ksplit=3), dict(kernel=4, bm=256, mt=8, pw=2, pf=3, ksplit=3)]
+        # round 5: uneven K slices (the host keeps 4 stages per slice; -1 = even slices, 0 = the automatic skew)
+        if nst >= 9:
+            v += [dict(kernel=4, ksplit=2, skew=1), dict(kernel=4, mt=4, ksplit=2, skew=63), dict(kernel=4, ksplit=2, skew=-1)]
+        if nst >= 18:
+            v += [dict(kernel=4, ksplit=4, skew=2), dict(kernel=4, bm=256, ksplit=3, skew=5), dict(kernel=4, bm=256, mt=8, pw=2, ksplit=2, skew=3)]
     if N % 64 == 0:  # wide kernel: 256 tokens x 256 columns per workgroup, four 512-register waves, no split-K
         v += [dict(kernel=5), dict(kernel=5, pf=8), dict(kernel=5, pw=4), dict(kernel=5, mt=8), dict(kernel=5, mt=8, pf=4),
               dict(kernel=5, bm=128), dict(kernel=5, bm=128, pf=8, pw=16)]
         if K % 128 == 0 and K // 128 >= 8:  # in-launch split-K: row-major partial tiles in C, tickets in workspace
             v += [dict(kernel=5, ksplit=2), dict(kernel=5, mt=8, ksplit=2)]
         if K % 128 == 0 and K // 128 >= 12:
-            v += [dict(kernel=5, ksplit=3), dict(kernel=5, mt=8, ksplit=3, pf=8)]
+            v += [dict(kernel=5, ksplit=3), dict(kernel=5, mt=8, ksplit=3, pf=8), dict(kernel=5, ksplit=2, skew=3), dict(kernel=5, bm=128, ksplit=3, skew=1)]
     if K % 128 == 0:
         for bm in (64, 128, 256):
             v.append(dict(kernel=2, bm=bm, glds=2, ksplit=1))

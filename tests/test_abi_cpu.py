@@ -30,7 +30,7 @@ def test_exports_every_declared_symbol(L):
             "qqq_pack_int4", "qqq_unpack_int4", "qqq_amd_abi_version", "qqq_amd_last_error"} == names
     for n in names:
         assert hasattr(L, n), n
-    assert L.qqq_amd_abi_version() == 2
+    assert L.qqq_amd_abi_version() == 3
     # the operator library is the operator only: measurement loops and hardware probes live in the dev library
     for n in ("qqq_bench_gemm", "qqq_probe_mfma", "qqq_probe_glds", "qqq_probe_fill", "qqq_add_bias", "qqq_dev_bench_gemm"):
         assert not hasattr(L, n), n
@@ -327,7 +327,7 @@ def test_compiled_torch_binding_imports_and_keeps_the_error_contract():
     kb.build()
     kb.build_torch_ext()
     E = ops._ext()
-    assert E is not None and E.abi_version() == 2
+    assert E is not None and E.abi_version() == 3
     assert hasattr(torch.ops.qqq_amd_native, "qqq_gemm") and hasattr(torch.ops.qqq_amd_native, "dynamic_quant")
     A = torch.zeros((4, 128), dtype=torch.int8)
     B = torch.zeros((8, 256), dtype=torch.int32)
@@ -350,3 +350,57 @@ def test_compiled_torch_binding_imports_and_keeps_the_error_contract():
             assert msg in str(ei.value), (fn, msg, str(ei.value)[:200])
     with pytest.raises(RuntimeError, match="no CPU path"):
         E.dynamic_quant(torch.zeros((2, 64), dtype=torch.float16))
+
+
+def test_uneven_k_slices_in_the_plan():
+    """Round 5 (profiles/r05_uneven_k_slices.txt): with a split K the panel kernel gives its LAST slice `skew` stages more than an even share, so that it arrives
+    last and finds the other deposits complete.  Automatic where measured: 4 stages at 128 tokens on the BASELINE layer (3 per-group, 3 in two slices), never so
+    many that a slice keeps fewer than four stages, none without a split; tune.skew = -1 switches it off, a positive value pins it (clamped the same way)."""
+    from qqq_amd import _lib
+
+    N, K = 8192, 21760
+    p = _lib.plan(128, N, K, -1, 16)
+    assert (p["kernel"], p["ksplit"], p["skew"]) == (4, 4, 4), p
+    assert _lib.plan(128, N, K, 128, 16)["skew"] == 3
+    p = _lib.plan(256, N, K, -1, 16, tune=dict(kernel=4))   # 128-column strips, two m-blocks, two slices
+    assert (p["kernel"], p["bm"], p["ksplit"], p["skew"]) == (4, 128, 2, 3), p
+    assert _lib.plan(128, N, K, -1, 16, tune=dict(skew=-1))["skew"] == 0 and _lib.plan(128, N, K, -1, 16, tune=dict(skew=9))["skew"] == 9
+    assert _lib.plan(128, N, K, -1, 16, tune=dict(kernel=4, ksplit=1))["skew"] == 0                     # nothing to hand off
+    assert _lib.plan(128, N, K, -1, 16, have_scratch=False)["skew"] == 0
+    # short K: 4096 x 4096 at 128 tokens = 32 stages in 4 slices -> at most 32 - 16 stages to give away; K = 2048: 16 stages, nothing
+    p = _lib.plan(128, 4096, 4096, -1, 16, tune=dict(kernel=4, ksplit=4, skew=63))
+    assert (p["ksplit"], p["skew"]) == (4, 16), p
+    p = _lib.plan(128, 4096, 2048, -1, 16, tune=dict(kernel=4, ksplit=4, skew=5))
+    assert p["skew"] == 0 and p["ksplit"] == 4, p
+    # the slices as the kernel cuts them (qqq_panel.hip.h): every stage exactly once, the last slice the longest by `skew`
+    for nst, ks, skew in ((170, 4, 4), (170, 2, 3), (32, 4, 3), (85, 3, 7), (171, 4, 0)):
+        cuts = [(nst - skew) * sp // ks for sp in range(ks)] + [nst]
+        lens = [cuts[i + 1] - cuts[i] for i in range(ks)]
+        assert sum(lens) == nst and min(lens) >= 4 and lens[-1] - max(lens[:-1]) in (skew, skew - 1, skew + 1), (nst, ks, skew, lens)
+    # the wide kernel takes the same knob (not automatic: not measured)
+    p = _lib.plan(1024, N, K, 128, 16)
+    assert (p["kernel"], p["ksplit"], p["skew"]) == (5, 2, 0), p
+    assert _lib.plan(1024, N, K, 128, 16, tune=dict(skew=5))["skew"] == 5
+
+
+def test_tiled_family_is_not_an_automatic_choice():
+    """Round 5: the tiled family (round 1's kernel) never won one of the 903 measured dispatch points of round 4 and is no longer a candidate of the automatic
+    dispatch; it stays reachable through tune.kernel = 2 (the fuzzers' independent reference)."""
+    from qqq_amd import _lib
+
+    for gs in (-1, 128):
+        for (n, k) in ((8192, 21760), (4096, 4096), (11008, 4096), (4096, 11008), (1024, 8192), (28672, 8192), (3584, 18944), (5120, 13824)):
+            for m in (1, 8, 16, 33, 64, 65, 128, 129, 256, 257, 384, 512, 768, 1024, 1536, 2048, 4096, 8192, 16384):
+                assert _lib.plan(m, n, k, gs, 16)["kernel"] != 2, (m, n, k, gs)
+    assert _lib.plan(4096, 8192, 21760, -1, 16, tune=dict(kernel=2))["kernel"] == 2
+
+
+def test_plan_is_pure_host_logic_with_the_mi355x_cu_count():
+    """qqq_w4a8_plan no longer asks the HIP runtime for the current device's CU count (the tile-walk decision depends on it); it plans for the
+    MI355X's 256.  qqq_w4a8_gemm_ex plans and launches with the CU count of the device it was GIVEN, capped by `sms`."""
+    from qqq_amd import _lib
+
+    p = _lib.plan(8192, 4096, 4096, -1, 16)   # 512 tiles of 256 x 256 on 256 CUs, K = 4096: the persistent tile walk
+    assert p["kernel"] == 5 and p["glds"] == 2, p
+    p = _lib.plan(2048, 4096, 4096, -1, 16)   # 128 tiles: fewer than one per CU -> one tile per workgroup
+    assert p["kernel"] == 5 and p["glds"] == 1, p

@@ -120,7 +120,8 @@ def test_random_shapes_against_oracle(dev):
             h = GemmHarness(B, s2, s3, dev)
             tunes = [None, dict(kernel=1), dict(kernel=1, ksplit=2, fused=1), dict(kernel=3), dict(kernel=3, mt=2, ksplit=2),
                      dict(kernel=4), dict(kernel=4, bm=256, ksplit=2), dict(kernel=4, waves=4, mt=2, pf=2), dict(kernel=4, mt=8, ksplit=3),
-                     dict(kernel=4, bm=256, mt=8, pw=2), dict(kernel=4, bm=256, mt=8, pw=2, ksplit=2, pf=3)]
+                     dict(kernel=4, bm=256, mt=8, pw=2), dict(kernel=4, bm=256, mt=8, pw=2, ksplit=2, pf=3),
+                     dict(kernel=4, mt=8, ksplit=2, skew=2), dict(kernel=4, mt=4, ksplit=3, skew=1)]
             if K % 128 == 0:
                 tunes += [dict(kernel=2), dict(kernel=2, bm=64, glds=1, stages=3), dict(kernel=2, bm=130, glds=1, stages=5),
                           dict(kernel=2, bm=258, glds=1, stages=3, ksplit=2)]
@@ -767,3 +768,68 @@ def test_split_k_scratch_stays_inside_the_reduce_buffer(dev):
                 assert ulp_distance(D.cpu().numpy(), eD) == 0, (M, N, K, max_par, tune)
                 assert bool((Cbig[nC:] == 0x5A5A5A5A).all()) and bool((Wbig[nW:] == 0x5A5A5A5A).all()), (M, N, K, max_par, tune)
                 assert int(ws.abs().sum().item()) == 0
+
+
+def test_sms_caps_the_compute_units_of_a_call(dev):
+    """The reference's `sms` argument (csrc/qqq_gemm.cu:998: the number of persistent threadblocks) is a CU cap here: with 0 < sms < the
+    device's CUs the call's kernels run on a CU-masked stream forked from / joined into the caller's stream.  Results are bit-identical
+    whatever the cap, the caller's stream order holds (a dependent kernel on the caller's stream sees the output), and a quarter of
+    the chip is measurably slower than all of it at a size that fills the chip."""
+    import ctypes
+
+    from qqq_amd import _lib, ops
+
+    rng = np.random.default_rng(77)
+    N, K = 4096, 4096
+    codes = torch.from_numpy(rng.integers(-7, 8, size=(K, N), dtype=np.int8)).to(dev)
+    from qqq_amd import pack as P
+
+    B = P.pack_codes(codes, False)
+    s2 = torch.from_numpy((rng.random((1, N), dtype=np.float32) * 2e-4 + 1e-5)).to(dev)
+    s3 = torch.empty(0, dtype=torch.float16, device=dev)
+    C = torch.zeros((16 * 64, N), dtype=torch.int32, device=dev)
+    ws = torch.zeros(N // 128 * 16, dtype=torch.int32, device=dev)
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    for M in (16, 128, 2048):
+        A = torch.from_numpy(rng.integers(-128, 128, size=(M, K), dtype=np.int8)).to(dev)
+        s1 = torch.from_numpy((rng.random((M, 1), dtype=np.float32) * 0.05 + 0.001)).to(dev)
+        outs = {}
+        for sms in (-1, cus, cus // 4, 8):
+            D = torch.full((M, N), float("nan"), dtype=torch.float16, device=dev)
+            ops.qqq_gemm(A, B, C, D, s1, s2, s3, ws, -1, -1, sms, 16)
+            chk = D.float().sum()  # a dependent kernel on the caller's stream: ordered behind the join
+            torch.cuda.synchronize()
+            assert bool(torch.isfinite(chk)), (M, sms)
+            outs[sms] = D
+            assert int(ws.abs().sum().item()) == 0
+        for sms in (cus, cus // 4, 8):
+            assert torch.equal(outs[sms], outs[-1]), (M, sms)
+    # timing at 2048 tokens (128 tiles of the wide kernel or more): 8 CUs must be far slower than the whole chip
+    def timed(sms, reps=5):
+        ops.qqq_gemm(A, B, C, D, s1, s2, s3, ws, -1, -1, sms, 16)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            ops.qqq_gemm(A, B, C, D, s1, s2, s3, ws, -1, -1, sms, 16)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    t_all, t_8 = timed(-1), timed(8)
+    assert t_8 > 3.0 * t_all, (t_all, t_8)
+    # the capped call under stream capture: the fork / join are captured as cross-stream dependencies and the graph replays correctly
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.qqq_gemm(A, B, C, D, s1, s2, s3, ws, -1, -1, cus // 4, 16)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    D.fill_(float("nan"))
+    with torch.cuda.graph(g):
+        ops.qqq_gemm(A, B, C, D, s1, s2, s3, ws, -1, -1, cus // 4, 16)
+    D.fill_(float("nan"))
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(D, outs[-1])

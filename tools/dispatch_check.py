@@ -43,7 +43,7 @@ for (N, K) in shapes:
             best = min((v, k) for k, v in res.items() if v == v and k != "auto")
             flag = "" if res["auto"] <= best[0] * 1.03 else f"   <-- {best[1]} is {100 * (res['auto'] / best[0] - 1):.0f}% faster"
             extra = "".join(f" {k} {res[k]:7.1f}" for k in ("w16x2", "w8", "w128", "w128x2", "walk", "plain") if k in res)
-            print(f"N={N:5d} K={K:5d} {mode:4s} M={M:4d}  auto(k{p['kernel']},ks{p['ksplit']}{',walk' if p['kernel'] == 5 and p['glds'] == 2 else ''}) {res['auto']:7.1f} | column {res['column']:7.1f} stream {res['stream']:7.1f} tiled {res['tiled']:7.1f} panel {res['panel']:7.1f} panel256 {res['panel256']:7.1f} panel256x2 {res['panel256x2']:7.1f} wide {res['wide']:7.1f}{extra}{flag}")
+            print(f"N={N:5d} K={K:5d} {mode:4s} M={M:4d}  auto(k{p['kernel']},ks{p['ksplit']}{',walk' if p['kernel'] == 5 and p['glds'] == 2 else ''}{',split@' + str(p['split_m']) if p.get('split_m') else ''}) {res['auto']:7.1f} | column {res['column']:7.1f} stream {res['stream']:7.1f} tiled {res['tiled']:7.1f} panel {res['panel']:7.1f} panel256 {res['panel256']:7.1f} panel256x2 {res['panel256x2']:7.1f} wide {res['wide']:7.1f}{extra}{flag}")
             sys.stdout.flush()
         del layer
         torch.cuda.empty_cache()
