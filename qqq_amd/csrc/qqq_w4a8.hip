@@ -726,10 +726,17 @@ static int panel_auto_skew(int mt, int bn, bool grouped, int NST, int ksplit) {
   const int sk = (int)(latency / (t_stage * ksplit / (ksplit - 1.0)) + 0.5);
   return sk < 1 ? 1 : sk;
 }
-// wide, split K (256 KiB deposits, kept in the XCD's L2 when the slices share one): not measured yet -> even slices
+// wide, split K: the same rule with the wide kernel's deposits (a 256 x 256 partial tile goes through the LDS transposition and out as 256 KiB of
+// row-major int32: ~20 us from the depositor's last MFMA to "complete", half of that for the 128-column tiles) and stage times (wide_estimate).
+// Measured (profiles/r05_uneven_k_slices_wide.txt): N = 8192, K = 21760 per-group at 1024 tokens 173.1 -> 165.9 us (skew 6; 4: 167.6, 8: 167.0), per-channel
+// two slices of 256 x 256 140.3 -> 133.2 (8); 256 x 128 tiles in two slices at 384 / 512 tokens 80.8 -> 76.4 / 85.6 -> 82.2 (6), per-group 512: 102.8 -> 98.6 (3-6);
+// Llama-2-7B down_proj (4096 x 11008) at 1024 tokens 50.1 -> 48.6, per-group 62.3 -> 58.1 (3).
 static int wide_auto_skew(int mt, int bn, bool grouped, int NST, int ksplit) {
-  (void)mt; (void)bn; (void)grouped; (void)NST; (void)ksplit;
-  return 0;
+  (void)NST;
+  const double t_stage = (mt == 16 && bn == 256) ? (grouped ? 1.635 : 1.25) : (mt == 16) ? (grouped ? 0.96 : 0.70) : (grouped ? 1.17 : 0.725);
+  const double latency = 20.0 * (16.0 * mt * bn) / 65536.0;
+  const int sk = (int)(latency / (t_stage * ksplit / (ksplit - 1.0)) + 0.5);
+  return sk < 1 ? 1 : sk;
 }
 
 // The dispatch decision of one call, as plain data (pure host logic: also exported as qqq_w4a8_plan so
