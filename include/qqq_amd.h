@@ -67,9 +67,10 @@ typedef struct qqq_tune {
                       LDS-DMA, in-launch split-K through row-major slots of C: from ~320 tokens up) */
   int ksplit;  /* 0 auto, else number of K slices (partials go through C)                   */
   int waves;   /* stream: waves per workgroup (4, 8 or 16); panel (bm = 128): 4 or 8 (two k-groups); 0 auto */
-  int fused;   /* split-K finish; 0 auto.  stream: 1 = last-arriving workgroup reduces in-launch (tickets in
-                  workspace, release fence), 3 = same with write-through slab stores (no release fence),
-                  2 = separate reduce launch.  tiled: 1 = in-launch (K slices of a tile meet in tile-sized int32
+  int fused;   /* split-K finish; 0 auto.  stream: 1 = last-arriving workgroup reduces the slabs in-launch (one ticket per tile in
+                  workspace, release / acquire fences), 3 = in-launch through arrival-order slots (two ticket words per tile; a slice
+                  writes its partial tile through to the slot of its arrival index, the last arrival keeps its own in LDS and adds
+                  the others'; uneven slices by `skew`), 2 = slabs + separate reduce launch.  tiled: 1 = in-launch (K slices of a tile meet in tile-sized int32
                   slots of C, tickets in workspace), 2 = ksplit [m,n] slabs in C + separate reduce launch.
                   tiled / panel / wide in-launch hand-off, OR-ed in: 4 = formal agent-scope acquire fence in front of the
                   fold, 8 = agent-scope release on the depositor's completion count (both off as shipped: the deposits
@@ -100,7 +101,8 @@ typedef struct qqq_tune {
   int skew;    /* panel / wide, in-launch split-K: uneven K slices -- the LAST slice gets this many 128-k stages more than an even share (the
                   others share what is left evenly), so that it arrives last and finds the other slices' deposits already in memory
                   instead of waiting a hand-off latency for them (arrival order still decides who folds: a matter of time, never of
-                  correctness).  in: -1 = even slices, 0 = automatic, 1..63 stages.  out (qqq_w4a8_plan): the stages used.  ABI 3. */
+                  correctness).  in: -1 = even slices, 0 = automatic, 1..63 stages.  out (qqq_w4a8_plan): the stages used.  ABI 3.
+                  stream (fused = 3): the same in 64-k steps (1..255). */
 } qqq_tune_t;
 
 /* As qqq_w4a8_gemm; `tune` may be NULL; if `acc_out` != NULL the raw int32 accumulators

@@ -27,8 +27,10 @@ __global__ __launch_bounds__(WAVES * 64) void qqq_stream_kernel(
     const int8_t* __restrict__ A, const unsigned char* __restrict__ B, int32_t* __restrict__ C,
     _Float16* __restrict__ D, const float* __restrict__ s1, const float* __restrict__ s2,
     const _Float16* __restrict__ s3, int32_t* __restrict__ acc_out, int* __restrict__ tickets,
-    const _Float16* __restrict__ bias, const int M, const int N, const int K, const int ksplit,
+    const _Float16* __restrict__ bias, const int M, const int N, const int K, const int ksplit_sk,
     const int fused) {
+  // (bits 16..23 of the K-split argument: `skew`, the 64-k steps the LAST K slice gets on top of an even share -- fused == 3 only)
+  const int ksplit = ksplit_sk & 0xffff, skew = (ksplit_sk >> 16) & 0xff;
   constexpr int NQ = MT * 8;  // MFMA output tiles per wave
   __shared__ int red[NQ * 4 * 64 + 64];
 
@@ -64,8 +66,9 @@ __global__ __launch_bounds__(WAVES * 64) void qqq_stream_kernel(
   const _Float16* sptr = GROUPED ? (s3 + (size_t)ng * 64 + c * 8) : nullptr;
 
   const int KS = K >> 6;  // 64-k steps
-  const int ks_begin = (int)(((long long)KS * sp) / ksplit);
-  const int ks_end = (int)(((long long)KS * (sp + 1)) / ksplit);
+  const int KSE = KS - skew;  // uneven slices (skew > 0): the last one is longer -- it arrives last and finds the other deposits complete
+  const int ks_begin = (int)(((long long)KSE * sp) / ksplit);
+  const int ks_end = (sp == ksplit - 1) ? KS : (int)(((long long)KSE * (sp + 1)) / ksplit);
 
   v4i acc[MT][4][2];
 #pragma unroll
@@ -141,6 +144,12 @@ __global__ __launch_bounds__(WAVES * 64) void qqq_stream_kernel(
     for (int p = 0; p < PF; ++p)
       if (s + p * WAVES < ks_end) load_step(s + p * WAVES, ring[p]);
   }
+  // fused == 3: the arrival ticket of this K slice, taken HERE -- a few steps ahead of the end of the loop, so that the atomic's round trip
+  // (agent scope, ~1 us) runs under the tail and the LDS reduction; consumed behind the barrier below.  (Taking it early is safe: whoever
+  // holds the last ticket only ever waits for workgroups that are resident and running.)
+  int arrival = 0;
+  if (fused == 3 && ksplit > 1 && tid == 0)
+    arrival = __hip_atomic_fetch_add(tickets + 2 * (size_t)(blockIdx.z * gridDim.x + strip), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   for (; s < ks_end; s += PF * WAVES) {
 #pragma unroll
     for (int p = 0; p < PF; ++p) {
@@ -202,6 +211,62 @@ __global__ __launch_bounds__(WAVES * 64) void qqq_stream_kernel(
     return;
   }
 
+  if (fused == 3) {
+    // ---- in-launch split-K, arrival-order slots (round 5; the panel kernel's protocol): slice with ticket t < ksplit - 1 writes its partial
+    // tile -- lane-linear, item `it` at 16 * it bytes: full lines -- through to slot t of the tile in C, drains, and counts itself complete;
+    // the LAST arrival deposits nothing: its own partial tile stays in LDS, it waits until the others' count is complete (with uneven slices
+    // it already is), adds their slots (agent-scope loads) and runs the epilogue.  One launch, no slab of the finisher's own, no re-read of it.
+    // Two ticket words per tile (arrivals, completed deposits), zero again on exit. ----
+    const size_t tile = (size_t)blockIdx.z * gridDim.x + strip;
+    int* tk = tickets + 2 * tile;
+    int* flag = &red[NQ * 4 * 64];
+    if (tid == 0) *flag = arrival;
+    __syncthreads();
+    const int t = __builtin_amdgcn_readfirstlane(*flag);
+    constexpr int SLOT_INTS = NQ * 64 * 4;
+    int32_t* slots = C + tile * (size_t)(ksplit - 1) * SLOT_INTS;
+    if (t < ksplit - 1) {
+      for (int it = tid; it < NQ * 64; it += WAVES * 64) {
+        const int q = it >> 6, ln = it & 63;
+        const int* rp = &red[(q * 4) * 64 + ln];
+        const v4i v = {rp[0], rp[64], rp[128], rp[192]};
+        int32_t* dst = slots + (size_t)t * SLOT_INTS + (size_t)it * 4;
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // every wave's part of the deposit has reached memory
+      if (tid == 0) __hip_atomic_fetch_add(tk + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    if (tid == 0) {
+      int spin = 0;
+      while (__hip_atomic_load(tk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ksplit - 1) {
+        if (++spin > QQQ_SPIN_LIMIT) __builtin_trap();  // (a depositor that never completes must not end in a silently wrong D)
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+    __syncthreads();
+    for (int it = tid; it < NQ * 64; it += WAVES * 64) {
+      int m, n;
+      item_coords(it, m, n);
+      const int q = it >> 6, ln = it & 63;
+      const int* rp = &red[(q * 4) * 64 + ln];
+      v4i sum = {rp[0], rp[64], rp[128], rp[192]};
+      const unsigned off = (unsigned)it * 16u;
+      for (int p0 = 0; p0 < ksplit - 1; p0 += 4) {  // four slots in flight; surplus loads re-read the last slot, only the add is skipped
+        v4i d[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) d[b] = load16_agent(agent_view(slots + (size_t)min(p0 + b, ksplit - 2) * SLOT_INTS), off);
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          if (p0 + b < ksplit - 1) sum += d[b];
+      }
+      if (m < M && n < N) epilogue_store4(sum[0], sum[1], sum[2], sum[3], m, n, N, s1[m], s2, D, acc_out, bias);
+    }
+    if (tid < 2) __hip_atomic_store(tk + tid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // workspace zero on return
+    return;
+  }
+
   // split-K: partial sums -> slab sp of C  (C[(sp*M + m)*N + n])
   for (int it = tid; it < NQ * 64; it += WAVES * 64) {
     int m, n;
@@ -211,35 +276,25 @@ __global__ __launch_bounds__(WAVES * 64) void qqq_stream_kernel(
       const int* rp = &red[(q * 4) * 64 + ln];
       v4i v = {rp[0], rp[64], rp[128], rp[192]};
       int32_t* dst = C + ((size_t)sp * M + m) * N + n;
-      if (fused == 2) {
-        // write-through (sc0 sc1) slab store: reaches memory without a later L2 write-back, so the
-        // publish below needs no agent-scope release fence (MI355X hand-off recipe R1)
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
-      } else {
-        *reinterpret_cast<v4i*>(dst) = v;
-      }
+      *reinterpret_cast<v4i*>(dst) = v;
     }
   }
   if (!fused) return;  // a separate reduce launch finishes the job
 
-  // in-launch reduction by the last-arriving workgroup of this (strip, m-block) tile:
-  // (fused == 1) plain stores -> agent-scope release -> ticket, or (fused == 2) write-through stores ->
-  // drained -> ticket; the last arriver folds the slabs (placement independent).
+  // fused == 1: the formally fenced in-launch reduction over the SLABS by the last-arriving workgroup of this (strip, m-block) tile -- plain
+  // stores -> agent-scope release -> ticket; the last arriver acquires and folds the slabs.  Kept as the by-the-book variant the
+  // tests run next to the slot protocol above (one ticket word per tile).
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  // The last arriver reads the slabs with agent-scope sc1 loads (load16_agent: 32-bit offsets inside one slab) -- the
-  // acquire fence it replaces is an invalidate of the XCD's whole L2, ~3 us; slabs beyond 2 GB keep the fence.
-  // (fused == 1 publishes with plain stores + a release fence: sc1 loads stand in for the acquire only behind sc1 stores)
-  const bool wide = fused == 1 || (size_t)M * N * 4 >= 0x7fffffffull;
   int* flag = &red[NQ * 4 * 64];
   if (tid == 0) {
-    if (fused == 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int* tk = tickets + (blockIdx.z * gridDim.x + strip);
     const int t = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int last = (t == ksplit - 1);
     if (last) {
-      if (wide) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // workspace zero on return
     }
     *flag = last;
@@ -251,20 +306,7 @@ __global__ __launch_bounds__(WAVES * 64) void qqq_stream_kernel(
     item_coords(it, m, n);
     if (m < M && n < N) {
       v4i sum = {0, 0, 0, 0};
-      if (!wide) {
-        const unsigned off = ((unsigned)m * (unsigned)N + (unsigned)n) * 4u;
-        for (int p0 = 0; p0 < ksplit; p0 += 4) {  // four slabs in flight; surplus loads re-read the last slab, only the add is skipped
-          v4i d[4];
-#pragma unroll
-          for (int b = 0; b < 4; ++b) d[b] = load16_agent(agent_view(C + (size_t)min(p0 + b, ksplit - 1) * M * N), off);
-#pragma unroll
-          for (int b = 0; b < 4; ++b)
-            if (p0 + b < ksplit) sum += d[b];
-        }
-      } else {
-        for (int p = 0; p < ksplit; ++p)
-          sum += *reinterpret_cast<const v4i*>(C + ((size_t)p * M + m) * N + n);
-      }
+      for (int p = 0; p < ksplit; ++p) sum += *reinterpret_cast<const v4i*>(C + ((size_t)p * M + m) * N + n);
       epilogue_store4(sum[0], sum[1], sum[2], sum[3], m, n, N, s1[m], s2, D, acc_out, bias);
     }
   }

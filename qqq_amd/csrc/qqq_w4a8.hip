@@ -173,7 +173,7 @@ struct LaunchArgs {
 
 template <int MT, bool GROUPED, int WAVES, int PF>
 static hipError_t launch_stream_t(const LaunchArgs& a, int ksplit, int fused) {
-  dim3 grid((a.N + 127) / 128, ksplit, (a.M + 16 * MT - 1) / (16 * MT));
+  dim3 grid((a.N + 127) / 128, ksplit & 0xffff, (a.M + 16 * MT - 1) / (16 * MT));
   hipLaunchKernelGGL((qqq_stream_kernel<MT, GROUPED, WAVES, PF>), grid, dim3(WAVES * 64), 0, a.stream,
                      a.A, a.B, a.C, a.D, a.s1, a.s2, a.s3, a.acc_out, a.tickets, a.bias, a.M, a.N, a.K,
                      ksplit, fused);
@@ -726,6 +726,19 @@ static int panel_auto_skew(int mt, int bn, bool grouped, int NST, int ksplit) {
   const int sk = (int)(latency / (t_stage * ksplit / (ksplit - 1.0)) + 0.5);
   return sk < 1 ? 1 : sk;
 }
+// stream, split K: how the slices meet (tune.fused = 0) -- 2 = slabs + a reduce launch, 3 = in-launch through arrival-order slots.  Not measured yet: 2.
+static int stream_auto_fused(int M, int N, int K, bool grouped, int ksplit) {
+  (void)M; (void)N; (void)K; (void)grouped; (void)ksplit;
+  return 2;
+}
+// ... and the skew of the slot protocol, in 64-k steps: the slices stream the matrix together in about N K / 2 / 5 TB/s, a deposit (8 ... 32 KiB written
+// through, drained, counted) takes ~2 us
+static int stream_auto_skew(int N, int K, int ksplit) {
+  const double pass_us = (double)N * K / 2.0 / 5.0e6;
+  const double t_step = pass_us * ksplit / (K / 64.0);
+  const int sk = (int)(2.0 / (t_step * ksplit / (ksplit - 1.0)) + 0.5);
+  return sk < 1 ? 1 : sk;
+}
 // wide, split K: the same rule with the wide kernel's deposits (a 256 x 256 partial tile goes through the LDS transposition and out as 256 KiB of
 // row-major int32: ~20 us from the depositor's last MFMA to "complete", half of that for the 128-column tiles) and stage times (wide_estimate).
 // Measured (profiles/r05_uneven_k_slices_wide.txt): N = 8192, K = 21760 per-group at 1024 tokens 173.1 -> 165.9 us (skew 6; 4: 167.6, 8: 167.0), per-channel
@@ -950,10 +963,21 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
     if (ksplit > 1 && (long long)ksplit * M > cap_rows) ksplit = (int)(cap_rows / M);
     if (ksplit < 1) ksplit = 1;
     int fused = t.fused & 3;  // (bits 2.. are the in-launch hand-off switches of the other families)
-    if (fused == 0) fused = 2;  // separate reduce launch measured ~2 us faster than the in-launch ticket path
-    // tickets: one int per (m-block, strip); the reference guarantees n/128*max_par ints
-    if ((fused == 1 || fused == 3) && (workspace == nullptr || (long long)mblocks * strips > (long long)(N / 128) * max_par))
+    if (fused == 0) fused = stream_auto_fused(M, N, K, grouped, ksplit);
+    // tickets: one int per (m-block, strip) for the fenced fold over the slabs (1), two for the slot protocol (3); the reference guarantees
+    // n/128*max_par ints.  Slots (3): (ksplit - 1) tiles of 16*mt x 128 ints per (m-block, strip), inside the rows of C we may use.
+    if (fused == 1 && (workspace == nullptr || (long long)mblocks * strips > (long long)(N / 128) * max_par)) fused = 2;
+    if (fused == 3 && (workspace == nullptr || 2ll * mblocks * strips > (long long)(N / 128) * max_par ||
+                       (long long)mblocks * strips * (ksplit - 1) * (16ll * mt * 128) > cap_rows * (long long)N))
       fused = 2;
+    pl.skew = 0;
+    if (fused == 3 && ksplit > 1) {  // uneven slices, in 64-k steps (tune.skew: -1 never, 0 automatic); every slice keeps two steps per wave
+      int sk = t.skew > 0 ? t.skew : (t.skew == 0 ? stream_auto_skew(N, K, ksplit) : 0);
+      const int room = KS - 2 * waves * ksplit;
+      if (sk > room) sk = room;
+      if (sk > 255) sk = 255;
+      pl.skew = sk > 0 ? sk : 0;
+    }
     pl.mt = mt;
     pl.waves = waves;
     pl.pf = t.pf > 0 ? t.pf : (mt <= 2 ? 3 : 2);
@@ -1196,8 +1220,10 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
     if (e != hipSuccess) return fail_hip(e, "qqq_column_kernel launch");
     reduce_launch = pl.ksplit > 1;
   } else if (pl.kernel == 1) {
-    // kernel arg: 0 = slabs only (separate reduce launch), 1 = in-launch + release fence, 2 = in-launch + write-through
-    e = launch_stream(a, grouped, pl.mt, pl.waves, pl.pf, pl.ksplit, pl.fused == 1 ? 1 : (pl.fused == 3 ? 2 : 0));
+    // kernel arg: 0 = slabs only (separate reduce launch), 1 = in-launch over the slabs with release / acquire fences, 3 = in-launch through
+    // arrival-order slots (the last arrival keeps its tile in LDS; uneven slices: skew in 64-k steps rides in bits 16.. of the K split)
+    e = launch_stream(a, grouped, pl.mt, pl.waves, pl.pf, pl.ksplit | ((pl.fused == 3 && pl.ksplit > 1 ? pl.skew & 0xff : 0) << 16),
+                      pl.ksplit > 1 ? (pl.fused == 1 ? 1 : (pl.fused == 3 ? 3 : 0)) : 0);
     if (e != hipSuccess) return fail_hip(e, "qqq_stream_kernel launch");
     reduce_launch = pl.ksplit > 1 && pl.fused != 1 && pl.fused != 3;
   } else {

@@ -60,6 +60,9 @@ def variants(M, K, N):
         v += [dict(kernel=1, ksplit=2, waves=4, fused=1), dict(kernel=1, ksplit=2, waves=4, fused=2), dict(kernel=1, ksplit=2, waves=8, fused=3)]
     if K // 64 >= 8:
         v += [dict(kernel=1, ksplit=3, waves=8, fused=1), dict(kernel=1, ksplit=4, waves=4, fused=3)]
+    if K // 64 >= 64:  # round 5: in-launch split-K through arrival-order slots (fused=3) with uneven slices (skew in 64-k steps; -1 = even)
+        v += [dict(kernel=1, ksplit=4, waves=8, fused=3, skew=5), dict(kernel=1, ksplit=3, waves=4, fused=3, skew=-1), dict(kernel=1, mt=4, ksplit=2, fused=3, skew=200),
+              dict(kernel=1, ksplit=7, waves=4, fused=3, skew=1)]
     if M <= 16:
         v += [dict(kernel=1, ksplit=1, waves=16)]
     v += [dict(kernel=1)]  # auto split
