@@ -121,6 +121,11 @@ int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, const void*
 int qqq_w4a8_plan(int prob_m, int prob_n, int prob_k, int groupsize, int max_par, int have_scratch,
                   int have_workspace, const qqq_tune_t* tune, qqq_tune_t* plan_out);
 
+/* Diagnostic (pure host logic): the dispatcher's cost models' price, in microseconds on an MI355X, of each kernel family for this problem --
+ * out[0] column, [1] stream, [2] panel, [3] wide; <= 0 where a family is not a candidate.  tools/cost_model_report.py holds these against the
+ * committed hardware measurements (profiles/r05_cost_model_error.txt). */
+int qqq_w4a8_model_us(int prob_m, int prob_n, int prob_k, int groupsize, int max_par, double* out);
+
 /*
  * Fused per-token dynamic int8 quantisation; replaces the ~8 torch launches of
  * QuantLinear.dynamic_quant (qlinear_marlin.py:265-268):

@@ -43,6 +43,8 @@ def lib():
     L.qqq_w4a8_gemm_ex.restype = ci
     L.qqq_w4a8_plan.argtypes = [ci, ci, ci, ci, ci, ci, ci, ctypes.POINTER(QQQTune), ctypes.POINTER(QQQTune)]
     L.qqq_w4a8_plan.restype = ci
+    L.qqq_w4a8_model_us.argtypes = [ci, ci, ci, ci, ci, ctypes.POINTER(ctypes.c_double)]
+    L.qqq_w4a8_model_us.restype = ci
     L.qqq_dynamic_quant.argtypes = [vp, vp, vp, ci, ci, ci, vp]
     L.qqq_dynamic_quant.restype = ci
     L.qqq_quantlinear_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp, ci, ci, vp, ci, vp]
@@ -76,3 +78,12 @@ def plan(m, n, k, groupsize=-1, max_par=16, have_scratch=True, have_workspace=Tr
     if rc:
         raise RuntimeError(f"qqq_w4a8_plan failed ({rc}): {last_error()}")
     return {f: getattr(out, f) for f, _ in QQQTune._fields_ if f != "reserved"}
+
+
+def model_us(m, n, k, groupsize=-1, max_par=16) -> dict:
+    """the cost models' price (us) of each family for one problem: {"column", "stream", "panel", "wide"} (families that are no candidate are left out)"""
+    out = (ctypes.c_double * 4)()
+    rc = lib().qqq_w4a8_model_us(m, n, k, groupsize, max_par, out)
+    if rc:
+        raise RuntimeError(f"qqq_w4a8_model_us failed ({rc}): {last_error()}")
+    return {name: out[i] for i, name in enumerate(("column", "stream", "panel", "wide")) if out[i] > 0}

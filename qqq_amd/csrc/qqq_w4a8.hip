@@ -619,6 +619,9 @@ static double panel_estimate(int M, int N, int K, bool grouped, bool have_scratc
     for (int ks = 1; ks <= 4; ++ks) {
       if (ks > 1 && (!have_scratch || 2 * tl > cap_tickets || tl * rows * bn * (ks - 1) > cap_rows * (long long)N || ks > NST / 4)) break;  // slots: tiles x (ks-1) x rows x bn ints inside C
       static const double tail[5] = {0.0, 0.0, 5.0, 6.5, 8.5};  // (fold by sc1 loads, no acquire fence: profiles/r02_panel_handoff.txt)
+      // (tools/cost_model_report.py, round 5: this form prices 65 ... 256 tokens 11 % high on average -- most on layers that leave CUs idle -- and a
+      //  version with a smaller tail and a fill factor was within 4 %, but ORDERED the families worse on the measured points (7 of 13 regret files
+      //  red): the constants here are calibrated for the ordering, which is what a dispatcher needs; the report keeps the absolute error in view)
       // (one unsplit round of 128-token m-blocks: 7.4 -- 4096 / 5120-square layers at 768 tokens measured 23.5 / 27.5 us per-channel, 30.4 / 36.7 per-group,
       // profiles/r04_dispatch_check_mid_shapes.txt)
       const double wg_us = ((mt == 8 && ks == 1 && tl <= 256) ? 7.4 : 8.7) + tail[ks] + ((double)NST / ks) * t_stage;
@@ -1117,6 +1120,33 @@ extern "C" int qqq_w4a8_plan(int prob_m, int prob_n, int prob_k, int groupsize, 
   plan_out->nslots = pl.nslots;
   plan_out->pw = pl.pw;
   plan_out->skew = pl.skew;
+  return QQQ_OK;
+}
+
+// The cost models' price (us) of each family for one problem, exactly as make_plan evaluates them -- so that ONE tool (tools/cost_model_report.py) can hold
+// every model against every committed measurement.  out[0] column, [1] stream, [2] panel, [3] wide; <= 0: not a candidate at this size.
+extern "C" int qqq_w4a8_model_us(int prob_m, int prob_n, int prob_k, int groupsize, int max_par, double* out) {
+  g_err[0] = 0;
+  if (!out || prob_m <= 0 || prob_n <= 0 || prob_k <= 0 || (prob_n % 64) != 0 || (prob_k % 64) != 0) {
+    snprintf(g_err, sizeof(g_err), "qqq_w4a8_model_us: bad argument");
+    return QQQ_ERR_ARG;
+  }
+  const int M = prob_m, N = prob_n, K = prob_k;
+  const bool grouped = groupsize != -1;
+  const long long cap_rows = (long long)(max_par > 0 ? max_par : 0) * 64, cap_tk = (long long)(N / 128) * (max_par > 0 ? max_par : 0);
+  for (int i = 0; i < 4; ++i) out[i] = -1.0;
+  if (M <= 32) {
+    out[0] = column_small_estimate(M, N, K, grouped);
+    out[1] = stream_small_estimate(M, N, K, grouped);
+    return QQQ_OK;
+  }
+  int a = 0, b = 0, c = 0;
+  if (M <= 256) out[1] = stream_estimate(M, N, K, grouped, cap_rows > 0, cap_rows);
+  out[2] = panel_estimate(M, N, K, grouped, cap_rows > 0, cap_rows, cap_tk, &a, &b, &c);
+  if (M > 256) {
+    const double w = wide_estimate(M, N, K, grouped, cap_rows > 0, cap_rows, cap_tk, &a, &b, &c);
+    out[3] = w < 1e29 ? w : -1.0;
+  }
   return QQQ_OK;
 }
 

@@ -26,7 +26,7 @@ def _declared(header):
 
 def test_exports_every_declared_symbol(L):
     names = _declared("qqq_amd.h")
-    assert {"qqq_w4a8_gemm", "qqq_w4a8_gemm_ex", "qqq_w4a8_plan", "qqq_dynamic_quant", "qqq_quantlinear_forward",
+    assert {"qqq_w4a8_gemm", "qqq_w4a8_gemm_ex", "qqq_w4a8_plan", "qqq_w4a8_model_us", "qqq_dynamic_quant", "qqq_quantlinear_forward",
             "qqq_pack_int4", "qqq_unpack_int4", "qqq_amd_abi_version", "qqq_amd_last_error"} == names
     for n in names:
         assert hasattr(L, n), n

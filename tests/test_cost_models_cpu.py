@@ -1,0 +1,45 @@
+"""The dispatcher's cost models against the clock, without a GPU: tools/cost_model_report.py asks the CURRENT library for its price of every kernel family
+(`qqq_w4a8_model_us`, pure host logic) at every point of the committed dispatch checks (round 4: 903 points, every family forced and timed on an MI355X)
+and compares it with the fastest measured variant of that family.  The bounds are what the library of round 5 reaches (profiles/r05_cost_model_error.txt)
+plus room for the measurements' own box-to-box spread; a kernel or model change that moves a family's price away from the clock fails here and says where.
+(That the models ORDER the families correctly is tests/test_dispatch_regret_cpu.py's business.)"""
+import glob
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+# (family, token regime) -> (least points, largest mean |error|, largest |bias|)
+BOUNDS = {
+    ("column", "1-8"): (120, 0.10, 0.07), ("column", "9-32"): (200, 0.09, 0.05),
+    ("stream", "1-8"): (120, 0.09, 0.05), ("stream", "9-32"): (200, 0.07, 0.04), ("stream", "33-64"): (150, 0.07, 0.05), ("stream", "65-256"): (180, 0.08, 0.04),
+    ("panel", "33-64"): (150, 0.05, 0.04), ("panel", "65-256"): (180, 0.14, 0.14), ("panel", "257-1024"): (190, 0.08, 0.06), ("panel", ">1024"): (230, 0.07, 0.04),
+    ("wide", "257-1024"): (190, 0.06, 0.04), ("wide", ">1024"): (230, 0.06, 0.05),
+}
+
+
+def test_every_model_is_within_its_bound_of_the_measurements():
+    import cost_model_report as C
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r04_dispatch_check_*.txt")))
+    assert len(files) >= 13
+    t = C.table([r for f in files for r in C.points(f)])
+    assert set(BOUNDS) <= set(t), sorted(set(BOUNDS) - set(t))
+    for key, (need, mae, bias) in BOUNDS.items():
+        n, got_mae, got_bias, worst, point = t[key]
+        assert n >= need and got_mae <= mae and abs(got_bias) <= bias, (key, n, got_mae, got_bias, point)
+
+
+def test_model_prices_follow_the_plan():
+    """the family the plan picks is the cheapest of the prices the report sees (same functions, same arguments)"""
+    from qqq_amd import _lib
+
+    fam = {1: "stream", 3: "column", 4: "panel", 5: "wide"}
+    for gs in (-1, 128):
+        for (n, k) in ((8192, 21760), (4096, 4096), (11008, 4096), (4096, 11008)):
+            for m in (40, 64, 100, 128, 200, 256, 300, 512, 1024, 4096):
+                prices = _lib.model_us(m, n, k, gs, 16)
+                plan = _lib.plan(m, n, k, gs, 16, tune=dict(split_m=-1))
+                best = min(prices, key=prices.get)
+                assert fam[plan["kernel"]] == best or abs(prices[fam[plan["kernel"]]] - prices[best]) < 1e-9, (m, n, k, gs, prices, plan["kernel"])
