@@ -274,6 +274,9 @@ static hipError_t launch_panel_shape(const LaunchArgs& a, int bn, int waves, int
   }
   if (bn == 256) return launch_panel_t<MT, GROUPED, 8, 1, PFS, XL>(a, ksplit);
   if (waves == 4) return launch_panel_t<MT, GROUPED, 4, 1, PFS, XL>(a, ksplit);
+  // (a NINTH wave feeding the activations by LDS-DMA -- so that they do not queue behind the weight loads in the compute waves' in-order
+  //  return queues -- was built and measured in round 5: bit-exact, 150 cases, and level with this kernel everywhere, 35.4 vs 35.4 us at 128
+  //  tokens: it is the L2 <-> CU traffic of the activations that costs, not how it is issued.  Not kept; profiles/r05_panel_feeder.txt)
   return launch_panel_t<MT, GROUPED, 4, 2, PFS, XL>(a, ksplit);
 }
 
@@ -607,7 +610,8 @@ static double stream_estimate(int M, int N, int K, bool grouped, bool have_scrat
 // per 128-k stage (bn = 128, per-channel), twice that for bn = 256, x1.45 per-group; ~9 us of launch / pipeline fill /
 // epilogue and 5..8.5 us for the in-launch split-K hand-off (deposit, ticket, fold by the last arrival)
 static double panel_estimate(int M, int N, int K, bool grouped, bool have_scratch, long long cap_rows, long long cap_tickets,
-                             int* bn_out, int* ks_out, int* cw_out) {
+                             int* bn_out, int* ks_out, int* cw_out, int* mt_out = nullptr) {
+  if (mt_out) *mt_out = 0;  // 0: the m-block the token count implies (16 / 32 / 64 / 128 rows)
   const int mt = (M <= 16) ? 1 : (M <= 32) ? 2 : (M <= 64) ? 4 : 8;
   const int rows = 16 * mt;
   const long long mblocks = (M + rows - 1) / rows;
@@ -661,6 +665,30 @@ static double panel_estimate(int M, int N, int K, bool grouped, bool have_scratc
         *bn_out = 256;
         *ks_out = ks;
         *cw_out = 2;
+      }
+    }
+  }
+  // More than 64 tokens as SEVERAL 64-token m-blocks (round 5, profiles/r05_panel_feeder.txt): on layers whose 128-token tiles leave CUs idle or hold few
+  // stages each, twice the workgroups of half the size finish sooner although every m-block streams the weights again (from L2 / the Infinity Cache) --
+  // 4096 x 4096 at 128 / 256 / 512 tokens 13.1 / 15.2 / 18.4 us against 15.2 / 17.7 / 19.4, 4096 x 11008 and 11008 x 4096 at 128 tokens 18.3 / 18.5 against
+  // 21.5 / 20.0, 8192 x 8192 21.3 against 22.1; not on the BASELINE layer (40.1 vs 35.4: the weights come from HBM twice) and not beyond one round of
+  // workgroups (11008 x 4096 at 256 tokens 27.7 vs 23.3).  Priced with the 64-token form above (within 1.0 us of nine of the ten points measured), the
+  // weight bytes once per m-block; one round only.
+  // (measured on layers of 4096 ... 11008 columns; narrower ones -- N = 1024 at 256 tokens is the stream kernel's, 13.7 us -- are left as they were)
+  if (mt == 8 && mt_out && N >= 4096) {
+    const long long mb4 = (M + 63) / 64, tl = mb4 * ((N + 127) / 128);
+    for (int ks = 1; ks <= 4; ++ks) {
+      if (tl * ks > 256) break;
+      if (ks > 1 && (!have_scratch || 2 * tl > cap_tickets || tl * 64 * 128 * (ks - 1) > cap_rows * (long long)N || ks > NST / 4)) break;
+      const double stage_us = ((double)NST / ks) * (grouped ? 0.52 : 0.316);
+      const double bytes_us = (double)mb4 * N * K / 2.0 / 5.3e6 * (grouped ? 1.45 : 1.0);
+      const double us = (ks == 1 ? 10.0 : 11.5) + (grouped ? 0.4 : 0.0) + (stage_us > bytes_us ? stage_us : bytes_us);
+      if (us < best) {
+        best = us;
+        *bn_out = 128;
+        *ks_out = ks;
+        *cw_out = 1;
+        *mt_out = 4;
       }
     }
   }
@@ -802,8 +830,8 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
     // with LDS-shared activations for K % 128 == 64 at any m (the tiled kernel needs 128-k blocks).
     if (column_ok && !column && M > 32) {
       const long long cap_tk = have_ws ? (long long)(N / 128) * (max_par > 0 ? max_par : 0) : 0;
-      int pbn = 128, pks = 1, pcw = 1;
-      const double e_panel = ((long long)(M + 127) / 128 <= 65535) ? panel_estimate(M, N, K, grouped, have_scratch && have_ws, cap_rows, cap_tk, &pbn, &pks, &pcw) : 1e30;
+      int pbn = 128, pks = 1, pcw = 1, pmt = 0;
+      const double e_panel = ((long long)(M + 127) / 128 <= 65535) ? panel_estimate(M, N, K, grouped, have_scratch && have_ws, cap_rows, cap_tk, &pbn, &pks, &pcw, &pmt) : 1e30;
       const double e_stream = (M <= 256) ? stream_estimate(M, N, K, grouped, have_scratch, cap_rows) : 1e30;
       // (the tiled family -- round 1's LDS-tiled 32x32x32 kernel -- is no longer a candidate of the automatic dispatch: in the 903 measured
       // dispatch points of round 4 it never won one (M = 4096: 585.9 vs 449.2 us).  It stays reachable through tune.kernel = 2 -- the
@@ -824,6 +852,7 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
       } else if (e_panel <= e_stream) {
         kernel = 4;
         if (t.bm == 0 && t.pw == 0 && t.mt == 0 && pcw == 2) t.pw = 2;
+        if (t.bm == 0 && t.mt == 0 && pmt) t.mt = pmt;  // several 64-token m-blocks instead of 128-token ones
         if (t.bm == 0) t.bm = pbn;
         if (t.ksplit <= 0) t.ksplit = pks;
       } else {
@@ -906,6 +935,7 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
     pl.stages = (pl.pf == 4 && t.stages != 4) ? 2 : pl.pf;
     // 32-column sets per wave: 2 = 4 waves x 64 columns x 2 k-groups for the 256-column, 128-token shape
     pl.pw = (cw2 && pl.pf >= 3 && pl.pf <= 4 && (pl.stages == pl.pf || (pl.pf == 4 && pl.stages == 2))) ? 2 : 1;
+    pl.waves = waves;
     pl.ksplit = ksplit;
     pl.fused = 1;
     // uneven K slices (tune.skew: -1 never, 0 automatic, else stages): every slice keeps at least 4 stages
@@ -1142,7 +1172,8 @@ extern "C" int qqq_w4a8_model_us(int prob_m, int prob_n, int prob_k, int groupsi
   }
   int a = 0, b = 0, c = 0;
   if (M <= 256) out[1] = stream_estimate(M, N, K, grouped, cap_rows > 0, cap_rows);
-  out[2] = panel_estimate(M, N, K, grouped, cap_rows > 0, cap_rows, cap_tk, &a, &b, &c);
+  int pm = 0;
+  out[2] = panel_estimate(M, N, K, grouped, cap_rows > 0, cap_rows, cap_tk, &a, &b, &c, &pm);
   if (M > 256) {
     const double w = wide_estimate(M, N, K, grouped, cap_rows > 0, cap_rows, cap_tk, &a, &b, &c);
     out[3] = w < 1e29 ? w : -1.0;

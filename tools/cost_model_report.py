@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
-FAMILY_OF = {"column": "column", "stream": "stream", "panel": "panel", "panel256": "panel", "panel256x2": "panel",
+FAMILY_OF = {"column": "column", "stream": "stream", "panel": "panel", "panel256": "panel", "panel256x2": "panel", "panel64": "panel",
              "wide": "wide", "w16x2": "wide", "w8": "wide", "w128": "wide", "w128x2": "wide", "walk": "wide", "plain": "wide"}
 REGIMES = ((1, 8, "1-8"), (9, 32, "9-32"), (33, 64, "33-64"), (65, 256, "65-256"), (257, 1024, "257-1024"), (1025, 1 << 30, ">1024"))
 

@@ -24,7 +24,7 @@ for (N, K) in shapes:
             # page tables of that point: "auto" read 5-9 % slower than the identical forced launch in the first version)
             cands = {"auto": None, "column": dict(kernel=3) if M <= 32 else 0, "stream": dict(kernel=1) if M <= 256 else 0,
                      "tiled": dict(kernel=2) if (M > 32 and K % 128 == 0) else 0, "panel": dict(kernel=4) if M > 8 else 0,
-                     "panel256": dict(kernel=4, bm=256) if M > 8 else 0, "panel256x2": dict(kernel=4, bm=256, pw=2, pf=4) if M >= 256 else 0,
+                     "panel256": dict(kernel=4, bm=256) if M > 8 else 0, "panel64": dict(kernel=4, mt=4) if 64 < M <= 1024 else 0, "panel256x2": dict(kernel=4, bm=256, pw=2, pf=4) if M >= 256 else 0,
                      "wide": dict(kernel=5) if M > 256 else 0}
             if os.environ.get("WIDE_SHAPES") == "1" and M > 256:  # every shape of the wide kernel, for fitting its cost model
                 cands.update({"w16x2": dict(kernel=5, ksplit=2), "w8": dict(kernel=5, mt=8), "w128": dict(kernel=5, bm=128),
@@ -38,12 +38,12 @@ for (N, K) in shapes:
                     samples[k].extend(layer.time_calls(A, s1, D, max(2, iters // 3), tune=tune) * 1e3)
             p = _lib.plan(M, N, K, 128 if grouped else -1, 16)
             res = {k: float(np.median(v)) for k, v in samples.items()}
-            for k in ("column", "stream", "tiled", "panel", "panel256", "panel256x2", "wide"):
+            for k in ("column", "stream", "tiled", "panel", "panel256", "panel256x2", "panel64", "wide"):
                 res.setdefault(k, float("nan"))
             best = min((v, k) for k, v in res.items() if v == v and k != "auto")
             flag = "" if res["auto"] <= best[0] * 1.03 else f"   <-- {best[1]} is {100 * (res['auto'] / best[0] - 1):.0f}% faster"
             extra = "".join(f" {k} {res[k]:7.1f}" for k in ("w16x2", "w8", "w128", "w128x2", "walk", "plain") if k in res)
-            print(f"N={N:5d} K={K:5d} {mode:4s} M={M:4d}  auto(k{p['kernel']},ks{p['ksplit']}{',walk' if p['kernel'] == 5 and p['glds'] == 2 else ''}{',split@' + str(p['split_m']) if p.get('split_m') else ''}) {res['auto']:7.1f} | column {res['column']:7.1f} stream {res['stream']:7.1f} tiled {res['tiled']:7.1f} panel {res['panel']:7.1f} panel256 {res['panel256']:7.1f} panel256x2 {res['panel256x2']:7.1f} wide {res['wide']:7.1f}{extra}{flag}")
+            print(f"N={N:5d} K={K:5d} {mode:4s} M={M:4d}  auto(k{p['kernel']},ks{p['ksplit']}{',walk' if p['kernel'] == 5 and p['glds'] == 2 else ''}{',split@' + str(p['split_m']) if p.get('split_m') else ''}) {res['auto']:7.1f} | column {res['column']:7.1f} stream {res['stream']:7.1f} tiled {res['tiled']:7.1f} panel {res['panel']:7.1f} panel256 {res['panel256']:7.1f} panel256x2 {res['panel256x2']:7.1f} panel64 {res['panel64']:7.1f} wide {res['wide']:7.1f}{extra}{flag}")
             sys.stdout.flush()
         del layer
         torch.cuda.empty_cache()

@@ -17,11 +17,13 @@ FAMILY = {1: "stream", 2: "tiled", 3: "column", 4: "panel", 5: "wide"}
 WIDE = {(16, 256, 1): "wide", (16, 256, 2): "w16x2", (8, 256, 1): "w8", (16, 128, 1): "w128", (16, 128, 2): "w128x2"}
 
 
-def column_of(plan, measured):
+def column_of(plan, measured, M=0):
     """the dispatch_check column a plan corresponds to"""
     name = FAMILY[plan["kernel"]]
     if name == "panel" and plan["bm"] == 256:
         name = "panel256x2" if plan["pw"] == 2 else "panel256"
+    if name == "panel" and plan["mt"] == 4 and M > 64:
+        name = "panel64"  # several 64-token m-blocks (round 5): a column of its own -- the round-4 files measured "panel" with 128-token m-blocks
     if name == "wide":
         name = WIDE.get((plan["mt"], plan["bm"], plan["ksplit"]), "wide")
         if plan["glds"] == 2 and "walk" in measured:
@@ -44,7 +46,7 @@ def regrets(path):
         measured = {cells[i]: float(cells[i + 1]) for i in range(0, len(cells) - 1, 2)}
         measured = {k: v for k, v in measured.items() if v == v}  # (nan: variant not applicable at this point)
         plan = _lib.plan(M, N, K, 128 if mode == "g128" else -1, 16)
-        col = column_of(plan, measured)
+        col = column_of(plan, measured, M)
         if col in measured:
             out.append((N, K, mode, M, col, measured[col], min(measured.values())))
     return out
