@@ -56,6 +56,7 @@
 #include "qqq_tiled.hip.h"
 #include "qqq_wide.hip.h"
 #include "qqq_small.hip.h"
+#include "qqq_panel_rates.h"
 
 // ------------------------------------------------------------------------------------------
 // host side: validation (mirrors the reference's), dispatch, C-ABI
@@ -606,65 +607,34 @@ static double stream_estimate(int M, int N, int K, bool grouped, bool have_scrat
   return grouped ? us * 1.15 : us;
 }
 
-// panel: 128-token m-blocks x bn-column strips x K slices; one workgroup per CU and round (mt = 8); measured ~0.47 us
-// per 128-k stage (bn = 128, per-channel), twice that for bn = 256, x1.45 per-group; ~9 us of launch / pipeline fill /
-// epilogue and 5..8.5 us for the in-launch split-K hand-off (deposit, ticket, fold by the last arrival)
+// panel: all tokens of an m-block (16 ... 128) x bn-column strips x K slices.  Priced from the GENERATED table qqq_panel_rates.h (tools/fit_panel_rates.py: one
+// linear form per (strip shape, m-block, mode), least squares over every forced panel variant of profiles/r05_dispatch_check_*.txt -- 2600 measurements, 2 ... 5 % mean
+// error per group): us = rounds x (a + c [split] + d (slices - 2) + b x stages per workgroup).  Round 5 replaced the hand-fitted constants of rounds 2 - 4 here (they
+// were 10 ... 35 % high once the uneven K slices had shortened the hand-off).
 static double panel_estimate(int M, int N, int K, bool grouped, bool have_scratch, long long cap_rows, long long cap_tickets,
                              int* bn_out, int* ks_out, int* cw_out, int* mt_out = nullptr) {
   if (mt_out) *mt_out = 0;  // 0: the m-block the token count implies (16 / 32 / 64 / 128 rows)
   const int mt = (M <= 16) ? 1 : (M <= 32) ? 2 : (M <= 64) ? 4 : 8;
+  const int mti = mt == 1 ? 0 : mt == 2 ? 1 : mt == 4 ? 2 : 3;
   const int rows = 16 * mt;
   const long long mblocks = (M + rows - 1) / rows;
   const int NST = (K / 64 + 1) / 2;
   double best = 1e30;
-  for (int bn = 128; bn <= 256; bn *= 2) {
+  for (int shape = 0; shape < 3; ++shape) {  // 128-column strips; 256-column strips; 256-column strips with 64 columns per wave (128-token m-blocks)
+    if (shape == 2 && mt != 8) continue;
+    const int bn = shape == 0 ? 128 : 256;
+    const QqqPanelRate& r = kQqqPanelRates[shape][mti][grouped ? 1 : 0];
+    if (r.b <= 0.0) continue;
     const long long tl = mblocks * ((N + bn - 1) / bn);
-    const double t_stage = ((mt == 8 && bn == 128) ? 0.506 : 0.13 + 0.042 * mt) * (bn == 256 ? 1.9 : 1.0) * (grouped ? (mt == 8 ? 1.45 : 1.6) : 1.0);
     for (int ks = 1; ks <= 4; ++ks) {
       if (ks > 1 && (!have_scratch || 2 * tl > cap_tickets || tl * rows * bn * (ks - 1) > cap_rows * (long long)N || ks > NST / 4)) break;  // slots: tiles x (ks-1) x rows x bn ints inside C
-      static const double tail[5] = {0.0, 0.0, 5.0, 6.5, 8.5};  // (fold by sc1 loads, no acquire fence: profiles/r02_panel_handoff.txt)
-      // (tools/cost_model_report.py, round 5: this form prices 65 ... 256 tokens 11 % high on average -- most on layers that leave CUs idle -- and a
-      //  version with a smaller tail and a fill factor was within 4 %, but ORDERED the families worse on the measured points (7 of 13 regret files
-      //  red): the constants here are calibrated for the ordering, which is what a dispatcher needs; the report keeps the absolute error in view)
-      // (one unsplit round of 128-token m-blocks: 7.4 -- 4096 / 5120-square layers at 768 tokens measured 23.5 / 27.5 us per-channel, 30.4 / 36.7 per-group,
-      // profiles/r04_dispatch_check_mid_shapes.txt)
-      const double wg_us = ((mt == 8 && ks == 1 && tl <= 256) ? 7.4 : 8.7) + tail[ks] + ((double)NST / ks) * t_stage;
-      double us = (double)((tl * ks + 255) / 256) * wg_us;
-      if (mt == 4 && bn == 128) {
-        // 64-token m-blocks x 128 columns, refitted over ten layer shapes in both modes (round 4, profiles/r04_dispatch_check_final*.txt;
-        // the form above was 2 ... 5 us high on every layer smaller than the BASELINE one): 11.5 us of launch / fill / hand-off / epilogue
-        // whatever the number of slices (10 unsplit; per-group + 0.4), 0.316 us per 128-k stage (per-group 0.52), and never faster than the weight matrix
-        // at 5.3 TB/s (per-group: x1.45 -- the re-quantiser and the stream do not overlap fully)
-        const double rounds = (double)((tl * ks + 255) / 256);
-        const double stage_us = rounds * ((double)NST / ks) * (grouped ? 0.52 : 0.316);
-        const double bytes_us = (double)N * K / 2.0 / 5.3e6 * (grouped ? 1.45 : 1.0);
-        us = rounds * ((ks == 1 ? 10.0 : 11.5) + (grouped ? 0.4 : 0.0)) + (stage_us > bytes_us ? stage_us : bytes_us);
-      }
+      const double rounds = (double)((tl * ks + 255) / 256);
+      const double us = rounds * (r.a + (ks > 1 ? r.c : 0.0) + (ks > 2 ? r.d * (ks - 2) : 0.0) + r.b * (double)NST / ks);
       if (us < best) {
         best = us;
         *bn_out = bn;
         *ks_out = ks;
-        *cw_out = 1;
-      }
-    }
-  }
-  // 64 columns per wave (bn = 256, 128-token m-blocks, per-channel): ~0.8 us per stage, workgroups of later rounds start
-  // as CUs free up (no per-round launch cost), a per-workgroup fixed part that weighs more on short K slices
-  // (profiles/r02_panel_cw2.txt)
-  if (mt == 8) {  // (per-group: x1.365 per stage -- the re-quantiser fills the VALU; wins up to ~1-2 K tokens, r02_dispatch_check_g128.txt)
-    const long long tl = mblocks * ((N + 255) / 256);
-    const double t2 = 0.805 * (grouped ? 1.365 : 1.0);
-    for (int ks = 1; ks <= 4; ++ks) {
-      if (ks > 1 && (!have_scratch || 2 * tl > cap_tickets || tl * rows * 256 * (ks - 1) > cap_rows * (long long)N || ks > NST / 4)) break;
-      static const double tail[5] = {0.0, 0.0, 7.0, 9.0, 11.0};
-      const double nst_k = (double)NST / ks;
-      const double wg_us = 5.0 + 100.0 / nst_k + tail[ks] + nst_k * t2 * (ks > 1 ? 1.04 : 1.0);
-      const double us = 3.7 + (double)((tl * ks + 255) / 256) * wg_us;
-      if (us < best) {
-        best = us;
-        *bn_out = 256;
-        *ks_out = ks;
-        *cw_out = 2;
+        *cw_out = shape == 2 ? 2 : 1;
       }
     }
   }
@@ -672,17 +642,19 @@ static double panel_estimate(int M, int N, int K, bool grouped, bool have_scratc
   // stages each, twice the workgroups of half the size finish sooner although every m-block streams the weights again (from L2 / the Infinity Cache) --
   // 4096 x 4096 at 128 / 256 / 512 tokens 13.1 / 15.2 / 18.4 us against 15.2 / 17.7 / 19.4, 4096 x 11008 and 11008 x 4096 at 128 tokens 18.3 / 18.5 against
   // 21.5 / 20.0, 8192 x 8192 21.3 against 22.1; not on the BASELINE layer (40.1 vs 35.4: the weights come from HBM twice) and not beyond one round of
-  // workgroups (11008 x 4096 at 256 tokens 27.7 vs 23.3).  Priced with the 64-token form above (within 1.0 us of nine of the ten points measured), the
-  // weight bytes once per m-block; one round only.
-  // (measured on layers of 4096 ... 11008 columns; narrower ones -- N = 1024 at 256 tokens is the stream kernel's, 13.7 us -- are left as they were)
-  if (mt == 8 && mt_out && N >= 4096) {
+  // workgroups (11008 x 4096 at 256 tokens 27.7 vs 23.3).  Priced with the 64-token form above; one round only.
+  // (the form holds on narrow layers as well: 74 single-round points with N < 4096 in profiles/r05_dispatch_check_*.txt, mean error 3.9 %)
+  if (mt == 8 && mt_out) {
     const long long mb4 = (M + 63) / 64, tl = mb4 * ((N + 127) / 128);
     for (int ks = 1; ks <= 4; ++ks) {
       if (tl * ks > 256) break;
       if (ks > 1 && (!have_scratch || 2 * tl > cap_tickets || tl * 64 * 128 * (ks - 1) > cap_rows * (long long)N || ks > NST / 4)) break;
+      // (fitted on the single-round points of profiles/r05_dispatch_check_panel64.txt -- fourteen layer shapes x 80 ... 512 tokens x both modes -- and checked on all
+      //  330 of profiles/r05_dispatch_check_*.txt: 8.0 us unsplit / 10.0 split, 0.316 (0.52) us per stage, every further m-block 0.8 of a weight pass at 5.3 TB/s:
+      //  mean error 2.7 %, worst 10 %)
       const double stage_us = ((double)NST / ks) * (grouped ? 0.52 : 0.316);
-      const double bytes_us = (double)mb4 * N * K / 2.0 / 5.3e6 * (grouped ? 1.45 : 1.0);
-      const double us = (ks == 1 ? 10.0 : 11.5) + (grouped ? 0.4 : 0.0) + (stage_us > bytes_us ? stage_us : bytes_us);
+      const double bytes_us = (1.0 + 0.8 * (double)(mb4 - 1)) * N * K / 2.0 / 5.3e6 * (grouped ? 1.45 : 1.0);
+      const double us = (ks == 1 ? 8.0 : 10.0) + (grouped ? 0.4 : 0.0) + (stage_us > bytes_us ? stage_us : bytes_us);
       if (us < best) {
         best = us;
         *bn_out = 128;

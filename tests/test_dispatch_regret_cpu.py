@@ -1,8 +1,9 @@
 """The dispatcher against this repository's own hardware measurements, without a GPU: every committed `tools/dispatch_check.py`
-output of round 4 (automatic choice and every forced family, timed interleaved on an MI355X) is replayed against the plans of the
-CURRENT library (`qqq_w4a8_plan` is pure host logic).  A change to a cost model that sends some measured point to a clearly slower
-family fails here; the bounds are what the final library of round 4 reaches on these files plus a little room (the measurements
-carry their box's noise: 3-5 % at the 10-20 us points)."""
+output of round 5 (automatic choice and every forced family -- column, stream, the panel kernel's strip shapes and m-blocks, every wide shape -- timed
+interleaved on an MI355X running the round-5 library; the grids are round 4's, measured again after the uneven K slices changed the panel / wide hand-off)
+is replayed against the plans of the CURRENT library (`qqq_w4a8_plan` is pure host logic).  A change to a cost model that sends some measured point to a
+clearly slower family fails here; the bounds are what the final library of round 5 reaches on these files plus a little room (the measurements carry their
+box's noise: 3-5 % at the 10-20 us points).  How far each model is from the clock in absolute terms: tests/test_cost_models_cpu.py."""
 import os
 import sys
 
@@ -13,21 +14,16 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 # file -> (least number of points, most points above 3 %, worst regret allowed)
 FILES = {
-    "r04_dispatch_check_final.txt": (75, 6, 0.09),          # BASELINE + Llama-2-7B layers, 1 ... 8192 tokens
-    "r04_dispatch_check_final_shapes.txt": (80, 11, 0.09),  # six other layer shapes
-    "r04_dispatch_check_mid_shapes.txt": (130, 14, 0.11),   # nine shapes at 96 ... 4096 tokens, every wide variant
-    "r04_dispatch_check_m64.txt": (80, 6, 0.09),            # ten shapes at 40 ... 64 tokens
-    "r04_dispatch_check_m16.txt": (100, 6, 0.08),           # ten shapes at 9 ... 32 tokens
-    "r04_dispatch_check_mid.txt": (15, 3, 0.06),            # BASELINE layer at 320 ... 3072 tokens
-    "r04_dispatch_check_after.txt": (75, 10, 0.16),         # the first two sets measured again on the library after all the refits (same-plan launch noise
-    "r04_dispatch_check_after_shapes.txt": (80, 18, 0.20),  #  at 8-10 us included; the 18 % line is a forced 256-column panel with ANOTHER K split than the plan's)
-    "r04_dispatch_check_merged.txt": (90, 5, 0.08),         # merged projections (N = 12288 / 22016) and narrow layers (N = 2048 / 1024)
-    # Qwen2-7B / Mistral-7B layers; the 26 % point (N = 18944 at 16 tokens) is the stream kernel measured with the two K slices it no longer uses there
-    # (profiles/r04_stream_ksplit_wide_n.txt: 10.9 us unsplit against the 14.6 in this file; the column kernel's 11.6 is the "best" it is held against)
-    "r04_dispatch_check_qwen_mistral.txt": (140, 20, 0.27),
-    # Yi-34B / Phi-3 / Llama-70B k,v / Qwen2-72B layers; the 29-37 % points (N = 7168, K = 20480 at <= 16 tokens) are the stream kernel measured with the five
-    # K slices (280 workgroups) it no longer uses there (r04_stream_ksplit_wide_n.txt: 18.9 / 22.2 us with four against the 22.7 / 28.6 in this file)
-    "r04_dispatch_check_more_models.txt": (155, 22, 0.38),
+    "r05_dispatch_check_m16.txt": (93, 9, 0.17),  # ten shapes at 9 ... 32 tokens
+    "r05_dispatch_check_m64.txt": (74, 12, 0.18),  # ten shapes at 40 ... 64 tokens
+    "r05_dispatch_check_main.txt": (74, 12, 0.12),  # BASELINE + Llama-2-7B layers, 1 ... 8192 tokens, every wide shape
+    "r05_dispatch_check_merged.txt": (87, 6, 0.1),  # merged projections (N = 12288 / 22016) and narrow layers (N = 2048 / 1024)
+    "r05_dispatch_check_mid.txt": (16, 3, 0.06),  # BASELINE layer at 320 ... 3072 tokens
+    "r05_dispatch_check_mid_shapes.txt": (131, 18, 0.18),  # nine shapes at 96 ... 4096 tokens, every wide shape
+    "r05_dispatch_check_more_models.txt": (148, 17, 0.14),  # Yi-34B / Phi-3 / Llama-70B k,v / Qwen2-72B layers
+    "r05_dispatch_check_panel64.txt": (204, 20, 0.12),  # fourteen shapes at 80 ... 512 tokens with the 64-token m-block column
+    "r05_dispatch_check_qwen_mistral.txt": (130, 10, 0.16),  # Qwen2-7B / Mistral-7B layers
+    "r05_dispatch_check_shapes.txt": (78, 15, 0.13),  # six other layer shapes
 }
 
 

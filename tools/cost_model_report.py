@@ -5,7 +5,7 @@ For each line of the `tools/dispatch_check.py` outputs under profiles/ (automati
 library's models are asked for their price of each family (`qqq_w4a8_model_us`, pure host logic) and compared with the fastest measured variant of that
 family at that point.  Per family and token regime: number of points, mean |error|, bias (model / measured - 1, mean) and the worst point.
 
-    python tools/cost_model_report.py [files ...]  > profiles/r05_cost_model_error.txt        (default: every profiles/r04_dispatch_check_*.txt)
+    python tools/cost_model_report.py [files ...]  > profiles/r05_cost_model_error.txt        (default: every profiles/r05_dispatch_check_*.txt)
 
 What the numbers are for: a model only has to ORDER the families correctly (tests/test_dispatch_regret_cpu.py checks that on the same files); this report
 says how far each is from the clock -- which constants a kernel change has moved, and by how much -- without a refit by eye."""
@@ -38,7 +38,7 @@ def points(path):
         best = {}
         for col, us in measured.items():
             fam = FAMILY_OF.get(col)
-            if fam and us == us:
+            if fam and us == us and not (fam == "wide" and M <= 1024 and "w128" not in measured):  # (a file without the wide shapes: the lone 256 x 256 column is no measure of the family)
                 best[fam] = min(best.get(fam, 1e30), us)
         model = _lib.model_us(M, N, K, 128 if mode == "g128" else -1, 16)
         for fam, us in model.items():
@@ -75,5 +75,5 @@ def main(files):
 
 
 if __name__ == "__main__":
-    files = sys.argv[1:] or sorted(glob.glob(os.path.join(ROOT, "profiles", "r04_dispatch_check_*.txt")))
+    files = sys.argv[1:] or sorted(glob.glob(os.path.join(ROOT, "profiles", "r05_dispatch_check_*.txt")))
     main(files)

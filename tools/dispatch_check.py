@@ -23,7 +23,8 @@ for (N, K) in shapes:
             # every variant timed in turn, `ROUNDS` times over (the first variant of a point otherwise pays for the cold A / D /
             # page tables of that point: "auto" read 5-9 % slower than the identical forced launch in the first version)
             cands = {"auto": None, "column": dict(kernel=3) if M <= 32 else 0, "stream": dict(kernel=1) if M <= 256 else 0,
-                     "tiled": dict(kernel=2) if (M > 32 and K % 128 == 0) else 0, "panel": dict(kernel=4) if M > 8 else 0,
+                     "tiled": dict(kernel=2) if (M > 32 and K % 128 == 0 and os.environ.get("TILED") == "1") else 0,  # (no longer a candidate of the automatic dispatch)
+                     "panel": dict(kernel=4, mt=8 if M > 64 else 0) if M > 8 else 0,
                      "panel256": dict(kernel=4, bm=256) if M > 8 else 0, "panel64": dict(kernel=4, mt=4) if 64 < M <= 1024 else 0, "panel256x2": dict(kernel=4, bm=256, pw=2, pf=4) if M >= 256 else 0,
                      "wide": dict(kernel=5) if M > 256 else 0}
             if os.environ.get("WIDE_SHAPES") == "1" and M > 256:  # every shape of the wide kernel, for fitting its cost model
