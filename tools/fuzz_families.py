@@ -40,6 +40,9 @@ while time.time() < t_end:
     picks = [vs[i] for i in rng.choice(len(vs), size=min(10, len(vs)), replace=False)] + [dict()]
     n_prob += 1
     for tune in picks:
+        # round 5: uneven K slices -- a random skew (-1 = even, 0 = automatic, 1 ... 12 stages / steps; the host clamps it) on half of the split-capable picks
+        if tune and tune.get("kernel") in (1, 4, 5) and "skew" not in tune and rng.random() < 0.5:
+            tune = dict(tune, skew=int(rng.integers(-1, 13)))
         loaded = bool(rng.integers(0, 2))
         if loaded:
             with torch.cuda.stream(side):
