@@ -76,5 +76,7 @@ for M in [int(x) for x in os.environ.get("MS", "128").split(",")]:
         g = xcc.reshape(-1, ks, -(-NN // bn))  # (mblk, slice, strip)
         same = (g == g[:, :1, :]).all(axis=1).mean()
         print(f"   tiles whose {ks} slices ran on one XCD: {same * 100:.0f} %;  entry skew between a tile's slices (us): {q((us[:, 0].reshape(g.shape).max(axis=1) - us[:, 0].reshape(g.shape).min(axis=1)).ravel())}")
+        sl = np.broadcast_to(np.arange(ks)[None, :, None], g.shape).ravel()  # the K slice of every workgroup (grid: strip fastest, then slice, then m-block)
+        print(f"   the finisher (last arrival) is the LAST K slice -- the longer one when the slices are uneven (plan skew {p.get('skew', 0)}) -- in {100 * (sl[last] == ks - 1).mean():.0f} % of the tiles")
         fin_wait = us[last, 5] - us[last, 4]
         print(f"   finisher: wait for the other slices' deposits {q(fin_wait)} us, fold {q(us[last, 6] - us[last, 5])} us, epilogue {q(us[last, 7] - us[last, 6])} us")
