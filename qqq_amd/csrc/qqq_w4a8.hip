@@ -56,7 +56,7 @@
 #include "qqq_tiled.hip.h"
 #include "qqq_wide.hip.h"
 #include "qqq_small.hip.h"
-#include "qqq_panel_rates.h"
+#include "qqq_rates.h"
 
 // ------------------------------------------------------------------------------------------
 // host side: validation (mirrors the reference's), dispatch, C-ABI
@@ -609,7 +609,7 @@ static double stream_estimate(int M, int N, int K, bool grouped, bool have_scrat
   return grouped ? us * 1.15 : us;
 }
 
-// panel: all tokens of an m-block (16 ... 128) x bn-column strips x K slices.  Priced from the GENERATED table qqq_panel_rates.h (tools/fit_panel_rates.py: one
+// panel: all tokens of an m-block (16 ... 128) x bn-column strips x K slices.  Priced from the GENERATED table qqq_rates.h (tools/fit_rates.py: one
 // linear form per (strip shape, m-block, mode), least squares over every forced panel variant of profiles/r05_dispatch_check_*.txt -- 2600 measurements, 2 ... 5 % mean
 // error per group): us = rounds x (a + c [split] + d (slices - 2) + b x stages per workgroup).  Round 5 replaced the hand-fitted constants of rounds 2 - 4 here (they
 // were 10 ... 35 % high once the uneven K slices had shortened the hand-off).
@@ -692,8 +692,12 @@ static double wide_estimate(int M, int N, int K, bool grouped, bool have_scratch
     const int mt = shape == 2 ? 8 : 16, bn = shape == 1 ? 128 : 256;
     const int rows = 16 * mt;
     const long long tl = (long long)((M + rows - 1) / rows) * ((N + bn - 1) / bn);
-    const double t_stage = shape == 0 ? (grouped ? 1.635 : 1.25) : shape == 1 ? (grouped ? 0.96 : 0.70) : (grouped ? 1.17 : 0.725);
-    const double fixed = shape == 0 ? 12.0 : 7.0;
+    // (round 5: fixed / t_stage / hand-off per shape and mode from the GENERATED table qqq_rates.h -- tools/fit_rates.py, least squares over every forced wide variant of
+    //  profiles/r05_dispatch_check_*.txt, 2.3 ... 3.9 % mean error per group; the hand-fitted values above -- 12 / 7 us, 1.25 / 0.70 / 0.725 us per stage, 15 us per
+    //  256 KiB -- are the history: the uneven K slices took the hand-off to 11-12.6)
+    const QqqWideRate& wr = kQqqWideRates[shape][grouped ? 1 : 0];
+    const double t_stage = wr.t_stage;
+    const double fixed = wr.fixed;
     for (int ks = 1; ks <= (mt == 16 ? 2 : 1); ++ks) {
       // one slot of rows x bn ints per tile and depositing slice inside C, two ticket words per tile
       if (ks > 1 && (!have_scratch || 2 * tl > cap_tickets || tl * rows * bn * (ks - 1) > cap_rows * (long long)N || ks > NST / 4)) break;
@@ -706,7 +710,7 @@ static double wide_estimate(int M, int N, int K, bool grouped, bool have_scratch
       const double lo = grouped ? 0.85 : 0.80, rel = x <= 0.5 ? 0.0 : (x - 0.5) / 0.5;
       const double load = x <= 1.0 ? lo + (1.0 - lo) * rel * rel : 1.0;
       // (15 us per 256 KiB of partial tile since the deposits stay in the XCD's L2, 20-23 written through: profiles/r04_wide_xcd_local_deposits.txt)
-      const double handoff = ks > 1 ? 15.0 * (double)(rows * bn) / 65536.0 : 0.0;
+      const double handoff = ks > 1 ? wr.handoff * (double)(rows * bn) / 65536.0 : 0.0;
       const double us = 3.7 + rounds * (fixed + handoff + ((double)NST / ks) * t_stage * load);
       if (us < best) {
         best = us;
@@ -751,7 +755,7 @@ static int stream_auto_skew(int N, int K, int ksplit) {
 // Llama-2-7B down_proj (4096 x 11008) at 1024 tokens 50.1 -> 48.6, per-group 62.3 -> 58.1 (3).
 static int wide_auto_skew(int mt, int bn, bool grouped, int NST, int ksplit) {
   (void)NST;
-  const double t_stage = (mt == 16 && bn == 256) ? (grouped ? 1.635 : 1.25) : (mt == 16) ? (grouped ? 0.96 : 0.70) : (grouped ? 1.17 : 0.725);
+  const double t_stage = kQqqWideRates[(mt == 16 && bn == 256) ? 0 : (mt == 16) ? 1 : 2][grouped ? 1 : 0].t_stage;
   const double latency = 20.0 * (16.0 * mt * bn) / 65536.0;
   const int sk = (int)(latency / (t_stage * ksplit / (ksplit - 1.0)) + 0.5);
   return sk < 1 ? 1 : sk;

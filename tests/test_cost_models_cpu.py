@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 BOUNDS = {
     ("column", "1-8"): (85, 0.10, 0.07), ("column", "9-32"): (180, 0.09, 0.05),
     ("stream", "1-8"): (85, 0.09, 0.08), ("stream", "9-32"): (180, 0.07, 0.04), ("stream", "33-64"): (125, 0.07, 0.05), ("stream", "65-256"): (300, 0.07, 0.04),
-    # the panel family is priced from the GENERATED table (tools/fit_panel_rates.py -> qqq_amd/csrc/qqq_panel_rates.h) since round 5
+    # the panel family is priced from the GENERATED table (tools/fit_rates.py -> qqq_amd/csrc/qqq_rates.h) since round 5
     ("panel", "33-64"): (125, 0.05, 0.03), ("panel", "65-256"): (300, 0.06, 0.04), ("panel", "257-1024"): (230, 0.06, 0.04), ("panel", ">1024"): (155, 0.06, 0.04),
     ("wide", "257-1024"): (150, 0.06, 0.04), ("wide", ">1024"): (155, 0.06, 0.05),
 }
@@ -46,18 +46,20 @@ def test_model_prices_follow_the_plan():
                 assert fam[plan["kernel"]] == best or abs(prices[fam[plan["kernel"]]] - prices[best]) < 1e-9, (m, n, k, gs, prices, plan["kernel"])
 
 
-def test_panel_rate_table_is_what_the_tool_generates():
-    """qqq_amd/csrc/qqq_panel_rates.h is GENERATED (tools/fit_panel_rates.py, least squares over every forced panel variant of the committed dispatch
-    checks): re-running the fit on the committed measurements reproduces the committed coefficients -- nobody edited the table by hand, and nobody changed the
-    measurements without regenerating it."""
+def test_rate_tables_are_what_the_tool_generates():
+    """qqq_amd/csrc/qqq_rates.h is GENERATED (tools/fit_rates.py, least squares over every forced panel / wide variant of the committed dispatch checks):
+    re-running the fit on the committed measurements reproduces the committed coefficients -- nobody edited a table by hand, and nobody changed the
+    measurements without regenerating them."""
     import re
 
-    import fit_panel_rates as F
+    import fit_rates as F
 
-    data = F.collect(sorted(glob.glob(os.path.join(ROOT, "profiles", "r05_dispatch_check_*.txt"))))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r05_dispatch_check_*.txt")))
     text = open(F.OUT).read()
-    rows = [tuple(float(v) for v in m) for m in re.findall(r"\{(-?[\d.]+), (-?[\d.]+), (-?[\d.]+), (-?[\d.]+)\}", text)]
+    panel_text, wide_text = text.split("struct QqqWideRate")
+    rows = [tuple(float(v) for v in m) for m in re.findall(r"\{(-?[\d.]+), (-?[\d.]+), (-?[\d.]+), (-?[\d.]+)\}", panel_text)]
     assert len(rows) == 24
+    data = F.collect(files)
     i = 0
     fitted = 0
     for ci in range(3):
@@ -73,3 +75,13 @@ def test_panel_rate_table_is_what_the_tool_generates():
                     assert rows[i] == (0.0, 0.0, 0.0, 0.0)
                 i += 1
     assert fitted == 18
+    wrows = [tuple(float(v) for v in m) for m in re.findall(r"\{(-?[\d.]+), (-?[\d.]+), (-?[\d.]+)\}", wide_text)]
+    assert len(wrows) == 6
+    wide = F.collect_wide(files)
+    for shape in range(3):
+        for gi, g in enumerate((False, True)):
+            coef, n, mae, bias, worst = F.fit_wide(wide[(shape, g)])
+            got = wrows[2 * shape + gi]
+            assert n >= 150 and mae < 0.05 and abs(coef[0] - got[0]) < 2e-3 and abs(coef[2] - got[2]) < 2e-4, (shape, g, coef, got, mae)
+            if coef[1] != 0.0:
+                assert abs(coef[1] - got[1]) < 2e-3
