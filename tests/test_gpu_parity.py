@@ -833,3 +833,19 @@ def test_sms_caps_the_compute_units_of_a_call(dev):
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(D, outs[-1])
+
+
+def test_local_deposit_kill_switch_env(dev):
+    """QQQ_AMD_NO_LOCAL_DEPOSITS=1 (read once per process) forces every split-K deposit of the wide kernel to be written through -- the escape hatch
+    should a driver / partition-mode change ever break the XCD-local hand-off.  Same results, in a process of its own."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, QQQ_AMD_NO_LOCAL_DEPOSITS="1")
+    cmd = [sys.executable, os.path.join(root, "tools", "check_variant.py"), "--nk", "4096,4096", "--ms", "700,1024",
+           "--tunes", "[dict(kernel=5, ksplit=2), dict(kernel=5, bm=128, ksplit=2, skew=3), dict(kernel=5, mt=8, ksplit=3)]", "--ref", "dict(kernel=4, ksplit=1)"]
+    p = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    out = p.stdout + p.stderr
+    assert p.returncode == 0 and "MISMATCH" not in out and out.count("bit-exact") == 12, out[-2000:]
