@@ -858,7 +858,13 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
     // (128 x 128 tiles compile from the same template and were measured: 39 us at M=128 against the panel kernel's 36, 4 % ahead
     // of it only at 160-256 tokens in two K slices -- not instantiated; profiles/r03_wide_128x128.txt)
     pl.stages = 1;                                        // activation lead: the LDS-DMA of a stage is issued a full stage ahead
-    pl.pf = (t.pf == 8 || t.pf == 4) ? t.pf : (grouped ? 8 : 4);  // weight ring in 64-k steps (per-group: 8 measured 1.5 % ahead)
+    // weight ring in 64-k steps.  Round 3 had per-channel 4 / per-group 8 (8 measured 1.5 % ahead per-group THEN).  Round 5, same A/B with the variants repeated in the
+    // interleaved list (profiles/r05_wide_ring_depth.txt): for the 256 x 256 tiles it is now the other way round -- per-channel 8: 449.8 vs 456.2 us at 4096 tokens,
+    // per-group 4: 584.1 vs 594.4 -- and the compiled code says why: of the two instantiations of a mode the slower one carries the register spills (69 / 27 scratch
+    // instructions against 3, all in the epilogue, none in the loop: tools/code_object.py); the ring depth moves hipcc's allocation at the seam between loop and epilogue.
+    // The other shapes (no spills either way) measure level and keep their depths.
+    const bool big_tile = (pl.mt == 16 && pl.bm == 256);
+    pl.pf = (t.pf == 8 || t.pf == 4) ? t.pf : (big_tile ? (grouped ? 4 : 8) : (grouped ? 8 : 4));
     pl.pw = (t.pw == 4 || t.pw == 8 || t.pw == 16 || t.pw == 32) ? t.pw : 8;
     const int rows = 16 * pl.mt;
     const long long tl = (long long)((M + rows - 1) / rows) * ((N + pl.bm - 1) / pl.bm);
