@@ -68,7 +68,8 @@ __global__ __launch_bounds__(WAVES * 64) void qqq_column_kernel(
     h2 sc;
   };
   auto load_step = [&](const int s, Step& r) {
-    r.w = *reinterpret_cast<const v4u*>(bptr + (size_t)(4 * s) * rowbytes);
+    if constexpr ((QQQ_W_NT & 1) != 0) r.w = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(bptr + (size_t)(4 * s) * rowbytes));
+    else r.w = *reinterpret_cast<const v4u*>(bptr + (size_t)(4 * s) * rowbytes);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) r.x[mt] = *reinterpret_cast<const v4i*>(xptr[mt] + 64 * s);
     if constexpr (GROUPED) r.sc = *reinterpret_cast<const h2*>(sptr + (size_t)(s >> 1) * N);

@@ -10,6 +10,15 @@
 
 #include "../../include/qqq_amd.h"
 
+// Weight loads: each byte of B is read once per launch, so its lines need not stay in the vector L1 / L2 behind the load.  Marking them non-temporal (`nt`)
+// pays where a wave instruction takes whole 128-byte lines ONCE -- the column kernel (decode: 17.9 -> 16.3 us on the BASELINE layer, 10.4 -> 8.9 on
+// 4096 x 11008) and the panel kernel's 64-token m-blocks (-5.5 % at 64 tokens) -- and costs where a lane comes back to its line with further 16-byte loads
+// (stream kernel: +11 % at 16 tokens) or the loop is bound elsewhere (panel kernel at 128 tokens +1.7 %, wide kernel level).  profiles/r05_nt_weight_loads.txt;
+// a bare HBM stream of 16-byte loads runs 14 % faster with `nt` (tools/l2_fill_bench.hip).  Bits: 1 column, 2 stream, 4 panel (MT <= 4), 8 wide, 16 panel (MT = 8);
+// the default is what measured faster, other values are measurement builds.
+#ifndef QQQ_W_NT
+#define QQQ_W_NT 5
+#endif
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 typedef unsigned int v4u __attribute__((ext_vector_type(4)));

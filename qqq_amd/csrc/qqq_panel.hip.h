@@ -170,7 +170,10 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
     int s = 2 * st + (KG == 2 ? kg : t);
     if (s >= KS) s = KS - 1;
 #pragma unroll
-    for (int hf = 0; hf < HW; ++hf) dst[hf] = *reinterpret_cast<const v4u*>(wptr + (size_t)(4 * s) * rowbytes + 256 * hf);
+    for (int hf = 0; hf < HW; ++hf) {
+      if constexpr (((QQQ_W_NT & 4) != 0 && MT <= 4) || ((QQQ_W_NT & 16) != 0 && MT > 4)) dst[hf] = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(wptr + (size_t)(4 * s) * rowbytes + 256 * hf));
+      else dst[hf] = *reinterpret_cast<const v4u*>(wptr + (size_t)(4 * s) * rowbytes + 256 * hf);
+    }
   };
   auto load_sc = [&](const int st_rel, h2 (&dst)[HW]) {
     const int st = st_begin + (st_rel < nst ? st_rel : nst - 1);

@@ -83,11 +83,8 @@ __global__ __launch_bounds__(WAVES * 64) void qqq_stream_kernel(
     const unsigned char* p = bptr + (size_t)(4 * s) * rowbytes;
 #pragma unroll
     for (int kq = 0; kq < 4; ++kq) {
-#ifdef QQQ_STREAM_NT
-      r.w[kq] = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(p + 16 * kq));  // streamed once
-#else
-      r.w[kq] = *reinterpret_cast<const v4u*>(p + 16 * kq);
-#endif
+      if constexpr ((QQQ_W_NT & 2) != 0) r.w[kq] = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(p + 16 * kq));  // streamed once
+      else r.w[kq] = *reinterpret_cast<const v4u*>(p + 16 * kq);
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) r.x[mt] = *reinterpret_cast<const v4i*>(xptr[mt] + 64 * s);

@@ -348,7 +348,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     (void)woff, (void)wdesc;
     so = __builtin_amdgcn_readfirstlane(so);
     asm("" : "+s"(so));
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=v"(dst) : "v"(woff), "s"(wdesc), "s"(so), "n"(256 * decltype(hfc)::value));
+    if constexpr ((QQQ_W_NT & 8) != 0)  // (measurement builds: non-temporal weight refills)
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4 nt" : "=v"(dst) : "v"(woff), "s"(wdesc), "s"(so), "n"(256 * decltype(hfc)::value));
+    else
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=v"(dst) : "v"(woff), "s"(wdesc), "s"(so), "n"(256 * decltype(hfc)::value));
   };
   auto load_w_so = [&](const unsigned so, v4u (&dst)[HW]) __attribute__((always_inline)) {
     qqq_static_for<HW>([&](auto hfc) { asm_load_w(dst[decltype(hfc)::value], hfc, so); });
