@@ -40,7 +40,8 @@ sys.path.insert(0, ROOT)
 
 N_FULL, K_FULL = 8192, 21760
 SWEEP_M = (1, 16, 128, 1024, 4096)
-NBUF = 5
+NBUF = 12  # weight copies per mode: 1.07 GB, so that a rotation never finds a copy in the 256 MiB Infinity Cache whatever its replacement policy (round 5: with 5 copies = 445 MB
+           # the per-M timing loop of the plain-load kernels did: decode read 17.9 us where 12 copies give 19.8; the column kernel's nt loads do not use that cache either way)
 MAX_PAR = 16
 PEAK_MFMA_TOPS = 5033.0  # dense int8: 256 CU x 2.4 GHz x 8192 op/clk/CU (MI355X_MICROARCH.md, = 2x bf16 2.5 PF)
 PEAK_HBM_GBS = 8000.0    # HBM3E spec; ~6300 achievable (MI355X_MICROARCH.md)
@@ -128,7 +129,9 @@ class Layer:
 
         L = _dev.lib()  # the event-timed loop lives in the test/tuning library; it calls the operator library's GEMM
         nb = len(self.Bs) if rotate else 1
-        arr = (ctypes.c_void_p * nb)(*[b.data_ptr() for b in self.Bs[:nb]])
+        rot = getattr(self, "_rot", 0) % nb  # the rotation goes on where the previous timed group stopped: a copy comes back after ALL the others
+        self._rot = rot + iters
+        arr = (ctypes.c_void_p * nb)(*[self.Bs[(rot + i) % nb].data_ptr() for i in range(nb)])
         out = (ctypes.c_float * iters)()
         tn = None
         if tune:
@@ -145,6 +148,11 @@ class Layer:
         if rc:
             raise RuntimeError(f"qqq_dev_bench_gemm rc={rc}: {_lib.last_error()} {_dev.last_error()}")
         return np.array(out[:], dtype=np.float64)
+
+
+def copies_for(N, K, total_bytes=1.1e9, lo=4, hi=160):
+    """weight copies of an N x K layer that make a rotation longer than anything the caches hold (tools/ab.py, tools/dispatch_check.py)"""
+    return int(min(hi, max(lo, -(-total_bytes // (N * K // 2)))))
 
 
 FAMILY = {1: "stream", 2: "tiled", 3: "column", 4: "panel", 5: "wide"}

@@ -76,7 +76,8 @@ typedef struct qqq_tune {
                   fold, 8 = agent-scope release on the depositor's completion count (both off as shipped: the deposits
                   are written through and read with agent-scope loads; the switches exist so that tests run both ways),
                   16 = wide: never keep a deposit in the XCD's L2 (as shipped, slices of a tile that find each other on one
-                  XCD do: DESIGN.md 3.4.2)                                                                        */
+                  XCD do: DESIGN.md 3.4.2), 32 = panel: plain grid order (as shipped the grid of a split K is walked so
+                  that the slices of a tile run on ONE XCD whatever the number of strips)                          */
   int bm;      /* tiled: rows per workgroup tile (64, 128, 256); panel: COLUMNS per workgroup (128, 256); wide: COLUMNS per
                   workgroup (256; 128 with mt = 16 only: 32 columns per wave); 0 auto */
   int glds;    /* tiled: 1 = direct global->LDS loads, 2 = register staged; 0 auto.

@@ -105,7 +105,25 @@ __global__ __launch_bounds__(64 * WN * KG) void qqq_panel_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave % WN;  // column set
   const int kg = wave / WN;  // k-group
-  const int strip = blockIdx.x, sp = blockIdx.y, mblk = blockIdx.z;
+  // Workgroup -> (strip, K slice).  The hardware deals consecutive workgroups round-robin to the 8 XCDs; with the plain grid order (strip = x, slice = y) the slices
+  // of a tile share an XCD only when the number of strips is a multiple of 8.  For a split K the grid is therefore walked 8 strips at a time through all their
+  // slices, so that every tile's slices meet in ONE L2 whatever N is and the finisher finds the other slices' deposits there: Llama-2-7B gate / up (N = 11008: 86 / 43
+  // strips) at 48 tokens 16.3 -> 15.5 us, 256-column strips 19.7 -> 17.5; N = 13824 18.2 -> 17.1 / 22.0 -> 18.9; nothing changes where it already was so (N = 4096,
+  // 12288) -- profiles/r05_panel_slices_one_xcd.txt.  hflags & 8 (tune.fused bit 5) keeps the plain order: measurement only.
+  int strip = blockIdx.x, sp = blockIdx.y;
+  if ((hflags & 8) == 0 && ksplit > 1) {
+    const int T = gridDim.x, L = blockIdx.x + T * blockIdx.y, full = (T >> 3) * 8 * ksplit;
+    if (L < full) {
+      const int r = L % (8 * ksplit);
+      strip = (L / (8 * ksplit)) * 8 + (r & 7);
+      sp = r >> 3;
+    } else {
+      const int rem = T & 7, l2 = L - full;
+      strip = (T & ~7) + l2 % rem;
+      sp = l2 / rem;
+    }
+  }
+  const int mblk = blockIdx.z;
   const int mbase = mblk * ROWS;
   const int ngroups = N >> 6;
   const int gl = (wn * HW) >> 1;  // 64-column group of this wave inside the strip

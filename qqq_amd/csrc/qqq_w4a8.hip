@@ -521,24 +521,32 @@ static double tiled_estimate(int M, int N, int K, bool grouped, bool have_scratc
   return best;
 }
 
-// 9 ... 32 tokens: the column kernel (one launch; every 32-column workgroup re-reads the m x K activations) against the stream kernel (K slices +
-// reduce launch).  Both fitted on ten layer shapes x {9, 12, 16, 24, 32} tokens x both modes on one box (round 4, profiles/r04_dispatch_check_m16.txt;
-// the rule they replace -- a bound on m * K -- was 20 ... 35 % behind on 8192 x 8192 at 24 / 32 tokens):
-//   column, per-channel: the decode time of the layer (4.7 us + weights at 8.8 TB/s -- the fit's slope, not a bandwidth claim) + 25 ns per 1000 bytes
-//   of activations a workgroup reads, per round of 256 workgroups;  per-group: bound by the re-quantiser -- 4.2 us + 0.907 us per 1000 k per round,
-//   flat up to 16 tokens, + 0.46 us per 1000 k for the second 16-token tile (growing as ((m - 16) / 16)^0.75);
-//   stream: 8.6 us + 0.72 weight passes at 5 TB/s up to 16 tokens, 9.1 + (m - 24) / 16 us + 0.90 passes from 17 (per-group x 1.13).
+// 1 ... 32 tokens: the column kernel (one launch; every 32-column workgroup re-reads the m x K activations) against the stream kernel (K slices + reduce launch).
+// Both are linear forms whose coefficients are GENERATED (qqq_rates.h, kQqqSmall; tools/fit_rates.py: least squares over the forced column / stream measurements of ten
+// dispatch grids, 3 - 4 % mean error per form -- round 5's last re-measurement, taken with enough rotating weight copies that the Infinity Cache serves nobody):
+//   column, per-channel: launch + the weights (c1 per MB) + the activations every workgroup reads again (c2 per 1e6 bytes, per round of 256 workgroups) + the serial depth
+//   of a chip that is not full (c3 per 1000 k, scaled by the share of idle CUs: N = 3584, K = 18944 at decode 16.2 us where the bytes alone say 10.7);
+//   per-group: bound by the re-quantiser -- g1 per 1000 k per round, flat up to 16 tokens, g2 for the second 16-token tile (growing as ((m - 16) / 16)^0.75) -- + the weights;
+//   stream: a + b weight passes at 5 TB/s up to 16 tokens, a + c (m - 24) / 16 + b passes from 17; per mode.
 static double column_small_estimate(int M, int N, int K, bool grouped) {
   const int wgs = N / 32, rounds = (wgs + 255) / 256;
-  if (!grouped) return 4.7 + 0.113 * ((double)N * K / 2.0e6) + 2.5e-5 * (double)K * M * rounds;
+  const double mb = (double)N * K / 2.0e6;
+  if (!grouped) {
+    const double* c = kQqqSmall.col_pc;
+    const double idle = wgs < 256 ? 1.0 - wgs / 256.0 : 0.0;
+    return c[0] + c[1] * mb + c[2] * 1e-6 * (double)K * M * rounds + c[3] * 1e-3 * K * idle;
+  }
+  const double* g = kQqqSmall.col_g;
   const double r = rounds == 1 ? 1.0 : 0.92 * rounds;
-  double us = 4.2 + 9.07e-4 * K * r;
-  if (M > 16) us += 4.6e-4 * K * r * pow((M - 16) / 16.0, 0.75);
+  double us = g[0] + g[1] * 1e-3 * K * r + g[3] * mb;
+  if (M > 16) us += g[2] * 1e-3 * K * r * pow((M - 16) / 16.0, 0.75);
   return us;
 }
 static double stream_small_estimate(int M, int N, int K, bool grouped) {
   const double pb = (double)N * K / 2.0 / 5.0e6;
-  const double us = M <= 16 ? 8.6 + 0.72 * pb : 9.1 + (M - 24) / 16.0 + 0.90 * pb;
+  const int gi = grouped ? 1 : 0;
+  const double us = M <= 16 ? kQqqSmall.st16[gi][0] + kQqqSmall.st16[gi][1] * pb
+                            : kQqqSmall.st32[gi][0] + kQqqSmall.st32[gi][1] * (M - 24) / 16.0 + kQqqSmall.st32[gi][2] * pb;
   if (!grouped) return us;
   // per-group a slice is also bound by its re-quantiser: 9.7 us + 2.1 us per 1000 k of the slice -- what a wide layer's unsplit strips pay
   // (N = 20480, K = 7168: 24.9 us against the column kernel's 21.1; profiles/r04_stream_ksplit_wide_n.txt).  The K split as make_plan picks it:
@@ -550,32 +558,34 @@ static double stream_small_estimate(int M, int N, int K, bool grouped) {
   if (ks > cap) ks = cap;
   if (ks < 1) ks = 1;
   const double requant = 9.7 + 2.1e-3 * (double)K / ks;
-  return 1.13 * us > requant ? 1.13 * us : requant;
+  return us > requant ? us : requant;
 }
 
-// stream, 65 ... 256 tokens (two to four 64-token m-blocks) on layers up to ~40 MB: the loop, not the weight stream, sets the time.  Fitted on eight layer
-// shapes x {64, 128, 256} tokens x both modes x K splits 1 ... 8 (round 4, profiles/r04_stream_panel_ksplit.txt; 10 % mean error, the right split at 44 of 48
-// points, never more than 5 % off the best one): 8.65 us + 0.153 us per 64-k step of a slice (per-group x 1.235), per round of 256 workgroups (x 1.2 from the
-// second round on), + for a K split the slabs and the reduce launch: 2 us + 0.4 us per MB of int32 slabs.  Returns the time and the split it is reached with --
-// "fill 256 workgroups" (the rule for <= 64 tokens) splits short-K layers that are better left whole (N = 8192, K = 3072 at 128 tokens: 19.4 us in two
-// slices, 15.7 unsplit).
+// stream, 65 ... 256 tokens (two to four 64-token m-blocks) on layers up to ~40 MB: the loop, not the weight stream, sets the time: a + b per 64-k step of a slice, per
+// round of 256 workgroups (x 1.2 from the second round on), + for a K split the slabs and the reduce launch (s0 + s1 per MB of int32 slabs); one set of rates per mode,
+// GENERATED (qqq_rates.h, kQqqSmall.stmid: 137 points per mode, 3 - 4 % mean error; round 4's hand fit -- 8.65 us + 0.153 per step, x 1.235 per-group, 2 + 0.4 per MB --
+// read 4 - 8 % low on the cold re-measurement).  Returns the time and the split it is reached with -- "fill 256 workgroups" (the rule for <= 64 tokens) splits
+// short-K layers that are better left whole (N = 8192, K = 3072 at 128 tokens: 19.4 us in two slices, 15.7 unsplit).
 static double stream_mid_estimate(int M, int N, int K, bool grouped, int ks_cap, int* ks_out) {
   const long long base = (long long)((N + 127) / 128) * ((M + 63) / 64);
   const int KS = K / 64;
-  double best = 1e30;
+  // The SPLIT is chosen by round 4's hand-fitted rates (right at 44 of its 48 points), the PRICE of that split comes from the generated ones: the forced stream
+  // kernel's plan then does not depend on the table, so the tool that fits the table from measurements of that plan reaches a fixed point in one pass.
+  double best_rule = 1e30, price = 1e30;
   *ks_out = 1;
+  const double* c = kQqqSmall.stmid[grouped ? 1 : 0];
   for (int ks = 1; ks <= 8 && ks <= ks_cap; ++ks) {
     if (ks > 1 && KS / ks < 8) break;  // (8-wave bodies: at least a step per wave)
     const double rounds = (double)((base * ks + 255) / 256);
-    const double loop = rounds * (rounds > 1.0 ? 1.2 : 1.0) * 0.153 * (grouped ? 1.235 : 1.0) * KS / ks;
-    const double slabs = ks > 1 ? 2.0 + 0.4 * ((double)M * N * 4.0 * ks / 1.0e6) : 0.0;
-    const double us = 8.65 + loop + slabs;
-    if (us < best) {
-      best = us;
+    const double steps = rounds * (rounds > 1.0 ? 1.2 : 1.0) * KS / ks, slab_mb = (double)M * N * 4.0 * ks / 1.0e6;
+    const double rule = 8.65 + 0.153 * (grouped ? 1.235 : 1.0) * steps + (ks > 1 ? 2.0 + 0.4 * slab_mb : 0.0);
+    if (rule < best_rule) {
+      best_rule = rule;
+      price = c[0] + c[1] * steps + (ks > 1 ? c[2] + c[3] * slab_mb : 0.0);
       *ks_out = ks;
     }
   }
-  return best;
+  return price;
 }
 
 // stream: every 64-token m-block streams the whole weight matrix (the first from HBM, the others mostly from L2 /
@@ -599,16 +609,12 @@ static double stream_estimate(int M, int N, int K, bool grouped, bool have_scrat
   double us = ((mblocks == 2 || mblocks == 3) ? 10.6 : 9.0 + 2.0 * mblocks) + per_block * passes;
   if ((long long)((N + 127) / 128) * mblocks > 256) us *= 1.35;
   if (mblocks == 1 && M > 32) {
-    // 33 ... 64 tokens, refitted over ten layer shapes in both modes (round 4, profiles/r04_dispatch_check_final*.txt, r04_dispatch_check_m64.txt:
-    // 11.8 ... 43.1 us): per token count a line in the weight bytes (no floor: the 8 MB layers sit ON the line) -- fixed part 10.3 -> 12.2 us and
-    // 0.93 -> 1.11 weight passes from 40 to 64 tokens, with a step where the fourth 16-token tile starts (49 tokens); per-group x1.125 / x1.06
+    // 33 ... 64 tokens: per token count a line in the weight bytes (no floor: the 8 MB layers sit ON the line), with a step where the fourth 16-token tile
+    // starts (49 tokens); one form per mode, coefficients generated (qqq_rates.h, kQqqSmall.st64: 68 points per mode, 3 % mean error)
     const double pb = (double)N * K / 2.0 / 5.0e6;
-    const bool four = M > 48;
-    const double fixed = 8.0 + 0.0575 * M + (four ? 0.5 : 0.0), passes64 = 0.75 + 0.0045 * M + (four ? 0.07 : 0.0);
-    // (+3 % from 49 tokens: where the two estimates tie the panel kernel is the one ahead -- 3584 x 3584 at 64 tokens 13.1 vs 15.2 us)
-    // (round 5: the +3 % that used to break ties in the panel kernel's favour from 49 tokens is gone -- the panel model is now the generated table, accurate to
-    //  2-3 % there, and with the handicap the stream kernel lost points it wins: per-group 64 tokens on the BASELINE layer 31.9 vs 34.4 us)
-    return grouped ? 1.125 * fixed + 1.06 * pb * passes64 : fixed + pb * passes64;
+    const double four = M > 48 ? 1.0 : 0.0;
+    const double* f = kQqqSmall.st64[grouped ? 1 : 0];
+    return f[0] + f[1] * M + f[2] * four + pb * (f[3] + f[4] * M + f[5] * four);
   }
   return grouped ? us * 1.15 : us;
 }
@@ -655,12 +661,12 @@ static double panel_estimate(int M, int N, int K, bool grouped, bool have_scratc
     for (int ks = 1; ks <= 4; ++ks) {
       if (tl * ks > 256) break;
       if (ks > 1 && (!have_scratch || 2 * tl > cap_tickets || tl * 64 * 128 * (ks - 1) > cap_rows * (long long)N || ks > NST / 4)) break;
-      // (fitted on the single-round points of profiles/r05_dispatch_check_panel64.txt -- fourteen layer shapes x 80 ... 512 tokens x both modes -- and checked on all
-      //  330 of profiles/r05_dispatch_check_*.txt: 8.0 us unsplit / 10.0 split, 0.316 (0.52) us per stage, every further m-block 0.8 of a weight pass at 5.3 TB/s:
-      //  mean error 2.7 %, worst 10 %)
-      const double stage_us = ((double)NST / ks) * (grouped ? 0.52 : 0.316);
-      const double bytes_us = (1.0 + 0.8 * (double)(mb4 - 1)) * N * K / 2.0 / 5.3e6 * (grouped ? 1.45 : 1.0);
-      const double us = (ks == 1 ? 8.0 : 10.0) + (grouped ? 0.4 : 0.0) + (stage_us > bytes_us ? stage_us : bytes_us);
+      // (rates GENERATED -- qqq_rates.h, kQqqSmall.panel64, tools/fit_rates.py: the single-round points of the column panel64 in profiles/r05_dispatch_check_*.txt,
+      //  165 per mode, 2.5 - 2.7 % mean error: launch + fill + epilogue unsplit / split, us per stage, every further m-block a share of a weight pass at bw MB/us)
+      const double* q = kQqqSmall.panel64[grouped ? 1 : 0];
+      const double stage_us = ((double)NST / ks) * q[2];
+      const double bytes_us = (1.0 + q[3] * (double)(mb4 - 1)) * ((double)N * K / 2.0e6) / q[4];
+      const double us = (ks == 1 ? q[0] : q[1]) + (stage_us > bytes_us ? stage_us : bytes_us);
       if (us < best) {
         best = us;
         *bn_out = 128;
@@ -802,12 +808,27 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
     // (per-group up to 16 tokens the cap of three rounds holds as at decode: N = 22016, K = 4096 at 16 tokens 15.0 vs 17.3 us)
     // Per-group the column kernel is bound by its re-quantiser (time ~ K per round), so on long-K layers the stream kernel's K slices win even
     // at decode (N = 3584, K = 18944: 15.4 vs 19.4 us; N = 4096, K = 14336: 13.5 vs 15.8): the two small models decide from one token on.
-    const bool col_cheaper = column_small_estimate(M, N, K, grouped) < stream_small_estimate(M, N, K, grouped);
+    // (a tie goes to the column kernel -- one launch instead of two; 2 % is where the measured regret of the rule is smallest: 0.27 % mean over 238 points against 0.32 % without)
+    const bool col_cheaper = column_small_estimate(M, N, K, grouped) < 1.02 * stream_small_estimate(M, N, K, grouped);
     const bool column = column_ok && N / 32 >= 16 && N / 32 <= ((M <= 8 || (grouped && M <= 16)) ? 768 : 512) &&
                         (grouped ? (M <= 32 && col_cheaper) : (M <= 8 || (M <= 32 && col_cheaper)));
     if (column) kernel = 3;
     else kernel = (M <= 128 || (K % 128) != 0) ? 1 : 2;
     if (column_ok && M <= 32) est = column ? column_small_estimate(M, N, K, grouped) : stream_small_estimate(M, N, K, grouped);
+    // 9 ... 32 tokens: the panel kernel's 16- / 32-token m-blocks are a third candidate -- on very wide layers 256-column strips in two or three K slices beat both
+    // (N = 20480, K = 7168 at 32 tokens: 21.7 us against 27.2 / 32.6; N = 28672 / 29568: 10 - 12 %; 10 of the 192 measured points, profiles/r05_dispatch_check_*.txt).
+    // It has to be clearly ahead (5 %: the three models are each good to 3 - 4 %).
+    if (column_ok && M > 8 && M <= 32 && t.bm == 0 && t.mt == 0 && t.ksplit <= 0) {
+      const long long cap_tk = have_ws ? (long long)(N / 128) * (max_par > 0 ? max_par : 0) : 0;
+      int pbn = 128, pks = 1, pcw = 1;
+      const double e_panel = panel_estimate(M, N, K, grouped, have_scratch && have_ws, cap_rows, cap_tk, &pbn, &pks, &pcw);
+      if (e_panel < 0.95 * est) {
+        kernel = 4;
+        est = e_panel;
+        t.bm = pbn;
+        t.ksplit = pks;
+      }
+    }
     // Above the decode regime the family is picked by the three cost models.  The panel kernel is also the MFMA path
     // with LDS-shared activations for K % 128 == 64 at any m (the tiled kernel needs 128-k blocks).
     if (column_ok && !column && M > 32) {
@@ -1156,6 +1177,10 @@ extern "C" int qqq_w4a8_model_us(int prob_m, int prob_n, int prob_k, int groupsi
   if (M <= 32) {
     out[0] = column_small_estimate(M, N, K, grouped);
     out[1] = stream_small_estimate(M, N, K, grouped);
+    if (M > 8) {
+      int a = 0, b = 0, c = 0;
+      out[2] = panel_estimate(M, N, K, grouped, cap_rows > 0, cap_rows, cap_tk, &a, &b, &c);
+    }
     return QQQ_OK;
   }
   int a = 0, b = 0, c = 0;
@@ -1233,7 +1258,7 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
   a.K = K;
   a.stream = static_cast<hipStream_t>(stream);
   a.skew = pl.skew;
-  a.hflags = (pl.kernel == 2 || pl.kernel == 4 || pl.kernel == 5) ? ((t.fused >> 2) & 7) : 0;
+  a.hflags = (pl.kernel == 2 || pl.kernel == 4 || pl.kernel == 5) ? ((t.fused >> 2) & (pl.kernel == 4 ? 15 : 7)) : 0;  // (panel: bit 3 = plain grid order, the slices of a tile NOT gathered on one XCD)
 
   DeviceGuard guard(dev);
   hipError_t e = hipSuccess;

@@ -25,8 +25,8 @@ grouped = os.environ.get("MODE", "pc") == "g128"
 rounds = int(os.environ.get("ROUNDS", "5"))
 iters = int(os.environ.get("ITERS", "4"))
 NN, KK = [int(x) for x in os.environ.get("NK", f"{Bn.N_FULL},{Bn.K_FULL}").split(",")]
-layer = Bn.Layer(dev, grouped=grouped, nbuf=int(os.environ.get("NBUF", "4")), N=NN, K=KK)
-arr = (ctypes.c_void_p * len(layer.Bs))(*[b.data_ptr() for b in layer.Bs])
+layer = Bn.Layer(dev, grouped=grouped, nbuf=int(os.environ.get("NBUF", "4")) or Bn.copies_for(NN, KK), N=NN, K=KK)
+rot = [0]  # the weight copies rotate on from one timed group to the next (NBUF=0: as many copies as make the rotation 1.1 GB long)
 for M in Ms:
     A, s1 = Bn.make_tokens(dev, M, M, K=KK)
     D = torch.empty((M, NN), dtype=torch.float16, device=dev)
@@ -41,11 +41,22 @@ for M in Ms:
             tn = _lib.QQQTune()
             for k, v in tune.items(): setattr(tn, k, int(v))
         st = torch.cuda.current_stream(dev).cuda_stream
+        nb = len(layer.Bs)
+        arr = (ctypes.c_void_p * nb)(*[layer.Bs[(rot[0] + i) % nb].data_ptr() for i in range(nb)])
+        rot[0] = (rot[0] + n) % nb
         rc = DEV.qqq_dev_bench_gemm(_dev.gemm_ex_ptr(L), A.data_ptr(), arr, len(layer.Bs), layer.C.data_ptr(), D.data_ptr(), s1.data_ptr(), layer.s2.data_ptr(),
                               layer.s3.data_ptr() if layer.s3.numel() else None, M, layer.N, layer.K, layer.ws.data_ptr(),
                               layer.groupsize, 0, ctypes.c_void_p(st), 16, ctypes.byref(tn) if tn is not None else None, n, out)
         assert rc == 0, (rc, L.qqq_amd_last_error())
         return np.array(out[:]) * 1e3
+    # FLUSH=1 (tools/visits/r5_v23.sh): 640 MB of unrelated traffic (read + write) in front of every timed group -- with ITERS = NBUF every call of the group then
+    # meets a cold copy whatever was timed before.  (Its dirty lines are written back under the first launches of the group: take groups of >= 8 calls.)
+    if os.environ.get("FLUSH") == "1":
+        junk = torch.zeros(640 << 20, dtype=torch.uint8, device=dev)
+        _run = run
+        def run(L, tune, n):
+            junk.add_(1)
+            return _run(L, tune, n)
     for li, L in enumerate(Ls):
         for tune in tunes: run(L, tune, 2)
     for r in range(rounds):

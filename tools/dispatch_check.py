@@ -16,7 +16,9 @@ iters = int(os.environ.get("ITERS", "10"))
 for (N, K) in shapes:
     for mode in modes:
         grouped = mode == "g128"
-        layer = Bn.Layer(dev, grouped=grouped, nbuf=4 if N * K > 6e7 else 12, N=N, K=K)
+        # enough weight copies that a rotation is longer (1.1 GB) than what the 256 MB Infinity Cache can hold: below ~64 tokens a launch is one pass over the weights,
+        # and with the 4 / 12 copies of rounds 2-4 the plain-load kernels were partly served from that cache (profiles/r05_nt_weight_loads.txt)
+        layer = Bn.Layer(dev, grouped=grouped, nbuf=Bn.copies_for(N, K) if min(Ms) <= 128 else (4 if N * K > 6e7 else 12), N=N, K=K)
         for M in Ms:
             A, s1 = Bn.make_tokens(dev, M, M, K=K)
             D = torch.empty((M, N), dtype=torch.float16, device=dev)
@@ -34,6 +36,7 @@ for (N, K) in shapes:
             samples = {k: [] for k in cands}
             for k, tune in cands.items():
                 layer.time_calls(A, s1, D, 2, tune=tune)
+            # (the weight copies rotate on from group to group -- bench.Layer.time_calls -- and there are enough of them, see nbuf above)
             for r in range(int(os.environ.get("ROUNDS", "3"))):
                 for k, tune in cands.items():
                     samples[k].extend(layer.time_calls(A, s1, D, max(2, iters // 3), tune=tune) * 1e3)
