@@ -7,7 +7,7 @@
 One STEP = one pass of the hot path over the BASELINE sweep (configs[1]): five `qqq_gemm` calls,
 per-channel W4A8, M in {1,16,128,1024,4096}, N=8192, K=21760, on synthetic int8 activations (full int8
 range, produced by the fused dynamic_quant of N(0,1) fp16 tokens) and random int4 weights, all resident
-in HBM before the timed region.  Consecutive calls use DIFFERENT 89 MB weight buffers (5 of them, 445 MB
+in HBM before the timed region.  Consecutive calls use DIFFERENT 89 MB weight buffers (12 of them, 1.07 GB
 > the 256 MiB Infinity Cache) so that "HBM GB/s" is not an L3 number.  `value` = sum(2*M*N*K) / time.
 The timed region replays hipGraphs: a one-step graph opens it (the GPU idles behind the barrier until the host has launched the
 first graph, and a short one launches fastest), the rest hold several consecutive steps each (--steps-per-graph, default 10,
@@ -423,7 +423,7 @@ def compact_line(result):
     out = {k: result[k] for k in keep if k in result}
     cfg = result.get("config", {})
     out["config"] = {"workload": "qqq_gemm per-channel sweep M in {1,16,128,1024,4096} N=8192 K=21760 (configs[1]); step = the 5 calls",
-                     "weights": cfg.get("weights_short", "5 rotating 89 MB int4 buffers, GPTQ-style N(0,0.02^2)"),
+                     "weights": cfg.get("weights_short", "12 rotating 89 MB int4 buffers, GPTQ-style N(0,0.02^2)"),
                      "launch": cfg.get("launch_short", "eager"), "parallelism": cfg.get("parallelism_short", cfg.get("parallelism", ""))}
     for key in ("roofline", "roofline_hbm"):
         r = result.get(key)
