@@ -522,6 +522,37 @@ def test_panel_two_workgroups_per_cu(dev):
                     assert ulp_distance(D, eD) == 0, (grouped, M, tune, rep)
 
 
+def test_panel_slices_of_a_tile_on_one_xcd_any_strip_count(dev):
+    """Round 5: for a split K the panel kernel walks its grid 8 strips at a time through all their K slices (every tile's slices on ONE XCD whatever the strip count;
+    tune.fused bit 5 keeps the plain grid order).  The order must not matter: strip counts below 8 (the whole grid is the plain-order tail), exact multiples of 8, and
+    ragged ones (9, 11, 18, 43 strips of 128 columns; 256-column strips halve them), 2 ... 4 slices, several m-blocks, both modes and both orders -- int32 accumulators and
+    fp16 outputs against the CPU oracle, and the two orders bit-identical to each other."""
+    from oracle import c_oracle as C
+    from oracle import qqq_ref as R
+
+    rng = np.random.default_rng(2025)
+    K = 2048
+    for N in (320, 1024, 1152, 1408, 2304, 5504):
+        for grouped in (False, True):
+            codes = rng.integers(0 if grouped else -8, 16 if grouped else 8, size=(K, N)).astype(np.int8)
+            B = R.pack_codes(codes, grouped)
+            s2 = rng.random((1, N), dtype=np.float32) * 2e-4 + 1e-5
+            s3 = (rng.random((K // 128, N), dtype=np.float32) * 15 + 0.5).astype(np.float16) if grouped else None
+            h = GemmHarness(B, s2, s3, dev)
+            for M in (48, 200):
+                A = rng.integers(-128, 128, size=(M, K), dtype=np.int8)
+                s1 = rng.random((M, 1), dtype=np.float32) * 0.05 + 0.001
+                eD, eacc = C.qqq_gemm(A, B, s1, s2, s3, return_acc=True)
+                for tune in (dict(kernel=4, ksplit=4), dict(kernel=4, ksplit=3), dict(kernel=4, bm=256, ksplit=2), dict(kernel=4, mt=4, ksplit=4, skew=2)):
+                    got = []
+                    for order in (0, 32):
+                        D, acc = h.run(A, s1, dict(tune, fused=order))
+                        assert np.array_equal(acc, eacc), (N, grouped, M, tune, order)
+                        assert ulp_distance(D, eD) == 0, (N, grouped, M, tune, order)
+                        got.append(D)
+                    assert np.array_equal(got[0].view(np.uint16), got[1].view(np.uint16)), (N, grouped, M, tune)
+
+
 def test_wide_every_instantiation_every_k_tail(dev):
     """The wide kernel stages by LDS-DMA and counts its own waits: every one of its twelve instantiations
     (per-channel / per-group x 256 x 256, 128 x 256, 256 x 128 tiles x ring of 4 / 8 steps), alone and in two K slices, on
