@@ -815,10 +815,11 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
     if (column) kernel = 3;
     else kernel = (M <= 128 || (K % 128) != 0) ? 1 : 2;
     if (column_ok && M <= 32) est = column ? column_small_estimate(M, N, K, grouped) : stream_small_estimate(M, N, K, grouped);
-    // 9 ... 32 tokens: the panel kernel's 16- / 32-token m-blocks are a third candidate -- on very wide layers 256-column strips in two or three K slices beat both
+    // 17 ... 32 tokens: the panel kernel's 32-token m-blocks are a third candidate -- on very wide layers 256-column strips in two or three K slices beat both
     // (N = 20480, K = 7168 at 32 tokens: 21.7 us against 27.2 / 32.6; N = 28672 / 29568: 10 - 12 %; 10 of the 192 measured points, profiles/r05_dispatch_check_*.txt).
-    // It has to be clearly ahead (5 %: the three models are each good to 3 - 4 %).
-    if (column_ok && M > 8 && M <= 32 && t.bm == 0 && t.mt == 0 && t.ksplit <= 0) {
+    // It has to be clearly ahead (5 %: the three models are each good to 3 - 4 %).  (Up to 16 tokens it won 3 of 116 measured points, and the one time the models
+    // picked it there -- N = 20480, K = 7168 -- the clock said 20.2 us against the stream kernel's 16.6: not a candidate.)
+    if (column_ok && M > 16 && M <= 32 && t.bm == 0 && t.mt == 0 && t.ksplit <= 0) {
       const long long cap_tk = have_ws ? (long long)(N / 128) * (max_par > 0 ? max_par : 0) : 0;
       int pbn = 128, pks = 1, pcw = 1;
       const double e_panel = panel_estimate(M, N, K, grouped, have_scratch && have_ws, cap_rows, cap_tk, &pbn, &pks, &pcw);

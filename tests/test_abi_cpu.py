@@ -409,6 +409,21 @@ def test_tiled_family_is_not_an_automatic_choice():
     assert _lib.plan(4096, 8192, 21760, -1, 16, tune=dict(kernel=2))["kernel"] == 2
 
 
+def test_panel_kernel_is_a_candidate_from_17_tokens():
+    """Round 5 (cold grids): on very wide layers 256-column strips in two or three K slices beat column and stream kernel at 17 ... 32 tokens (N = 20480, K = 7168 at 32
+    tokens: 21.7 us against 27.2 / 32.6); up to 16 tokens the choice stays between those two, and a tie between them goes to the column kernel (one launch)."""
+    from qqq_amd import _lib
+
+    p = _lib.plan(32, 20480, 7168, -1, 16)
+    assert (p["kernel"], p["bm"]) == (4, 256) and p["ksplit"] in (2, 3), p
+    assert _lib.plan(32, 28672, 8192, -1, 16)["kernel"] == 4
+    assert _lib.plan(16, 20480, 7168, -1, 16)["kernel"] in (1, 3)
+    assert _lib.plan(32, 4096, 4096, -1, 16)["kernel"] == 3 and _lib.plan(24, 8192, 8192, -1, 16)["kernel"] == 3
+    assert _lib.plan(8, 8192, 21760, 128, 16)["kernel"] == 3  # (the tie: 25.6 vs 25.5 us modelled, 22.3 vs 24.2 measured)
+    prices = _lib.model_us(24, 8192, 8192, -1, 16)
+    assert set(prices) == {"column", "stream", "panel"} and all(v > 0 for v in prices.values()), prices
+
+
 def test_plan_is_pure_host_logic_with_the_mi355x_cu_count():
     """qqq_w4a8_plan no longer asks the HIP runtime for the current device's CU count (the tile-walk decision depends on it); it plans for the
     MI355X's 256.  qqq_w4a8_gemm_ex plans and launches with the CU count of the device it was GIVEN, capped by `sms`."""

@@ -20,7 +20,7 @@ FILES = {
     "r05_dispatch_check_merged.txt": (90, 8, 0.10),  # merged projections (N = 12288 / 22016) and narrow layers (N = 2048 / 1024)
     "r05_dispatch_check_mid.txt": (16, 3, 0.06),  # BASELINE layer at 320 ... 3072 tokens
     "r05_dispatch_check_mid_shapes.txt": (135, 16, 0.11),  # nine shapes at 96 ... 4096 tokens, every wide shape
-    "r05_dispatch_check_more_models.txt": (150, 17, 0.24),  # Yi-34B / Phi-3 / Llama-70B k,v / Qwen2-72B layers (the 21.7 %: 20480 x 7168 at 16 tokens, panel against stream)
+    "r05_dispatch_check_more_models.txt": (150, 16, 0.15),  # Yi-34B / Phi-3 / Llama-70B k,v / Qwen2-72B layers
     "r05_dispatch_check_panel64.txt": (205, 19, 0.10),  # fourteen shapes at 80 ... 512 tokens with the 64-token m-block column
     "r05_dispatch_check_qwen_mistral.txt": (132, 16, 0.19),  # Qwen2-7B / Mistral-7B layers
     "r05_dispatch_check_shapes.txt": (80, 11, 0.13),  # six other layer shapes
