@@ -248,7 +248,9 @@ def test_dispatch_of_the_baseline_sweep(L):
     assert (p["kernel"], p["mt"], p["ksplit"]) == (4, 4, 2), p
     # M split (rows are independent; profiles/r04_ragged_m.txt): a token count one past whole tiles / rounds of the wide kernel runs as two launches --
     # 4097 tokens 624 us in one launch, 464 us as 4096 + 1 -- where the models price the pair 7 % below the single launch, and only there
-    assert [_lib.plan(m, N, K, -1, 16)["split_m"] for m in (4096, 4097, 4224, 4352, 2049, 1025, 8200, 5000)] == [0, 4096, 4096, 4096, 2048, 1024, 8192, 0]
+    # (round 5, rates refitted on the cold, order-shuffled grids: 4700 ... 5120 tokens -- 2.3 ... 2.5 rounds of 256 x 256 tiles -- split as well: 5000 tokens
+    #  560 us as 4096 + 904 against 620 in one launch, per-group 725 against 810; profiles/r05_m_split_refit.txt)
+    assert [_lib.plan(m, N, K, -1, 16)["split_m"] for m in (4096, 4097, 4224, 4352, 2049, 1025, 8200, 5000)] == [0, 4096, 4096, 4096, 2048, 1024, 8192, 4096]
     assert _lib.plan(4097, N, K, 128, 16)["split_m"] == 4096 and _lib.plan(4097, N, K, -1, 16, tune=dict(split_m=-1))["split_m"] == 0
     assert _lib.plan(8200, 11008, 4096, -1, 16)["split_m"] == 0 and _lib.plan(4100, 4096, 11008, -1, 16)["split_m"] == 4096   # 43 strips: no whole rounds to keep
     assert _lib.plan(4097, N, K, -1, 16, tune=dict(kernel=5))["split_m"] == 0                                                # a forced family is never split
@@ -270,7 +272,9 @@ def test_dispatch_of_the_baseline_sweep(L):
             assert (p["kernel"], p["mt"], p["bm"], p["ksplit"]) == (5, 16, 128, 2), (m, gs, p)
     for m in (640, 768, 1024):
         p, g = _lib.plan(m, N, K, -1, 16), _lib.plan(m, N, K, 128, 16)
-        assert (p["kernel"], p["mt"], p["bm"], p["ksplit"]) == ((5, 8, 256, 1) if m == 640 else (5, 16, 128, 1)), (m, p)
+        # (round 5: with the 256 x 256 tiles' ring depth 8 and uneven slices two K slices of them overtook the 256 x 128 tiles at 1024 tokens: 133.8 vs 135.6 us,
+        #  profiles/r05_m_split_refit.txt)
+        assert (p["kernel"], p["mt"], p["bm"], p["ksplit"]) == ((5, 8, 256, 1) if m == 640 else (5, 16, 128, 1) if m == 768 else (5, 16, 256, 2)), (m, p)
         assert (g["kernel"], g["mt"], g["bm"], g["ksplit"]) == (5, 16, 256, 2), (m, g)
     p = _lib.plan(1024, N, K, -1, 16, tune=dict(kernel=4, bm=256, mt=8, pw=2))  # the round-2 choice stays available
     assert (p["kernel"], p["bm"], p["mt"], p["pw"], p["ksplit"]) == (4, 256, 8, 2, 1), p

@@ -14,10 +14,10 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 BOUNDS = {
     # every family is priced from GENERATED rates (tools/fit_rates.py -> qqq_amd/csrc/qqq_rates.h) at the end of round 5: panel + wide tables, and up to 256 tokens the
     # linear forms of the column / stream kernels (the stream kernel's large-layer branch above 64 tokens is the one hand-fitted piece left)
-    ("column", "1-8"): (85, 0.06, 0.03), ("column", "9-32"): (180, 0.055, 0.03),
-    ("stream", "1-8"): (85, 0.065, 0.03), ("stream", "9-32"): (180, 0.055, 0.03), ("stream", "33-64"): (125, 0.045, 0.02), ("stream", "65-256"): (300, 0.06, 0.03),
-    ("panel", "9-32"): (180, 0.05, 0.03), ("panel", "33-64"): (125, 0.045, 0.02), ("panel", "65-256"): (300, 0.05, 0.04), ("panel", "257-1024"): (230, 0.055, 0.03),
-    ("panel", ">1024"): (155, 0.06, 0.03), ("wide", "257-1024"): (150, 0.045, 0.03), ("wide", ">1024"): (155, 0.05, 0.04),
+    ("column", "1-8"): (85, 0.05, 0.02), ("column", "9-32"): (180, 0.05, 0.02),
+    ("stream", "1-8"): (85, 0.055, 0.03), ("stream", "9-32"): (180, 0.05, 0.02), ("stream", "33-64"): (125, 0.045, 0.02), ("stream", "65-256"): (300, 0.06, 0.02),
+    ("panel", "9-32"): (180, 0.045, 0.025), ("panel", "33-64"): (125, 0.04, 0.02), ("panel", "65-256"): (300, 0.045, 0.035), ("panel", "257-1024"): (230, 0.05, 0.03),
+    ("panel", ">1024"): (155, 0.055, 0.03), ("wide", "257-1024"): (150, 0.04, 0.03), ("wide", ">1024"): (155, 0.035, 0.02),
 }
 
 

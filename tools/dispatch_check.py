@@ -37,8 +37,13 @@ for (N, K) in shapes:
             for k, tune in cands.items():
                 layer.time_calls(A, s1, D, 2, tune=tune)
             # (the weight copies rotate on from group to group -- bench.Layer.time_calls -- and there are enough of them, see nbuf above)
+            # ... in a different (seeded) order every round: on a power-limited chip a variant timed right behind a slow, cool one finds higher clocks -- with a fixed order
+            # the same plan read 502 us as column `wide` (behind the panel variants) and 536 / 538 as `walk` / auto at 8192 tokens (profiles/r05_dispatch_check_merged.txt of visit 27)
+            import random
             for r in range(int(os.environ.get("ROUNDS", "3"))):
-                for k, tune in cands.items():
+                order = list(cands.items())
+                random.Random(hash((N, K, M, grouped, r)) & 0xffffffff).shuffle(order)
+                for k, tune in order:
                     samples[k].extend(layer.time_calls(A, s1, D, max(2, iters // 3), tune=tune) * 1e3)
             p = _lib.plan(M, N, K, 128 if grouped else -1, 16)
             res = {k: float(np.median(v)) for k, v in samples.items()}
