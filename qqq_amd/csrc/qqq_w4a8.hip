@@ -21,7 +21,7 @@
 //    an operand as long as both operands use the same order ("k-slot freedom"), and the
 //    packed order [kq][r] IS natural k order, so the activation operand is 16 contiguous bytes.
 //  * "column" kernel (decode: m <= 8, up to 32 tokens while m*K is small): HBM-bound.  32 weight columns x all of K per workgroup, so a wide layer
-//    fills the chip without split-K (one launch per call); packed words re-distributed between lanes with DPP.
+//    fills the chip without split-K (one launch per call); packed words re-distributed between lanes with DPP; non-temporal weight loads (round 5).
 //  * "stream" kernel (a few tens of tokens; small layers up to ~256): HBM-bound.  v_mfma_i32_16x16x64_i8; a lane (i = 8*g + c, h)
 //    loads its 64 weight bytes of k-tile 4*s + h straight from HBM into VGPRs (no LDS: the
 //    weights are used once), a wave eats 128 columns x 64 k = 4 KiB per step, waves of a
@@ -30,16 +30,16 @@
 //  * "panel" kernel (about 64 .. 1024 tokens): all tokens of a 128-token m-block x 128 / 256 columns x a K slice per
 //    workgroup; the waves split the columns (weights HBM -> VGPR, once per workgroup), the activations are shared
 //    through LDS, software-pipelined 16x16x64 MFMAs, in-launch split-K with one slot of C per depositing slice.
-//    Uneven K slices (round 5): the last slice is a few stages longer, arrives last and finds the other deposits complete.
+//    Uneven K slices (round 5): the last slice is a few stages longer, arrives last and finds the other deposits complete; the slices of a tile run on one XCD.
 //  * "wide" kernel (from ~320 tokens up, qqq_wide.hip.h): 256 x 256 / 256 x 128 / 128 x 256 tiles, four waves with 512 registers each, every
 //    instruction of the loop placed by hand around in-place MFMAs, activations by LDS-DMA, persistent tile walk on short-K layers.
 //  * "tiled" kernel (round 1; tune.kernel = 2 only since round 5 -- the fuzzers' independent reference, the fallback beyond 4 GB of packed
 //    weights): v_mfma_i32_32x32x32_i8; BMx256 tiles, BK = 128, activations and RAW packed weights staged in LDS by LDS-DMA (XOR-swizzled
 //    16-byte chunks so that every fragment read is bank-conflict free), continuous fragment pipeline, XCD-aware tile order,
 //    in-launch split-K through tile-sized slots of C.
-//  Host side: make_plan() picks family / tile / split from measured cost models -- the panel and wide kernels' from the GENERATED tables of
-//  qqq_rates.h (tools/fit_rates.py), the decode / stream ones hand-fitted -- all held against the committed measurements by
-//  tools/cost_model_report.py; the C-ABI entry points are at the end of the file.
+//  Host side: make_plan() picks family / tile / split from measured cost models whose rates are all GENERATED (qqq_rates.h, tools/fit_rates.py: the panel and wide
+//  kernels' tables, the small-m forms of the column / stream kernels, the 64-token m-block form) -- only the stream kernel's many-m-block branch on large layers is
+//  still hand-fitted -- and held against the committed measurements by tools/cost_model_report.py; the C-ABI entry points are at the end of the file.
 //
 // The accumulators are the reference's: per-channel weights enter as 16*w4 (high nibble of each
 // byte) and pack() has pre-divided s_channel by 16; per-group weights are re-quantised to int8
