@@ -229,7 +229,8 @@ static hipError_t launch_column_t(const LaunchArgs& a, int ksplit) {
 }
 
 template <bool GROUPED>
-static hipError_t launch_column_g(const LaunchArgs& a, int mt, int pf, int ksplit) {
+static hipError_t launch_column_g(const LaunchArgs& a, int mt, int pf, int ksplit, int waves) {
+  if (waves == 16 && mt == 1) return launch_column_t<1, GROUPED, 16, 3>(a, ksplit);  // (tune.waves = 16: sixteen waves split K inside the workgroup)
   if (mt >= 2) {
     if (pf <= 4) return launch_column_t<2, GROUPED, 8, 4>(a, ksplit);
     return launch_column_t<2, GROUPED, 8, 8>(a, ksplit);
@@ -242,8 +243,8 @@ static hipError_t launch_column_g(const LaunchArgs& a, int mt, int pf, int kspli
   return launch_column_t<1, GROUPED, 8, 12>(a, ksplit);
 }
 
-static hipError_t launch_column(const LaunchArgs& a, bool grouped, int mt, int pf, int ksplit) {
-  return grouped ? launch_column_g<true>(a, mt, pf, ksplit) : launch_column_g<false>(a, mt, pf, ksplit);
+static hipError_t launch_column(const LaunchArgs& a, bool grouped, int mt, int pf, int ksplit, int waves = 8) {
+  return grouped ? launch_column_g<true>(a, mt, pf, ksplit, waves) : launch_column_g<false>(a, mt, pf, ksplit, waves);
 }
 
 template <int MT, bool GROUPED, int WN, int KG, int PFS, int XL, int HW = 1>
@@ -969,7 +970,9 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
     if (ksplit > 1 && (long long)ksplit * M > cap_rows) ksplit = (int)(cap_rows / M);
     if (ksplit < 1) ksplit = 1;
     pl.mt = mt;
-    pl.waves = 8;
+    // sixteen waves per workgroup (the waves split K inside the workgroup) where the re-quantiser binds: per-group up to 8 tokens -2 ... -6 % on five layer shapes
+    // (BASELINE layer at decode 23.5 -> 22.05 us); per-channel mixed (+4 % there), from 9 tokens level: eight (profiles/r05_column_16_waves.txt)
+    pl.waves = mt == 1 && (t.waves == 16 || (t.waves == 0 && grouped && M <= 8)) ? 16 : 8;
     pl.pf = t.pf > 0 ? t.pf : 3;
     pl.ksplit = ksplit;
     pl.fused = 2;
@@ -1291,7 +1294,7 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
     if (e != hipSuccess) return fail_hip(e, "qqq_panel_kernel launch");
     reduce_launch = false;
   } else if (pl.kernel == 3) {
-    e = launch_column(a, grouped, pl.mt, pl.pf, pl.ksplit);
+    e = launch_column(a, grouped, pl.mt, pl.pf, pl.ksplit, pl.waves);
     if (e != hipSuccess) return fail_hip(e, "qqq_column_kernel launch");
     reduce_launch = pl.ksplit > 1;
   } else if (pl.kernel == 1) {

@@ -67,7 +67,7 @@ def variants(M, K, N):
         v += [dict(kernel=1, ksplit=1, waves=16)]
     v += [dict(kernel=1)]  # auto split
     if N % 64 == 0:  # column kernel (decode): 32 columns x all of K per workgroup
-        v += [dict(kernel=3), dict(kernel=3, mt=1, pf=4), dict(kernel=3, mt=2, pf=4), dict(kernel=3, mt=1, pf=12, ksplit=2)]
+        v += [dict(kernel=3), dict(kernel=3, mt=1, pf=4), dict(kernel=3, mt=2, pf=4), dict(kernel=3, mt=1, pf=12, ksplit=2), dict(kernel=3, mt=1, waves=16), dict(kernel=3, mt=1, waves=16, ksplit=2)]
         if K // 64 >= 3:
             v += [dict(kernel=3, mt=2, pf=8, ksplit=3), dict(kernel=3, mt=1, pf=2), dict(kernel=3, mt=1, pf=6)]
     if N % 64 == 0:  # panel kernel: all tokens of an m-block x 128 / 256 columns x a K slice, in-launch split-K

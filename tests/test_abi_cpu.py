@@ -413,6 +413,17 @@ def test_tiled_family_is_not_an_automatic_choice():
     assert _lib.plan(4096, 8192, 21760, -1, 16, tune=dict(kernel=2))["kernel"] == 2
 
 
+def test_column_kernel_takes_sixteen_waves_where_the_requantiser_binds():
+    """Round 5: per-group up to 8 tokens the column kernel's workgroups have sixteen waves (-2 ... -6 % on five layer shapes, profiles/r05_column_16_waves.txt); per-channel
+    and from 9 tokens eight; tune.waves = 16 forces it for one 16-token tile."""
+    from qqq_amd import _lib
+
+    N, K = 8192, 21760
+    assert [_lib.plan(m, N, K, 128, 16)["waves"] for m in (1, 8)] == [16, 16] and _lib.plan(1, 4096, 4096, 128, 16)["waves"] == 16
+    assert _lib.plan(1, N, K, -1, 16)["waves"] == 8 and _lib.plan(12, 4096, 4096, 128, 16)["waves"] == 8
+    assert _lib.plan(4, N, K, -1, 16, tune=dict(kernel=3, waves=16))["waves"] == 16 and _lib.plan(24, N, K, -1, 16, tune=dict(kernel=3, mt=2, waves=16))["waves"] == 8
+
+
 def test_panel_kernel_is_a_candidate_from_17_tokens():
     """Round 5 (cold grids): on very wide layers 256-column strips in two or three K slices beat column and stream kernel at 17 ... 32 tokens (N = 20480, K = 7168 at 32
     tokens: 21.7 us against 27.2 / 32.6); up to 16 tokens the choice stays between those two, and a tie between them goes to the column kernel (one launch)."""
