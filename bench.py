@@ -115,13 +115,24 @@ def make_tokens(dev, M, seed, K=K_FULL):
 class Layer:
     """device buffers of one QuantLinear-like layer + the rotating weight copies"""
 
-    def __init__(self, dev, grouped=False, nbuf=NBUF, N=N_FULL, K=K_FULL):
+    def __init__(self, dev, grouped=False, nbuf=NBUF, N=N_FULL, K=K_FULL, expand=False):
         self.dev, self.N, self.K, self.grouped = dev, N, K, grouped
         self.Bs, self.s2, s3 = make_weights(dev, grouped, nbuf, N=N, K=K)
         self.s3 = s3 if s3 is not None else torch.empty(0, dtype=torch.float16, device=dev)
         self.C = torch.zeros((MAX_PAR * 64, N), dtype=torch.int32, device=dev)
         self.ws = torch.zeros(N // 128 * MAX_PAR, dtype=torch.int32, device=dev)
         self.groupsize = 128 if grouped else -1
+        self.W8s = None
+        if expand and grouped:
+            self.expand()
+
+    def expand(self):
+        """opt-in load-time re-layout (QuantLinear.expand_for_prefill): every weight copy also as expanded int8 (K x N bytes each)"""
+        from qqq_amd import ops
+
+        self.W8s = [ops.expand_int8(B, self.s3) for B in self.Bs]
+        torch.cuda.synchronize()
+        return self
 
     def time_calls(self, A, s1, D, iters, tune=None, rotate=True):
         """per-call durations (ms) from HIP event pairs recorded natively around each launch"""
@@ -139,12 +150,21 @@ class Layer:
             for k, v in tune.items():
                 setattr(tn, k, int(v))
         st = torch.cuda.current_stream(self.dev).cuda_stream
-        rc = L.qqq_dev_bench_gemm(
-            _dev.gemm_ex_ptr(), A.data_ptr(), arr, nb, self.C.data_ptr(), D.data_ptr(), s1.data_ptr(), self.s2.data_ptr(),
-            self.s3.data_ptr() if self.s3.numel() else None, A.shape[0], self.N, self.K, self.ws.data_ptr(),
-            self.groupsize, self.dev.index or 0, ctypes.c_void_p(st), MAX_PAR,
-            ctypes.byref(tn) if tn is not None else None, iters, out,
-        )
+        if self.W8s is not None:  # the calls also get the copy's expanded int8 weights (the library uses them where its plan is the wide kernel's)
+            arr8 = (ctypes.c_void_p * nb)(*[self.W8s[(rot + i) % nb].data_ptr() for i in range(nb)])
+            rc = L.qqq_dev_bench_gemm2(
+                _dev.gemm_ex2_ptr(), A.data_ptr(), arr, arr8, nb, self.C.data_ptr(), D.data_ptr(), s1.data_ptr(), self.s2.data_ptr(),
+                self.s3.data_ptr() if self.s3.numel() else None, A.shape[0], self.N, self.K, self.ws.data_ptr(),
+                self.groupsize, self.dev.index or 0, ctypes.c_void_p(st), MAX_PAR,
+                ctypes.byref(tn) if tn is not None else None, iters, out,
+            )
+        else:
+            rc = L.qqq_dev_bench_gemm(
+                _dev.gemm_ex_ptr(), A.data_ptr(), arr, nb, self.C.data_ptr(), D.data_ptr(), s1.data_ptr(), self.s2.data_ptr(),
+                self.s3.data_ptr() if self.s3.numel() else None, A.shape[0], self.N, self.K, self.ws.data_ptr(),
+                self.groupsize, self.dev.index or 0, ctypes.c_void_p(st), MAX_PAR,
+                ctypes.byref(tn) if tn is not None else None, iters, out,
+            )
         if rc:
             raise RuntimeError(f"qqq_dev_bench_gemm rc={rc}: {_lib.last_error()} {_dev.last_error()}")
         return np.array(out[:], dtype=np.float64)
@@ -431,7 +451,8 @@ def compact_line(result):
             out[key] = {k: r.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes", "avg_launch_us")}
             if key == "roofline" and isinstance(r.get("sustained_on_random_int8"), dict):
                 out[key]["sustained_16x16x64_tops"] = r["sustained_on_random_int8"].get("mfma_16x16x64_only_tops")
-    for key in ("per_m", "per_m_g128"):
+                out[key]["frac_of_sustained"] = r.get("frac_of_sustained")  # achieved / the same run's register-only 16x16x64 rate: separates box spread from kernel changes
+    for key in ("per_m", "per_m_g128", "per_m_g128_expanded"):
         pm = result.get(key)
         if isinstance(pm, dict) and "error" not in pm:
             out[key] = {m: {"us": e.get("us_median"), "frac": e.get("roof_frac_median"), "roof": e.get("roof"), "kernel": e.get("kernel"),
@@ -482,7 +503,7 @@ def compact_line(result):
     out = _r(out)
     line = json.dumps(out, separators=(",", ":"))
     if len(line) > LINE_LIMIT:  # never let an optional block make the line unreadable again: drop them in order of dispensability
-        for k in ("llama7b", "per_m_g128", "multi_gpu", "clocks_mhz", "per_m"):
+        for k in ("llama7b", "per_m_g128_expanded", "per_m_g128", "multi_gpu", "clocks_mhz", "per_m"):
             if k in out:
                 out[k] = {"dropped": "see detail file"}
                 line = json.dumps(out, separators=(",", ":"))
@@ -552,11 +573,17 @@ def main():
     Dfull = {M: torch.empty((M, N_FULL), dtype=torch.float16, device=dev) for M in SWEEP_M}
 
     # ---- one step = the 5-call sweep ----
+    # (single GPU: step t binds sweep point j to weight copy (5 t + j) % NBUF -- inside a multi-step graph as well as eagerly --, so a copy is
+    #  re-read only after the other NBUF - 1 have passed through the Infinity Cache: what `config.weights` says)
+    step_no = [0]
     if world == 1:
-        def step_body():
+        def step_body(t=None):
+            if t is None:
+                t = step_no[0]
+                step_no[0] += 1
             for j, M in enumerate(SWEEP_M):
                 A, s1 = toks[M]
-                ops.qqq_gemm(A, layer.Bs[j % NBUF], layer.C, Dfull[M], s1, layer.s2, layer.s3, layer.ws, -1, -1, -1, MAX_PAR)
+                ops.qqq_gemm(A, layer.Bs[(len(SWEEP_M) * t + j) % NBUF], layer.C, Dfull[M], s1, layer.s2, layer.s3, layer.ws, -1, -1, -1, MAX_PAR)
     else:
         sharded = {}
         for j, M in enumerate(SWEEP_M):
@@ -571,7 +598,7 @@ def main():
                 spans = sg.spans(M, N_FULL)
                 sharded[M] = (sg, take_rows(A, spans), take_rows(s1, spans))
 
-        def step_body():
+        def step_body(t=None):
             for j, M in enumerate(SWEEP_M):
                 if M in sharded:
                     sg, a_loc, s1_loc = sharded[M]
@@ -595,7 +622,7 @@ def main():
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                step_body()
+                step_body(0)
             g.replay()
             torch.cuda.synchronize()
             graph = g
@@ -604,8 +631,8 @@ def main():
                 def capture(n):
                     gg = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(gg):
-                        for _ in range(n):
-                            step_body()
+                        for i in range(n):
+                            step_body(1 + i)  # (behind the one-step opener's copies 0 .. 4)
                     gg.replay()
                     torch.cuda.synchronize()
                     return gg
@@ -756,9 +783,9 @@ def main():
                        + ("W ~ N(0, 0.02^2) quantised GPTQ-style (SURVEY 8d)" if os.environ.get("QQQ_BENCH_WEIGHTS", "gptq") != "uniform"
                           else "uniformly random int4 codes"),
             "tokens": "x ~ N(0,1) fp16 through the fused dynamic int8 quantiser",
-            "launch": (f"hipGraph replay: a one-step graph opens the timed region, then {spg} step(s) per graph (each sweep point bound to one of the rotating "
-                       "weight buffers: a buffer is re-read only after the other four, 356 MB, have passed through the 256 MiB "
-                       "Infinity Cache)") if graph is not None else "eager",
+            "launch": (f"hipGraph replay: a one-step graph opens the timed region, then {spg} step(s) per graph (step t of a graph binds sweep point j to weight copy "
+                       f"(5 t + j) % {NBUF}: a copy is re-read only after the other {NBUF - 1}, {(NBUF - 1) * 89} MB, have passed through the 256 MiB Infinity Cache)"
+                       if world == 1 else "hipGraph replay, one step per graph (each sweep point bound to one of the weight copies)") if graph is not None else "eager",
             "weights_short": f"{NBUF} rotating 89 MB int4 buffers (cold Infinity Cache), " + ("GPTQ-style N(0,0.02^2)" if os.environ.get("QQQ_BENCH_WEIGHTS", "gptq") != "uniform" else "uniform int4 codes"),
             "launch_short": (f"hipGraph replay, 1-step opener then {spg} steps/graph" if graph is not None and world == 1 else n_launch),
             "parallelism_short": "single GPU" if world == 1 else f"M-sharded over {world} GPUs + RCCL all-gather (M >= {64*world})",
@@ -841,6 +868,7 @@ def main():
             # (the kernel issues v_mfma_i32_16x16x64_i8: the only probe rung that is a ceiling FOR IT is the register-only loop of that
             # instruction; the 32x32x32 rungs -- the round-1 tiled kernel's shapes -- are context, not ceilings, and carry no fraction)
             "frac_of_sustained_mfma_16x16x64_only": (a["tops"] / sus["mfma_16x16x64_only_tops"]) if "mfma_16x16x64_only_tops" in sus else None,
+            "frac_of_sustained": (algorithmic_ops(4096, N_FULL, K_FULL) / a["us_median"] / 1e6 / sus["mfma_16x16x64_only_tops"]) if "mfma_16x16x64_only_tops" in sus else None,
             "note": "peak = 256 CU x 2.4 GHz x 8192 int8 op/clk; 4404 TOPS is the v_mfma_i32_32x32x32_i8 micro-benchmark ceiling; "
                     "under the M=4096 kernel the chip clocks ~2.06 GHz (power; `clocks`, profiles/r03_pmc_wide_m4096.txt); "
                     "sustained_on_random_int8 = this part's matrix pipe measured in this run on random operands: register-only loops of "
@@ -882,8 +910,28 @@ def main():
                 if "fp16_gemm_us" in per_m[str(M)]:
                     pg[str(M)]["speedup_vs_fp16"] = per_m[str(M)]["fp16_gemm_us"] / us
             result["per_m_g128"] = pg
+            # ... and the same layer with the opt-in load-time int8 expansion (QuantLinear.expand_for_prefill): the points whose plan reads it
+            lg.expand()
+            px = {}
+            for M in SWEEP_M:
+                pln = _L.plan(M, N_FULL, K_FULL, 128, MAX_PAR, tune=dict(w8=1))
+                if not pln["w8"]:
+                    continue
+                A, s1 = toks[M]
+                lg.time_calls(A, s1, Dfull[M], 3)
+                cold = lg.time_calls(A, s1, Dfull[M], it, rotate=True) * 1e3
+                med = float(np.median(cold))
+                mfma_us = algorithmic_ops(M, N_FULL, K_FULL) / PEAK_MFMA_TOPS / 1e6
+                px[str(M)] = {"us_median": med, "tops": algorithmic_ops(M, N_FULL, K_FULL) / med / 1e6, "kernel": plan_label(pln) + " (expanded int8 weights)",
+                              "ksplit": pln["ksplit"], "roof": "mfma", "roof_frac_median": mfma_us / med, "vs_in_loop_requantiser": pg[str(M)]["us_median"] / med}
+                if "fp16_gemm_us" in per_m[str(M)]:
+                    px[str(M)]["speedup_vs_fp16"] = per_m[str(M)]["fp16_gemm_us"] / med
+            result["per_m_g128_expanded"] = px
+            lg.W8s = None
+            torch.cuda.empty_cache()
         except Exception as e:  # pragma: no cover
-            result["per_m_g128"] = {"error": str(e)}
+            result.setdefault("per_m_g128", {"error": str(e)})
+            result["per_m_g128_expanded"] = {"error": str(e)}
         # the clocks behind `roofline.frac`: rocminfo's maximum, and rocm-smi's reading with ~1 s of M=4096 launches queued
         try:
             A4, s14 = toks[4096]

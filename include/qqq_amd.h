@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define QQQ_AMD_ABI_VERSION 3
+#define QQQ_AMD_ABI_VERSION 4
 
 /* return codes; 0/1/2 are the reference's (csrc/qqq_gemm.cu:947-948, :1002-1003) */
 #define QQQ_OK 0
@@ -77,7 +77,10 @@ typedef struct qqq_tune {
                   are written through and read with agent-scope loads; the switches exist so that tests run both ways),
                   16 = wide: never keep a deposit in the XCD's L2 (as shipped, slices of a tile that find each other on one
                   XCD do: DESIGN.md 3.4.2), 32 = panel: plain grid order (as shipped the grid of a split K is walked so
-                  that the slices of a tile run on ONE XCD whatever the number of strips)                          */
+                  that the slices of a tile run on ONE XCD whatever the number of strips), 64 = wide, two K slices of
+                  256-column tiles: in: never the exchange hand-off (as shipped each slice deposits the row half the other one
+                  finishes and finishes its own, even slices; with the bit: one slice deposits everything, the other folds, uneven
+                  slices); out (qqq_w4a8_plan): set when the plan exchanges                                          */
   int bm;      /* tiled: rows per workgroup tile (64, 128, 256); panel: COLUMNS per workgroup (128, 256); wide: COLUMNS per
                   workgroup (256; 128 with mt = 16 only: 32 columns per wave); 0 auto */
   int glds;    /* tiled: 1 = direct global->LDS loads, 2 = register staged; 0 auto.
@@ -104,6 +107,9 @@ typedef struct qqq_tune {
                   instead of waiting a hand-off latency for them (arrival order still decides who folds: a matter of time, never of
                   correctness).  in: -1 = even slices, 0 = automatic, 1..63 stages.  out (qqq_w4a8_plan): the stages used.  ABI 3.
                   stream (fused = 3): the same in 64-k steps (1..255). */
+  int w8;      /* per-group, wide kernel: the expanded int8 weights of qqq_expand_int8 (ABI 4).  in (qqq_w4a8_gemm_ex2): 0 = use them where the call has
+                  them and the plan is the wide kernel's, -1 = ignore them (A/B timing); in (qqq_w4a8_plan): 1 = plan for a call that has them.
+                  out (qqq_w4a8_plan): 1 = the planned loop reads the expanded weights. */
 } qqq_tune_t;
 
 /* As qqq_w4a8_gemm; `tune` may be NULL; if `acc_out` != NULL the raw int32 accumulators
@@ -114,6 +120,25 @@ int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, const void*
                      const void* s3, int prob_m, int prob_n, int prob_k, void* workspace,
                      int groupsize, int dev, void* stream, int thread_k, int thread_n, int sms,
                      int max_par, const qqq_tune_t* tune, int32_t* acc_out, const void* bias);
+
+/*
+ * Opt-in load-time re-layout for per-group layers (sits beside QuantLinear.pack, qlinear_marlin.py:181-262; default OFF: nothing changes
+ * for a caller that never calls it, and the packed int4 tensor B stays the layer's checkpoint format).
+ * A per-group weight is a pure function of (B, s_group): qqq_expand_int8 runs the reference's in-loop re-quantisation (dequant_per_group,
+ * csrc/qqq_gemm.cu:167-210: w8 = low byte of fp16((u - 8) * s + 1152) ^ 0x80, bit for bit, wrap region included) ONCE per weight and stores the int8
+ * result in the wide kernel's MFMA operand order:
+ *   W8[k / 64][n / 64][2 hf + b][lane = 16 h + 4 c + jt][i]  =  w8(k = 64 (k / 64) + 16 h + i, n = 64 (n / 64) + 16 jt + 8 b + 4 hf + c),   i = 0..15
+ * (k * n bytes, device memory owned by the caller -- twice the packed tensor; B is still needed: small-m calls keep reading it).
+ * qqq_w4a8_gemm_ex2 is qqq_w4a8_gemm_ex with that tensor as a last argument (NULL = none): where the plan of a per-group call is the wide kernel's
+ * (MFMA-bound calls, from a few hundred tokens up) its loop reads W8 -- no transpose, no re-quantiser, no group scales: the per-channel loop minus its
+ * unpack -- and produces the SAME int32 accumulators and the same D bit for bit; everywhere else W8 is ignored.  groupsize must be 128, k % 128 == 0,
+ * n % 64 == 0, k * n < 4 GiB; both enqueue on `stream` and return.
+ */
+int qqq_expand_int8(const void* B, const void* s3, void* W8, int k, int n, int groupsize, int dev, void* stream);
+int qqq_w4a8_gemm_ex2(const void* A, const void* B, void* C, void* D, const void* s1, const void* s2,
+                      const void* s3, int prob_m, int prob_n, int prob_k, void* workspace,
+                      int groupsize, int dev, void* stream, int thread_k, int thread_n, int sms,
+                      int max_par, const qqq_tune_t* tune, int32_t* acc_out, const void* bias, const void* W8);
 
 /* The dispatch decision qqq_w4a8_gemm_ex would take for this problem, without touching the GPU (pure host
  * logic; used by tests and tools).  have_scratch / have_workspace: whether C / workspace would be non-NULL.
@@ -143,6 +168,11 @@ int qqq_dynamic_quant(const void* x, void* xq, void* s1, int m, int k, int dev, 
 int qqq_quantlinear_forward(const void* x, void* xq, void* s1, const void* B, void* C, void* D, const void* s2,
                             const void* s3, int m, int n, int k, void* workspace, int groupsize, int dev,
                             void* stream, int max_par, const void* bias);
+
+/* ... with the layer's expanded int8 weights (qqq_expand_int8; NULL = none), as qqq_w4a8_gemm_ex2 */
+int qqq_quantlinear_forward2(const void* x, void* xq, void* s1, const void* B, void* C, void* D, const void* s2,
+                             const void* s3, int m, int n, int k, void* workspace, int groupsize, int dev,
+                             void* stream, int max_par, const void* bias, const void* W8);
 
 /*
  * int4 packer / unpacker for the Marlin/QQQ weight layout -- replaces the python-loop interleave of

@@ -21,6 +21,12 @@ typedef int (*qqq_gemm_ex_fn)(const void* A, const void* B, void* C, void* D, co
                               int dev, void* stream, int thread_k, int thread_n, int sms, int max_par,
                               const qqq_tune_t* tune, int32_t* acc_out, const void* bias);
 
+/* signature of qqq_w4a8_gemm_ex2 (the same + the layer's expanded int8 weights) */
+typedef int (*qqq_gemm_ex2_fn)(const void* A, const void* B, void* C, void* D, const void* s1, const void* s2,
+                               const void* s3, int prob_m, int prob_n, int prob_k, void* workspace, int groupsize,
+                               int dev, void* stream, int thread_k, int thread_n, int sms, int max_par,
+                               const qqq_tune_t* tune, int32_t* acc_out, const void* bias, const void* W8);
+
 /* Runs `iters` calls of `gemm_ex` back to back on `stream`, call i using the weight buffer Bs[i % nB] (rotate
  * >= 4 x 89 MB buffers to defeat the 256 MiB Infinity Cache), each bracketed by its own hipEvent pair recorded on
  * `stream`; synchronises the stream and writes the `iters` durations in milliseconds to ms_each (host memory). */
@@ -28,6 +34,12 @@ int qqq_dev_bench_gemm(qqq_gemm_ex_fn gemm_ex, const void* A, const void* const*
                        const void* s1, const void* s2, const void* s3, int prob_m, int prob_n, int prob_k,
                        void* workspace, int groupsize, int dev, void* stream, int max_par, const qqq_tune_t* tune,
                        int iters, float* ms_each);
+
+/* the same through qqq_w4a8_gemm_ex2: call i also gets the expanded weights W8s[i % nB] (W8s may be NULL: none) */
+int qqq_dev_bench_gemm2(qqq_gemm_ex2_fn gemm_ex2, const void* A, const void* const* Bs, const void* const* W8s, int nB, void* C, void* D,
+                        const void* s1, const void* s2, const void* s3, int prob_m, int prob_n, int prob_k,
+                        void* workspace, int groupsize, int dev, void* stream, int max_par, const qqq_tune_t* tune,
+                        int iters, float* ms_each);
 
 /* One MFMA on raw per-lane operands, so that the lane<->element maps the kernels rely on are checked on the device.
  * kind 16: v_mfma_i32_16x16x64_i8 (a,b: 64 lanes x 16 B; out: 64 x 4 int32)
@@ -51,6 +63,10 @@ int qqq_dev_probe_fill(const void* src, size_t wg_stride, size_t bytes_per_wg, i
  * 2: + the per-channel int4 unpack; 3: register operands only, on v_mfma_i32_16x16x64_i8 (16 per k-step).  Times ONE launch (after a warm-up launch); ms_out in host memory. */
 int qqq_dev_probe_mfma_rate(int mode, const void* ops, int nwg, int iters, void* sink, int dev, void* stream,
                             float* ms_out);
+/* Placement probe: `nwg` one-wave workgroups each record {HW_REG_XCC_ID, HW_REG_HW_ID} into out[2 * workgroup] (uint32 pairs, device memory) and hold
+ * their CU for `hold_us` microseconds.  cu_mask != NULL: launched on a temporary stream created with that CU mask (mask_words 32-bit words,
+ * hipExtStreamCreateWithCUMask) and synchronised before return -- how the bit -> (XCD, CU) map of the mask was read off the hardware; NULL: on `stream`. */
+int qqq_dev_probe_placement(const uint32_t* cu_mask, int mask_words, int nwg, int hold_us, void* out, int dev, void* stream);
 const char* qqq_dev_last_error(void);
 
 #ifdef __cplusplus

@@ -186,6 +186,23 @@ def weight_operand(B, s3, grouped: bool) -> np.ndarray:
     return dequant_per_group_faithful(codes, s_full)
 
 
+def expand_int8(B, s3=None) -> np.ndarray:
+    """What qqq_expand_int8 (include/qqq_amd.h; round 6, SURVEY 8 f-3's opt-in load-time re-layout) must produce for a
+    layer: the int8 operand `weight_operand(B, s3, grouped)` -- per-group `dequant_per_group` (csrc/qqq_gemm.cu:167-210)
+    applied once per weight, per-channel (s3 None / empty) 16 * w4 -- laid out in the wide kernel's MFMA operand order
+        W8[k // 64][n // 64][2*hf + b][lane = 16*h + 4*c + jt][i] = Wq[64*(k // 64) + 16*h + i, 64*(n // 64) + 16*jt + 8*b + 4*hf + c]
+    (h, c, jt in 0..3; hf, b in 0..1; i in 0..15).  The reference has no counterpart of the LAYOUT (it re-quantises inside its
+    main loop, :527-537); the VALUES are its in-loop operand.  Returns int8 [K * N]."""
+    grouped = s3 is not None and np.asarray(s3).size != 0  # (per-channel layers: the operand is 16 * w4, csrc/qqq_gemm.cu:146-151, :540)
+    Wq = weight_operand(B, s3, grouped)  # [K, N]
+    K, N = Wq.shape
+    assert K % 64 == 0 and N % 64 == 0
+    # axes of the reshape: k -> (s, h, i); n -> (ng, jt, b, hf, c)   [n % 64 = 16 jt + 8 b + 4 hf + c]
+    W = Wq.reshape(K // 64, 4, 16, N // 64, 4, 2, 2, 4)  # [s, h, i, ng, jt, b, hf, c]
+    W = W.transpose(0, 3, 6, 5, 1, 7, 4, 2)             # [s, ng, hf, b, h, c, jt, i]
+    return np.ascontiguousarray(W).reshape(-1)
+
+
 # ----------------------------------------------------------------------------------------------
 # the GEMM
 # ----------------------------------------------------------------------------------------------

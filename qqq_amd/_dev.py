@@ -35,6 +35,11 @@ def lib():
     L.qqq_dev_bench_gemm.argtypes = [vp, vp, ctypes.POINTER(vp), ci, vp, vp, vp, vp, vp, ci, ci, ci, vp, ci, ci, vp, ci,
                                      ctypes.POINTER(_lib.QQQTune), ci, ctypes.POINTER(ctypes.c_float)]
     L.qqq_dev_bench_gemm.restype = ci
+    L.qqq_dev_bench_gemm2.argtypes = [vp, vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ci, vp, vp, vp, vp, vp, ci, ci, ci, vp, ci, ci, vp, ci,
+                                      ctypes.POINTER(_lib.QQQTune), ci, ctypes.POINTER(ctypes.c_float)]
+    L.qqq_dev_bench_gemm2.restype = ci
+    L.qqq_dev_probe_placement.argtypes = [ctypes.POINTER(ctypes.c_uint32), ci, ci, ci, vp, ci, vp]
+    L.qqq_dev_probe_placement.restype = ci
     L.qqq_dev_last_error.restype = ctypes.c_char_p
     _dev = L
     return L
@@ -44,6 +49,12 @@ def gemm_ex_ptr(operator_lib=None):
     """address of qqq_w4a8_gemm_ex in the operator library (what qqq_dev_bench_gemm times)"""
     L = operator_lib if operator_lib is not None else _lib.lib()
     return ctypes.cast(L.qqq_w4a8_gemm_ex, ctypes.c_void_p)
+
+
+def gemm_ex2_ptr(operator_lib=None):
+    """address of qqq_w4a8_gemm_ex2 (what qqq_dev_bench_gemm2 times)"""
+    L = operator_lib if operator_lib is not None else _lib.lib()
+    return ctypes.cast(L.qqq_w4a8_gemm_ex2, ctypes.c_void_p)
 
 
 def last_error() -> str:

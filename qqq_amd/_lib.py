@@ -8,7 +8,7 @@ import os
 from . import build as _build
 
 _lib = None
-ABI_VERSION = 3  # QQQ_AMD_ABI_VERSION in include/qqq_amd.h
+ABI_VERSION = 4  # QQQ_AMD_ABI_VERSION in include/qqq_amd.h
 
 
 class QQQTune(ctypes.Structure):
@@ -16,7 +16,7 @@ class QQQTune(ctypes.Structure):
         ("kernel", ctypes.c_int), ("ksplit", ctypes.c_int), ("waves", ctypes.c_int),
         ("fused", ctypes.c_int), ("bm", ctypes.c_int), ("glds", ctypes.c_int),
         ("pf", ctypes.c_int), ("stages", ctypes.c_int), ("mt", ctypes.c_int), ("pw", ctypes.c_int),
-        ("nslots", ctypes.c_int), ("split_m", ctypes.c_int), ("skew", ctypes.c_int),
+        ("nslots", ctypes.c_int), ("split_m", ctypes.c_int), ("skew", ctypes.c_int), ("w8", ctypes.c_int),
     ]
 
 
@@ -41,6 +41,12 @@ def lib():
     L.qqq_w4a8_gemm.restype = ci
     L.qqq_w4a8_gemm_ex.argtypes = gemm_args + [ctypes.POINTER(QQQTune), vp, vp]
     L.qqq_w4a8_gemm_ex.restype = ci
+    L.qqq_w4a8_gemm_ex2.argtypes = gemm_args + [ctypes.POINTER(QQQTune), vp, vp, vp]
+    L.qqq_w4a8_gemm_ex2.restype = ci
+    L.qqq_expand_int8.argtypes = [vp, vp, vp, ci, ci, ci, ci, vp]
+    L.qqq_expand_int8.restype = ci
+    L.qqq_quantlinear_forward2.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp, ci, ci, vp, ci, vp, vp]
+    L.qqq_quantlinear_forward2.restype = ci
     L.qqq_w4a8_plan.argtypes = [ci, ci, ci, ci, ci, ci, ci, ctypes.POINTER(QQQTune), ctypes.POINTER(QQQTune)]
     L.qqq_w4a8_plan.restype = ci
     L.qqq_w4a8_model_us.argtypes = [ci, ci, ci, ci, ci, ctypes.POINTER(ctypes.c_double)]

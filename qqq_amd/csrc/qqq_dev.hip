@@ -272,12 +272,64 @@ extern "C" int qqq_dev_probe_mfma_rate(int mode, const void* ops, int nwg, int i
   return QQQ_OK;
 }
 
+// Where does a workgroup run?  Every workgroup records HW_REG_XCC_ID and HW_REG_HW_ID (CU / SH / SE ids) and then holds its CU for `hold_us`
+// so that the grid spreads over every CU the stream may use.
+__global__ __launch_bounds__(64) void qqq_probe_placement_kernel(unsigned* __restrict__ out, const int hold_us) {
+  unsigned xcc, hwid;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+  const unsigned long long t0 = wall_clock64();  // 100 MHz
+  while (wall_clock64() - t0 < (unsigned long long)hold_us * 100ull) __builtin_amdgcn_s_sleep(8);
+  if (threadIdx.x == 0) {
+    out[2 * blockIdx.x] = xcc;
+    out[2 * blockIdx.x + 1] = hwid;
+  }
+}
+
+extern "C" int qqq_dev_probe_placement(const uint32_t* cu_mask, int mask_words, int nwg, int hold_us, void* out, int dev, void* stream) {
+  g_dev_err[0] = 0;
+  if (!out || nwg <= 0) return QQQ_ERR_ARG;
+  DevGuard guard(dev);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipStream_t own = nullptr;
+  if (cu_mask && mask_words > 0) {
+    hipError_t e = hipExtStreamCreateWithCUMask(&own, (uint32_t)mask_words, cu_mask);
+    if (e != hipSuccess) return dev_fail(e, "hipExtStreamCreateWithCUMask");
+    st = own;
+  }
+  hipLaunchKernelGGL(qqq_probe_placement_kernel, dim3(nwg), dim3(64), 0, st, static_cast<unsigned*>(out), hold_us);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess && own) e = hipStreamSynchronize(own);
+  if (own) (void)hipStreamDestroy(own);
+  if (e != hipSuccess) return dev_fail(e, "qqq_dev_probe_placement");
+  return QQQ_OK;
+}
+
+static int bench_loop(qqq_gemm_ex_fn gemm_ex, qqq_gemm_ex2_fn gemm_ex2, const void* A, const void* const* Bs, const void* const* W8s, int nB, void* C, void* D,
+                      const void* s1, const void* s2, const void* s3, int prob_m, int prob_n, int prob_k,
+                      void* workspace, int groupsize, int dev, void* stream, int max_par,
+                      const qqq_tune_t* tune, int iters, float* ms_each);
+
 extern "C" int qqq_dev_bench_gemm(qqq_gemm_ex_fn gemm_ex, const void* A, const void* const* Bs, int nB, void* C, void* D,
                                   const void* s1, const void* s2, const void* s3, int prob_m, int prob_n, int prob_k,
                                   void* workspace, int groupsize, int dev, void* stream, int max_par,
                                   const qqq_tune_t* tune, int iters, float* ms_each) {
+  return bench_loop(gemm_ex, nullptr, A, Bs, nullptr, nB, C, D, s1, s2, s3, prob_m, prob_n, prob_k, workspace, groupsize, dev, stream, max_par, tune, iters, ms_each);
+}
+
+extern "C" int qqq_dev_bench_gemm2(qqq_gemm_ex2_fn gemm_ex2, const void* A, const void* const* Bs, const void* const* W8s, int nB, void* C, void* D,
+                                   const void* s1, const void* s2, const void* s3, int prob_m, int prob_n, int prob_k,
+                                   void* workspace, int groupsize, int dev, void* stream, int max_par,
+                                   const qqq_tune_t* tune, int iters, float* ms_each) {
+  return bench_loop(nullptr, gemm_ex2, A, Bs, W8s, nB, C, D, s1, s2, s3, prob_m, prob_n, prob_k, workspace, groupsize, dev, stream, max_par, tune, iters, ms_each);
+}
+
+static int bench_loop(qqq_gemm_ex_fn gemm_ex, qqq_gemm_ex2_fn gemm_ex2, const void* A, const void* const* Bs, const void* const* W8s, int nB, void* C, void* D,
+                      const void* s1, const void* s2, const void* s3, int prob_m, int prob_n, int prob_k,
+                      void* workspace, int groupsize, int dev, void* stream, int max_par,
+                      const qqq_tune_t* tune, int iters, float* ms_each) {
   g_dev_err[0] = 0;
-  if (!gemm_ex || iters <= 0 || nB <= 0 || !Bs || !ms_each) return QQQ_ERR_ARG;
+  if ((!gemm_ex && !gemm_ex2) || iters <= 0 || nB <= 0 || !Bs || !ms_each) return QQQ_ERR_ARG;
   DevGuard guard(dev);
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipEvent_t* ev = new hipEvent_t[2 * iters];
@@ -290,8 +342,12 @@ extern "C" int qqq_dev_bench_gemm(qqq_gemm_ex_fn gemm_ex, const void* A, const v
   if (rc == QQQ_OK) {
     for (int i = 0; i < iters && rc == QQQ_OK; ++i) {
       (void)hipEventRecord(ev[2 * i], st);
-      rc = gemm_ex(A, Bs[i % nB], C, D, s1, s2, s3, prob_m, prob_n, prob_k, workspace, groupsize, dev, stream, -1, -1, -1,
-                   max_par, tune, nullptr, nullptr);
+      if (gemm_ex2)
+        rc = gemm_ex2(A, Bs[i % nB], C, D, s1, s2, s3, prob_m, prob_n, prob_k, workspace, groupsize, dev, stream, -1, -1, -1,
+                      max_par, tune, nullptr, nullptr, W8s ? W8s[i % nB] : nullptr);
+      else
+        rc = gemm_ex(A, Bs[i % nB], C, D, s1, s2, s3, prob_m, prob_n, prob_k, workspace, groupsize, dev, stream, -1, -1, -1,
+                     max_par, tune, nullptr, nullptr);
       (void)hipEventRecord(ev[2 * i + 1], st);
     }
     hipError_t e = hipStreamSynchronize(st);

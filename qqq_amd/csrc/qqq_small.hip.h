@@ -169,4 +169,43 @@ __global__ __launch_bounds__(128) void qqq_unpack_int4_kernel(const unsigned* __
 }
 
 
+// ------------------------------------------------------------------------------------------
+// Load-time expansion of per-group weights to int8 (round 6; SURVEY 8 f-3: "an optional CDNA-friendly re-layout at load time as an
+// opt-in variant, default off").  A per-group weight is a pure function of (B, s_group): the re-quantisation the reference does inside
+// its main loop (dequant_per_group, csrc/qqq_gemm.cu:167-210 -- here dequant_group4, the same bit tricks, wrap region included) is run
+// ONCE per weight, and the int8 result is stored in the wide kernel's MFMA operand order, so that its loop needs neither the
+// re-quantiser nor the quad transpose nor the group scales:
+//   W8[step s = k / 64][ng = n / 64][q = 2 hf + b][lane = 16 h + 4 c + jt][16 bytes i]  =  w8(k = 64 s + 16 h + i, n = 64 ng + 16 jt + 8 b + 4 hf + c)
+// One workgroup = one (step, 64-column group): 4 k-tiles x 128 packed words in, 4 KiB out; thread (h, c8 = 4 hf + c, jt) reads its four
+// words kq = 0..3 (k = 16 (4 s + h) + 4 kq + r) and the scale pair of its two columns b = 0, 1 (stored order: 64 ng + 8 c8 + 2 jt + b).
+// ------------------------------------------------------------------------------------------
+// Per-channel layers (GROUPED = false) expand the same way: the operand the kernels form with `q & 0xF0F0F0F0` / `(q << 4) & 0xF0F0F0F0` (16 w4,
+// csrc/qqq_gemm.cu:146-151, :540) stored as int8 -- no scales involved.
+template <bool GROUPED>
+__global__ __launch_bounds__(128) void qqq_expand_int8_kernel(const unsigned* __restrict__ B, const _Float16* __restrict__ s3,
+                                                              v4u* __restrict__ W8, const int N) {
+  const int tid = threadIdx.x, ng = blockIdx.x, s = blockIdx.y;
+  const int h = tid >> 5, c8 = (tid >> 2) & 7, jt = tid & 3;
+  const unsigned* src = B + (size_t)(4 * s + h) * (2 * (size_t)N) + 128 * ng + 16 * c8 + jt;
+  h2 sb0 = {(_Float16)0, (_Float16)0}, sb1 = sb0;
+  if constexpr (GROUPED) {
+    const h2 sc = *reinterpret_cast<const h2*>(s3 + (size_t)(s >> 1) * N + 64 * ng + 8 * c8 + 2 * jt);
+    sb0 = (h2){sc[0], sc[0]};
+    sb1 = (h2){sc[1], sc[1]};
+  }
+  v4u w0, w1;
+#pragma unroll
+  for (int kq = 0; kq < 4; ++kq) {
+    int a, b;
+    unpack_pair<GROUPED>(src[4 * kq], sb0, sb1, a, b);
+    w0[kq] = (unsigned)a;
+    w1[kq] = (unsigned)b;
+  }
+  const int hf = c8 >> 2, lane = 16 * h + 4 * (c8 & 3) + jt;
+  v4u* dst = W8 + (((size_t)s * (N >> 6) + ng) * 4 + 2 * hf) * 64 + lane;
+  dst[0] = w0;
+  dst[64] = w1;
+}
+
+
 #endif  // QQQ_AMD_QQQ_SMALL_HIP_H_

@@ -4,7 +4,7 @@
 // libqqq_amd.so and carries no kernel code.  Two faces:
 //   * pybind functions (`qqq_amd._torch_ext.qqq_gemm`, `.quantlinear_forward`, `.dynamic_quant`): the eager fast path -- no
 //     dispatcher round trip, no ctypes marshalling (tools/host_overhead.py: 7.5 us -> ~2 us of host time per call);
-//   * TORCH_LIBRARY ops `qqq_amd_native::{qqq_gemm, qqq_gemm_bias, dynamic_quant}` for callers that want dispatcher-visible
+//   * TORCH_LIBRARY ops `qqq_amd_native::{qqq_gemm, qqq_gemm_bias, qqq_gemm_w8, expand_int8, dynamic_quant}` for callers that want dispatcher-visible
 //     native ops (the Python custom ops of ops.py stay the torch.compile path: they carry the fake kernels).
 // Errors: the reference's own checks and messages (csrc/qqq_gemm.cu:1062-1075, :1096-1105) plus the ones it leaves undefined.
 #include <c10/hip/HIPStream.h>
@@ -65,6 +65,42 @@ void qqq_gemm(const at::Tensor& A, const at::Tensor& B, at::Tensor& C, at::Tenso
   raise_for(err, c, thread_k, thread_n);
 }
 
+// the expanded int8 weights of a per-group layer (qqq_expand_int8): int8, k * n elements, on A's device
+const void* checked_w8(const c10::optional<at::Tensor>& W8, int64_t k, int64_t n, int64_t groupsize, const c10::Device& dev) {
+  if (!W8.has_value() || W8->numel() == 0) return nullptr;
+  TORCH_CHECK(W8->scalar_type() == at::kChar && W8->numel() == k * n && W8->is_contiguous() && W8->device() == dev && (groupsize == 128 || groupsize == -1),
+              "W8 must be the contiguous int8 [k * n] tensor of expand_int8 on A's device");
+  return W8->data_ptr();
+}
+
+// qqq_gemm with the fused fp16 bias and / or the layer's expanded int8 weights (both optional)
+void qqq_gemm_w8(const at::Tensor& A, const at::Tensor& B, at::Tensor& C, at::Tensor& D, const at::Tensor& s1, const at::Tensor& s2,
+                 const at::Tensor& s3, at::Tensor& workspace, const c10::optional<at::Tensor>& bias, const c10::optional<at::Tensor>& W8,
+                 int64_t max_par) {
+  const Checked c = check_common(A, B, C, D, s1, s2, s3, workspace, max_par);
+  const at::Tensor* b = bias.has_value() ? &bias.value() : nullptr;
+  TORCH_CHECK(!b || (b->scalar_type() == at::kHalf && b->numel() == c.n && b->is_contiguous() && b->device() == A.device()),
+              "bias must be a contiguous fp16 [n] tensor on A's device");
+  const void* w8 = checked_w8(W8, c.k, c.n, c.groupsize, A.device());
+  const int err = qqq_w4a8_gemm_ex2(ptr(A), ptr(B), ptr(C), ptr(D), ptr(s1), ptr(s2), ptr(s3), c.m, c.n, c.k, ptr(workspace), c.groupsize,
+                                    A.device().index(), stream_of(A), -1, -1, -1, (int)max_par, nullptr, nullptr, b ? ptr(*b) : nullptr, w8);
+  raise_for(err, c, -1, -1);
+}
+
+// load-time expansion of per-group weights: B [k/16, 2n] int32 + s_group [k/128, n] fp16 (stored order) -> W8 int8 [k * n]
+at::Tensor expand_int8(const at::Tensor& B, const at::Tensor& s3) {
+  TORCH_CHECK(B.scalar_type() == at::kInt && B.is_cuda() && B.is_contiguous() && B.dim() == 2, "expand_int8: B must be the packed int32 [k/16, 2n] weight on the GPU");
+  const int64_t k = B.size(0) * 16, n = B.size(1) / 2;
+  const bool grouped = s3.numel() != 0;
+  TORCH_CHECK(!grouped || (s3.scalar_type() == at::kHalf && s3.is_contiguous() && s3.device() == B.device() && s3.dim() == 2 && s3.size(1) == n &&
+                           s3.size(0) * 128 == k),
+              "expand_int8: s_group must be the contiguous fp16 [k/128, n] tensor of a per-group layer on B's device (or empty: per-channel)");
+  at::Tensor W8 = at::empty({k * n}, B.options().dtype(at::kChar));
+  const int err = qqq_expand_int8(ptr(B), ptr(s3), ptr(W8), (int)k, (int)n, grouped ? 128 : -1, B.device().index(), stream_of(B));
+  TORCH_CHECK(err == QQQ_OK, "qqq_amd: expand_int8 error ", err, ": ", qqq_amd_last_error());
+  return W8;
+}
+
 void qqq_gemm_bias(const at::Tensor& A, const at::Tensor& B, at::Tensor& C, at::Tensor& D, const at::Tensor& s1, const at::Tensor& s2,
                    const at::Tensor& s3, at::Tensor& workspace, const at::Tensor& bias, int64_t max_par) {
   const Checked c = check_common(A, B, C, D, s1, s2, s3, workspace, max_par);
@@ -93,7 +129,8 @@ std::tuple<at::Tensor, at::Tensor> dynamic_quant(const at::Tensor& x) {
 
 // QuantLinear.forward (qlinear_marlin.py:270-288) for a contiguous 2-D fp16 input: fused quantiser + GEMM (+ bias), one call
 at::Tensor quantlinear_forward(const at::Tensor& x, const at::Tensor& B, at::Tensor& C, const at::Tensor& s2, const at::Tensor& s3,
-                               at::Tensor& workspace, const c10::optional<at::Tensor>& bias, int64_t max_par) {
+                               at::Tensor& workspace, const c10::optional<at::Tensor>& bias, int64_t max_par,
+                               const c10::optional<at::Tensor>& W8) {
   TORCH_CHECK(x.scalar_type() == at::kHalf && x.is_cuda() && x.dim() == 2 && x.is_contiguous(),
               "quantlinear_forward: expected a contiguous 2-D fp16 tensor on the GPU (there is no CPU path)");
   const int64_t m = x.size(0), k = x.size(1), n = C.size(1);
@@ -117,8 +154,9 @@ at::Tensor quantlinear_forward(const at::Tensor& x, const at::Tensor& B, at::Ten
   at::Tensor s1 = at::empty({m, 1}, x.options().dtype(at::kFloat));
   at::Tensor D = at::empty({m, n}, x.options());
   if (m == 0) return D;
-  const int err = qqq_quantlinear_forward(ptr(x), ptr(xq), ptr(s1), ptr(B), ptr(C), ptr(D), ptr(s2), ptr(s3), (int)m, (int)n, (int)k,
-                                          ptr(workspace), (int)groupsize, dev.index(), stream_of(x), (int)max_par, b ? ptr(*b) : nullptr);
+  const void* w8 = checked_w8(W8, k, n, groupsize, dev);
+  const int err = qqq_quantlinear_forward2(ptr(x), ptr(xq), ptr(s1), ptr(B), ptr(C), ptr(D), ptr(s2), ptr(s3), (int)m, (int)n, (int)k,
+                                           ptr(workspace), (int)groupsize, dev.index(), stream_of(x), (int)max_par, b ? ptr(*b) : nullptr, w8);
   raise_for(err, Checked{(int)m, (int)n, (int)k, (int)groupsize}, -1, -1);
   return D;
 }
@@ -130,12 +168,17 @@ TORCH_LIBRARY(qqq_amd_native, m) {
         "int thread_n, int sms, int max_par) -> ()");
   m.def("qqq_gemm_bias(Tensor A, Tensor B, Tensor(a!) C, Tensor(b!) D, Tensor s1, Tensor s2, Tensor s3, Tensor(c!) workspace, Tensor bias, "
         "int max_par) -> ()");
+  m.def("qqq_gemm_w8(Tensor A, Tensor B, Tensor(a!) C, Tensor(b!) D, Tensor s1, Tensor s2, Tensor s3, Tensor(c!) workspace, Tensor? bias, "
+        "Tensor? W8, int max_par) -> ()");
+  m.def("expand_int8(Tensor B, Tensor s_group) -> Tensor");
   m.def("dynamic_quant(Tensor x) -> (Tensor, Tensor)");
 }
 
 TORCH_LIBRARY_IMPL(qqq_amd_native, CUDA, m) {  // the HIP backend of a ROCm torch registers under the CUDA dispatch key
   m.impl("qqq_gemm", &qqq_gemm);
   m.impl("qqq_gemm_bias", &qqq_gemm_bias);
+  m.impl("qqq_gemm_w8", &qqq_gemm_w8);
+  m.impl("expand_int8", &expand_int8);
   m.impl("dynamic_quant", &dynamic_quant);
 }
 
@@ -144,6 +187,9 @@ PYBIND11_MODULE(_torch_ext, m) {
   m.def("qqq_gemm", &qqq_gemm);
   m.def("qqq_gemm_bias", &qqq_gemm_bias);
   m.def("dynamic_quant", &dynamic_quant);
-  m.def("quantlinear_forward", &quantlinear_forward);
+  m.def("quantlinear_forward", &quantlinear_forward, pybind11::arg("x"), pybind11::arg("B"), pybind11::arg("C"), pybind11::arg("s2"), pybind11::arg("s3"),
+        pybind11::arg("workspace"), pybind11::arg("bias"), pybind11::arg("max_par"), pybind11::arg("W8") = c10::optional<at::Tensor>());
+  m.def("qqq_gemm_w8", &qqq_gemm_w8);
+  m.def("expand_int8", &expand_int8);
   m.def("abi_version", []() { return qqq_amd_abi_version(); });
 }

@@ -49,6 +49,7 @@
 #include <map>
 #include <mutex>
 #include <thread>
+#include <tuple>
 #include <type_traits>
 #include <utility>
 #include <vector>
@@ -125,29 +126,34 @@ static int ref_shape_check(int m, int n, int k, int groupsize, int thread_k, int
 }
 
 // `sms` as a CU cap (the reference launches `sms` persistent threadblocks, csrc/qqq_gemm.cu:998, :1016-1036): the call's kernels run on a
-// library-owned stream created with a CU mask of `sms` CUs (spread evenly over the CU index space, hence over the XCDs), forked from and
-// joined back into the caller's stream with two events -- the caller sees the usual stream order and `sms` CUs' worth of occupancy, the
-// other CUs stay free for whatever else it runs (RCCL's kernels in the sharded sweep).  One stream + two events per (device, sms), created
-// on first use and kept for the life of the process; the fork / launch / join sequence of a call holds the entry's lock.
-// (Inside a hipGraph capture the fork / join are captured like any cross-stream dependency, but kernel nodes carry no CU mask: a
-// replayed graph is not capped.)
+// library-owned stream created with a CU mask of `sms` CUs, forked from and joined back into the caller's stream with two events -- the
+// caller sees the usual stream order and `sms` CUs' worth of occupancy, the other CUs stay free for whatever else it runs (RCCL's kernels
+// in the sharded sweep).
+// The mask, as read off the hardware (tools/cu_mask_probe.py, profiles/r06_cu_mask_probe.txt): bit i is CU i / 8 of XCD
+// i % 8 -- the bits are dealt round-robin over the XCDs --, and an XCD whose bits are ALL zero is not restricted at all.  So the FIRST `sms`
+// bits are set (an even spread: sms / 8 CUs per XCD, the first sms % 8 XCDs one more), and the smallest cap that holds is 8 (one CU per
+// XCD): 0 < sms < 8 runs on 8 CUs.  (Round 5 set every (CUs / sms)-th bit: sms = 64 enabled all of XCDs 3 and 7 and left the other six
+// unrestricted -- no cap at all.)
+// One stream + two events per (device, sms, caller stream) -- callers on independent streams do not serialise on one masked stream --, created
+// on first use and kept for the life of the process (at most 64 entries; beyond that callers share the (device, sms) entry of the NULL stream);
+// the fork / launch / join sequence of a call holds the entry's lock.  A call whose stream is being CAPTURED is not masked: kernel nodes carry
+// no CU mask (a replayed graph is never capped), and pulling a shared library-owned stream into somebody's capture would make every other
+// capped call on it part of that graph (or an error) until the capture ends.
 struct MaskedStream {
   hipStream_t s = nullptr;
   hipEvent_t fork = nullptr, join = nullptr;
   std::mutex mu;
 };
-static MaskedStream* masked_stream(int dev, int sms, int cus) {
+static int masked_cus(int sms) { return sms < 8 ? 8 : sms; }
+static MaskedStream* masked_stream(int dev, int sms, int cus, hipStream_t caller) {
   static std::mutex mu;
-  static std::map<std::pair<int, int>, MaskedStream*> cache;
+  static std::map<std::tuple<int, int, hipStream_t>, MaskedStream*> cache;
   std::lock_guard<std::mutex> lk(mu);
-  auto it = cache.find({dev, sms});
+  if (cache.size() >= 64 && cache.find({dev, sms, caller}) == cache.end()) caller = nullptr;
+  auto it = cache.find({dev, sms, caller});
   if (it != cache.end()) return it->second;
   uint32_t mask[16] = {};
-  for (int i = 0, on = 0; i < cus && i < 512; ++i)  // CU i is enabled when the running share crosses an integer: `sms` of `cus`, evenly spread
-    if ((long long)(i + 1) * sms / cus > on) {
-      mask[i >> 5] |= 1u << (i & 31);
-      ++on;
-    }
+  for (int i = 0; i < masked_cus(sms) && i < cus && i < 512; ++i) mask[i >> 5] |= 1u << (i & 31);
   MaskedStream* m = new MaskedStream;
   if (hipExtStreamCreateWithCUMask(&m->s, (uint32_t)((cus + 31) / 32), mask) != hipSuccess ||
       hipEventCreateWithFlags(&m->fork, hipEventDisableTiming) != hipSuccess ||
@@ -155,9 +161,25 @@ static MaskedStream* masked_stream(int dev, int sms, int cus) {
     delete m;  // (a stream or event that was created stays with the runtime: this path is an out-of-resources error)
     return nullptr;
   }
-  cache[{dev, sms}] = m;
+  cache[{dev, sms, caller}] = m;
   return m;
 }
+// the fork into a masked stream, joined back into the caller's stream on EVERY way out of the call (error returns included: the caller's
+// stream must not be left waiting on nothing, nor the masked stream's work un-ordered against what the caller enqueues next)
+struct MaskedFork {
+  MaskedStream* ms = nullptr;
+  hipStream_t caller = nullptr;
+  std::unique_lock<std::mutex> lock;
+  hipError_t join() {
+    if (!ms) return hipSuccess;
+    hipError_t e = hipEventRecord(ms->join, ms->s);
+    if (e == hipSuccess) e = hipStreamWaitEvent(caller, ms->join, 0);
+    ms = nullptr;
+    lock.unlock();
+    return e;
+  }
+  ~MaskedFork() { (void)join(); }
+};
 
 struct LaunchArgs {
   const int8_t* A;
@@ -178,11 +200,15 @@ struct LaunchArgs {
 
 template <int MT, bool GROUPED, int WAVES, int PF>
 static hipError_t launch_stream_t(const LaunchArgs& a, int ksplit, int fused) {
+#ifdef QQQ_DEV_WIDE_ONLY  // measurement builds (tools/ab.py variants of the wide kernel): the other families are not compiled
+  return hipErrorNotSupported;
+#else
   dim3 grid((a.N + 127) / 128, ksplit & 0xffff, (a.M + 16 * MT - 1) / (16 * MT));
   hipLaunchKernelGGL((qqq_stream_kernel<MT, GROUPED, WAVES, PF>), grid, dim3(WAVES * 64), 0, a.stream,
                      a.A, a.B, a.C, a.D, a.s1, a.s2, a.s3, a.acc_out, a.tickets, a.bias, a.M, a.N, a.K,
                      ksplit, fused);
   return hipGetLastError();
+#endif
 }
 
 // prefetch depth PF (ring slots of 4 KiB weights per wave): deeper for the small-m bodies
@@ -222,10 +248,14 @@ static hipError_t launch_stream(const LaunchArgs& a, bool grouped, int mt, int w
 
 template <int MT, bool GROUPED, int WAVES, int PF>
 static hipError_t launch_column_t(const LaunchArgs& a, int ksplit) {
+#ifdef QQQ_DEV_WIDE_ONLY  // measurement builds (tools/ab.py variants of the wide kernel): the other families are not compiled
+  return hipErrorNotSupported;
+#else
   dim3 grid(a.N / 32, ksplit, (a.M + 16 * MT - 1) / (16 * MT));
   hipLaunchKernelGGL((qqq_column_kernel<MT, GROUPED, WAVES, PF>), grid, dim3(WAVES * 64), 0, a.stream, a.A,
                      a.B, a.C, a.D, a.s1, a.s2, a.s3, a.acc_out, a.bias, a.M, a.N, a.K, ksplit);
   return hipGetLastError();
+#endif
 }
 
 template <bool GROUPED>
@@ -249,6 +279,9 @@ static hipError_t launch_column(const LaunchArgs& a, bool grouped, int mt, int p
 
 template <int MT, bool GROUPED, int WN, int KG, int PFS, int XL, int HW = 1>
 static hipError_t launch_panel_t(const LaunchArgs& a, int ksplit) {
+#ifdef QQQ_DEV_WIDE_ONLY  // measurement builds (tools/ab.py variants of the wide kernel): the other families are not compiled
+  return hipErrorNotSupported;
+#else
   constexpr int ROWS = 16 * MT, BN = 32 * WN * HW;
   constexpr int XBUF = (qqq_panel_relaxed(KG, PFS, XL, HW) ? 4 : KG == 2 ? 2 : 3) * ROWS * 128;
   constexpr int EP = ROWS * (BN + 4) * 4;
@@ -268,6 +301,7 @@ static hipError_t launch_panel_t(const LaunchArgs& a, int ksplit) {
   hipLaunchKernelGGL(kern, grid, dim3(64 * WN * KG), LDS, a.stream, a.A, a.B, a.C, a.D, a.s1, a.s2, a.s3, a.acc_out,
                      a.tickets, a.bias, a.M, a.N, a.K, ksplit | ((a.hflags & 0xff) << 16) | ((ksplit > 1 ? a.skew & 0x3f : 0) << 24));
   return hipGetLastError();
+#endif
 }
 
 template <int MT, bool GROUPED, int PFS, int XL>
@@ -315,6 +349,9 @@ static hipError_t launch_panel(const LaunchArgs& a, bool grouped, int mt, int bn
 
 template <int BM, int MTW, int JW, int NB, bool GROUPED, int NS>
 static hipError_t launch_tiled_t(const LaunchArgs& a, int ksplit, int nslots, int pw) {
+#ifdef QQQ_DEV_WIDE_ONLY  // measurement builds (tools/ab.py variants of the wide kernel): the other families are not compiled
+  return hipErrorNotSupported;
+#else
   constexpr int WAVES = (BM / (32 * MTW)) * (4 / JW) * (2 / NB);
   constexpr int NT = WAVES * 64;
   constexpr int STAGE = 8 * 2048 + BM * 128 + ((NS > 0 && GROUPED) ? WAVES * 512 : 0);
@@ -336,6 +373,7 @@ static hipError_t launch_tiled_t(const LaunchArgs& a, int ksplit, int nslots, in
   hipLaunchKernelGGL(kern, grid, dim3(NT), LDS, a.stream, a.A, a.B, a.C, a.D, a.s1, a.s2, a.s3,
                      a.acc_out, a.bias, a.M, a.N, a.K, ksplit | (a.hflags << 16), tiles_m, tiles_n, a.tickets, nslots, pw);
   return hipGetLastError();
+#endif
 }
 
 // stages: 0 = register-staged; 2..4 = LDS-DMA ring depth (clamped to what fits in 160 KiB of LDS)
@@ -416,7 +454,8 @@ static bool wide_chain_ok(int M, int N, int K, int rows, int bn, int ksplit) {
   return ksplit == 1 && K / 128 >= 8 && tl >= (long long)(device_cus() & ~7) && (device_cus() & ~7) >= 8;
 }
 
-template <bool GROUPED, int MT, int P, int RS, int HW, bool CHAIN = false>
+// MODE: 0 per-channel, 1 per-group (re-quantised in the loop), 2 = expanded int8 weights (a.B is the W8 tensor of qqq_expand_int8)
+template <int MODE, int MT, int P, int RS, int HW, bool CHAIN = false>
 static hipError_t launch_wide_t(const LaunchArgs& a, int pw, int ksplit) {
   constexpr int ROWS = 16 * MT, BN = 128 * HW;
   constexpr int XBUF = P * ROWS * 128, EP = (HW == 2 ? 8 * MT : 16 * MT) * (BN + 4) * 4 + 16;  // + the ticket exchange word
@@ -424,7 +463,7 @@ static hipError_t launch_wide_t(const LaunchArgs& a, int pw, int ksplit) {
   constexpr int LDS = CHAIN ? CH : (XBUF > EP ? XBUF : EP);
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static bool attr_set[64] = {};  // per instantiation, per device
-  auto kern = qqq_wide_kernel<GROUPED, MT, P, RS, HW, CHAIN>;
+  auto kern = qqq_wide_kernel<MODE, MT, P, RS, HW, CHAIN>;
   int cur = 0;
   (void)hipGetDevice(&cur);
   if (cur < 0 || cur >= 64 || !attr_set[cur]) {
@@ -442,15 +481,18 @@ static hipError_t launch_wide_t(const LaunchArgs& a, int pw, int ksplit) {
 
 // mt: 16 (256-token tiles) or 8 (128-token tiles); pf: weight ring in 64-k steps (4 or 8); four LDS stage buffers;
 // bn: 256 columns per workgroup, or (mt = 16 only) 128: 32 columns per wave
-template <bool GROUPED, int MT>
+template <int MODE, int MT>
 static hipError_t launch_wide_m(const LaunchArgs& a, int pf, int pw, int ksplit) {
-  return pf == 4 ? launch_wide_t<GROUPED, MT, 4, 4, 2>(a, pw, ksplit) : launch_wide_t<GROUPED, MT, 4, 8, 2>(a, pw, ksplit);
+  return pf == 4 ? launch_wide_t<MODE, MT, 4, 4, 2>(a, pw, ksplit) : launch_wide_t<MODE, MT, 4, 8, 2>(a, pw, ksplit);
 }
-// the persistent tile walk: the ring depth each mode runs by default (per-channel 4 steps, per-group 8)
-static hipError_t launch_wide_chain(const LaunchArgs& a, bool grouped, int mt, int bn, int pw) {
-  if (bn == 128) return grouped ? launch_wide_t<true, 16, 4, 8, 1, true>(a, pw, 1) : launch_wide_t<false, 16, 4, 4, 1, true>(a, pw, 1);
-  if (mt == 8) return grouped ? launch_wide_t<true, 8, 4, 8, 2, true>(a, pw, 1) : launch_wide_t<false, 8, 4, 4, 2, true>(a, pw, 1);
-  return grouped ? launch_wide_t<true, 16, 4, 8, 2, true>(a, pw, 1) : launch_wide_t<false, 16, 4, 4, 2, true>(a, pw, 1);
+// the persistent tile walk: the ring depth each mode runs by default (per-channel 4 steps, per-group 8; expanded weights: 256 x 256 tiles only)
+static hipError_t launch_wide_chain(const LaunchArgs& a, int mode, int mt, int bn, int pw) {
+  // (expanded weights: ring of 4 steps -- 64 registers; with 8 the walk's seam spills inside the stage loop: 32 registers, 75 scratch instructions)
+  if (mode == 2) return launch_wide_t<2, 16, 4, 4, 2, true>(a, pw, 1);
+  const bool grouped = mode == 1;
+  if (bn == 128) return grouped ? launch_wide_t<1, 16, 4, 8, 1, true>(a, pw, 1) : launch_wide_t<0, 16, 4, 4, 1, true>(a, pw, 1);
+  if (mt == 8) return grouped ? launch_wide_t<1, 8, 4, 8, 2, true>(a, pw, 1) : launch_wide_t<0, 8, 4, 4, 2, true>(a, pw, 1);
+  return grouped ? launch_wide_t<1, 16, 4, 8, 2, true>(a, pw, 1) : launch_wide_t<0, 16, 4, 4, 2, true>(a, pw, 1);
 }
 // Automatic choice (profiles/r04_tile_walk_sweep.txt: plain vs walk over nine layer shapes x five token counts x both modes).
 // A seam costs 5.5 us (per-group 7) where the plain grid pays 9 us between two tiles of a CU (epilogue 6.3 + relaunch 0.2 +
@@ -462,14 +504,22 @@ static hipError_t launch_wide_chain(const LaunchArgs& a, bool grouped, int mt, i
 static bool wide_chain_pays(long long tiles, int K, int mt, int bn) {
   return mt == 16 && bn == 256 && K / 128 <= 64 && tiles > (long long)(device_cus() & ~7);
 }
-static hipError_t launch_wide(const LaunchArgs& a, bool grouped, int mt, int bn, int pf, int pw, int ksplit, bool chain = false) {
-  if (chain) return launch_wide_chain(a, grouped, mt, bn, pw);
-  if (bn == 128) {
-    if (grouped) return pf == 4 ? launch_wide_t<true, 16, 4, 4, 1>(a, pw, ksplit) : launch_wide_t<true, 16, 4, 8, 1>(a, pw, ksplit);
-    return pf == 4 ? launch_wide_t<false, 16, 4, 4, 1>(a, pw, ksplit) : launch_wide_t<false, 16, 4, 8, 1>(a, pw, ksplit);
+static hipError_t launch_wide(const LaunchArgs& a, int mode, int mt, int bn, int pf, int pw, int ksplit, bool chain = false) {
+  if (chain) return launch_wide_chain(a, mode, mt, bn, pw);
+  if (mode == 2) {
+    // expanded weights: ring of 4 steps in every shape (the ring holds ready operands -- 16 registers per step, not 8; 4 measured 1 - 1.5 % ahead of 8 on the
+    // 256 x 256 tiles, profiles/r06_w8_first_numbers.txt; with 8 the 128-token shape parks ring registers in accumulation registers)
+    if (bn == 128) return launch_wide_t<2, 16, 4, 4, 1>(a, pw, ksplit);
+    if (mt == 8) return launch_wide_t<2, 8, 4, 4, 2>(a, pw, ksplit);
+    return launch_wide_t<2, 16, 4, 4, 2>(a, pw, ksplit);
   }
-  if (mt == 8) return grouped ? launch_wide_m<true, 8>(a, pf, pw, ksplit) : launch_wide_m<false, 8>(a, pf, pw, ksplit);
-  return grouped ? launch_wide_m<true, 16>(a, pf, pw, ksplit) : launch_wide_m<false, 16>(a, pf, pw, ksplit);
+  const bool grouped = mode == 1;
+  if (bn == 128) {
+    if (grouped) return pf == 4 ? launch_wide_t<1, 16, 4, 4, 1>(a, pw, ksplit) : launch_wide_t<1, 16, 4, 8, 1>(a, pw, ksplit);
+    return pf == 4 ? launch_wide_t<0, 16, 4, 4, 1>(a, pw, ksplit) : launch_wide_t<0, 16, 4, 8, 1>(a, pw, ksplit);
+  }
+  if (mt == 8) return grouped ? launch_wide_m<1, 8>(a, pf, pw, ksplit) : launch_wide_m<0, 8>(a, pf, pw, ksplit);
+  return grouped ? launch_wide_m<1, 16>(a, pf, pw, ksplit) : launch_wide_m<0, 16>(a, pf, pw, ksplit);
 }
 
 static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -691,12 +741,15 @@ static double panel_estimate(int M, int N, int K, bool grouped, bool have_scratc
 //                              tile counts do not decide -- 0.72 / 0.71 had it the other way round.)
 // Two K slices (256-token tiles): hand-off 15 us per 256 KiB of partial tile (kept in the XCD's L2 when its slices share one -- round 4 --,
 // folded by the last arrival; 20 us written through).
+// (w8: the call has the expanded int8 weights.  The loop is then the per-channel loop minus its unpack, with two more 16-byte
+//  loads per step: priced with the per-channel rates until it has a fit of its own; profiles/r06_w8_first_numbers.txt.)
 static double wide_estimate(int M, int N, int K, bool grouped, bool have_scratch, long long cap_rows, long long cap_tickets, int* ks_out,
-                            int* mt_out, int* bn_out) {
+                            int* mt_out, int* bn_out, bool w8 = false) {
   *ks_out = 1;
   *mt_out = 16;
   *bn_out = 256;
-  if ((long long)N * K / 2 >= (1ll << 32) || (K % 128) != 0) return 1e30;  // 32-bit offsets into the packed weights; whole stages
+  if ((long long)N * K / (w8 ? 1 : 2) >= (1ll << 32) || (K % 128) != 0) return 1e30;  // 32-bit offsets into the weights; whole stages
+  if (w8) grouped = false;
   const int NST = K / 128;
   double best = 1e30;
   for (int shape = 0; shape < 3; ++shape) {
@@ -764,8 +817,9 @@ static int stream_auto_skew(int N, int K, int ksplit) {
 // Measured (profiles/r05_uneven_k_slices_wide.txt): N = 8192, K = 21760 per-group at 1024 tokens 173.1 -> 165.9 us (skew 6; 4: 167.6, 8: 167.0), per-channel
 // two slices of 256 x 256 140.3 -> 133.2 (8); 256 x 128 tiles in two slices at 384 / 512 tokens 80.8 -> 76.4 / 85.6 -> 82.2 (6), per-group 512: 102.8 -> 98.6 (3-6);
 // Llama-2-7B down_proj (4096 x 11008) at 1024 tokens 50.1 -> 48.6, per-group 62.3 -> 58.1 (3).
-static int wide_auto_skew(int mt, int bn, bool grouped, int NST, int ksplit) {
+static int wide_auto_skew(int mt, int bn, bool grouped, int NST, int ksplit, bool w8 = false) {
   (void)NST;
+  if (w8) grouped = false;
   const double t_stage = kQqqWideRates[(mt == 16 && bn == 256) ? 0 : (mt == 16) ? 1 : 2][grouped ? 1 : 0].t_stage;
   const double latency = 20.0 * (16.0 * mt * bn) / 65536.0;
   const int sk = (int)(latency / (t_stage * ksplit / (ksplit - 1.0)) + 0.5);
@@ -782,10 +836,14 @@ struct Plan {
   int bm, stages, nslots, pw; // tiled
   int chain;                  // wide: 1 = persistent tile walk (one workgroup per CU walks its run of tiles)
   int skew;                   // panel: extra 128-k stages of the last K slice
+  int w8;                     // wide: 1 = the loop reads the expanded int8 weights (the call has them)
+  int exch;                   // wide, two K slices of 256-column tiles: 1 = exchange hand-off (each slice finishes one row half), even slices
 };
 
+// (t.w8: 1 = the call has the expanded int8 weights of its layer -- gemm_ex2 sets it from its W8 argument --, -1 = ignore them)
 static Plan make_plan(const int M, const int N, const int K, const bool grouped, const int max_par,
                       const bool have_C, const bool have_ws, qqq_tune_t t, double* est_out = nullptr) {
+  const bool have_w8 = t.w8 > 0 && (long long)N * K < (1ll << 32) && (K % 128) == 0;
   Plan pl;
   memset(&pl, 0, sizeof(pl));
   double est = -1.0;  // the chosen family's modelled time (us) when the choice is the models' (automatic dispatch); -1 otherwise
@@ -843,7 +901,7 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
       // differential fuzzers' independent reference -- and as the fallback for packed weights beyond 4 GB, where the wide kernel's 32-bit
       // offsets end.)
       int wks = 1, wmt = 16, wbn = 256;
-      const double e_wide = (M > 256) ? wide_estimate(M, N, K, grouped, have_scratch && have_ws, cap_rows, cap_tk, &wks, &wmt, &wbn) : 1e30;
+      const double e_wide = (M > 256) ? wide_estimate(M, N, K, grouped, have_scratch && have_ws, cap_rows, cap_tk, &wks, &wmt, &wbn, have_w8) : 1e30;
       est = e_wide < e_panel ? e_wide : e_panel;
       if (e_stream < est) est = e_stream;
       if (e_wide < e_panel && e_wide < e_stream) {
@@ -887,7 +945,8 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
     // instructions against 3, all in the epilogue, none in the loop: tools/code_object.py); the ring depth moves hipcc's allocation at the seam between loop and epilogue.
     // The other shapes (no spills either way) measure level and keep their depths.
     const bool big_tile = (pl.mt == 16 && pl.bm == 256);
-    pl.pf = (t.pf == 8 || t.pf == 4) ? t.pf : (big_tile ? (grouped ? 4 : 8) : (grouped ? 8 : 4));
+    pl.w8 = have_w8 ? 1 : 0;
+    pl.pf = pl.w8 ? 4 : (t.pf == 8 || t.pf == 4) ? t.pf : (big_tile ? (grouped ? 4 : 8) : (grouped ? 8 : 4));
     pl.pw = (t.pw == 4 || t.pw == 8 || t.pw == 16 || t.pw == 32) ? t.pw : 8;
     const int rows = 16 * pl.mt;
     const long long tl = (long long)((M + rows - 1) / rows) * ((N + pl.bm - 1) / pl.bm);
@@ -901,8 +960,10 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
     pl.ksplit = ksplit;
     pl.fused = 1;
     pl.skew = 0;
-    if (ksplit > 1) {  // uneven K slices (tune.skew: -1 never, 0 automatic, else stages): every slice keeps at least 4 stages
-      int sk = t.skew > 0 ? t.skew : (t.skew == 0 ? wide_auto_skew(pl.mt, pl.bm, grouped, K / 128, ksplit) : 0);
+    // two slices of 256-column tiles: the exchange hand-off (qqq_wide.hip.h; tune.fused bit 64 = never, a forced skew = the classic fold with uneven slices)
+    pl.exch = (ksplit == 2 && pl.bm == 256 && t.skew <= 0 && !(t.fused & 64)) ? 1 : 0;
+    if (ksplit > 1 && !pl.exch) {  // uneven K slices (tune.skew: -1 never, 0 automatic, else stages): every slice keeps at least 4 stages
+      int sk = t.skew > 0 ? t.skew : (t.skew == 0 ? wide_auto_skew(pl.mt, pl.bm, grouped, K / 128, ksplit, pl.w8 != 0) : 0);
       const int room = K / 128 - 4 * ksplit;
       if (sk > room) sk = room;
       if (sk > 63) sk = 63;
@@ -910,7 +971,8 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
     }
     // the persistent tile walk (t.glds: 1 = never, 2 = whenever it applies, 0 = automatic); its ring depth is the mode's default
     pl.chain = (t.glds != 1 && wide_chain_ok(M, N, K, rows, pl.bm, ksplit) && (t.glds == 2 || wide_chain_pays(tl, K, pl.mt, pl.bm))) ? 1 : 0;
-    if (pl.chain) pl.pf = grouped ? 8 : 4;
+    if (pl.chain && pl.w8 && !big_tile) pl.chain = 0;  // (the walk over expanded weights is instantiated for 256 x 256 tiles only)
+    if (pl.chain) pl.pf = pl.w8 ? 4 : grouped ? 8 : 4;
     return pl;
   }
 
@@ -1153,7 +1215,7 @@ extern "C" int qqq_w4a8_plan(int prob_m, int prob_n, int prob_k, int groupsize, 
   plan_out->split_m = choose_split(prob_m, prob_n, prob_k, groupsize != -1, max_par, have_scratch != 0, have_workspace != 0, t, pl, est);
   plan_out->kernel = pl.kernel;
   plan_out->ksplit = pl.ksplit;
-  plan_out->fused = pl.fused;
+  plan_out->fused = pl.fused | (pl.kernel == 5 && pl.exch ? 64 : 0);
   plan_out->waves = pl.waves;
   plan_out->pf = pl.pf;
   plan_out->mt = pl.mt;
@@ -1163,6 +1225,7 @@ extern "C" int qqq_w4a8_plan(int prob_m, int prob_n, int prob_k, int groupsize, 
   plan_out->nslots = pl.nslots;
   plan_out->pw = pl.pw;
   plan_out->skew = pl.skew;
+  plan_out->w8 = pl.w8;
   return QQQ_OK;
 }
 
@@ -1203,6 +1266,15 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
                                 void* workspace, int groupsize, int dev, void* stream, int thread_k,
                                 int thread_n, int sms, int max_par, const qqq_tune_t* tune,
                                 int32_t* acc_out, const void* bias) {
+  return qqq_w4a8_gemm_ex2(A, B, C, D, s1, s2, s3, prob_m, prob_n, prob_k, workspace, groupsize, dev, stream, thread_k, thread_n, sms, max_par,
+                           tune, acc_out, bias, nullptr);
+}
+
+extern "C" int qqq_w4a8_gemm_ex2(const void* A, const void* B, void* C, void* D, const void* s1,
+                                 const void* s2, const void* s3, int prob_m, int prob_n, int prob_k,
+                                 void* workspace, int groupsize, int dev, void* stream, int thread_k,
+                                 int thread_n, int sms, int max_par, const qqq_tune_t* tune,
+                                 int32_t* acc_out, const void* bias, const void* W8) {
   g_err[0] = 0;
   const int rc = ref_shape_check(prob_m, prob_n, prob_k, groupsize, thread_k, thread_n);
   if (rc != QQQ_OK) return rc;
@@ -1214,14 +1286,16 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
   // the kernels use 16-byte vector / LDS-DMA accesses on A, B, C, D, bias, acc_out, s3 and 8-byte loads on s2
   if ((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)D | (uintptr_t)bias | (uintptr_t)acc_out |
         (groupsize != -1 ? (uintptr_t)s3 : 0)) & 15) != 0 ||
-      (((uintptr_t)s2) & 7) != 0 || (((uintptr_t)s1 | (uintptr_t)workspace) & 3) != 0) {
-    snprintf(g_err, sizeof(g_err), "misaligned pointer argument (A/B/C/D/s3/bias/acc_out: 16 bytes, s2: 8, s1/workspace: 4)");
+      (((uintptr_t)s2) & 7) != 0 || (((uintptr_t)s1 | (uintptr_t)workspace) & 3) != 0 || (((uintptr_t)W8) & 15) != 0) {
+    snprintf(g_err, sizeof(g_err), "misaligned pointer argument (A/B/C/D/s3/bias/acc_out/W8: 16 bytes, s2: 8, s1/workspace: 4)");
     return QQQ_ERR_ARG;
   }
   const bool grouped = groupsize != -1;
   qqq_tune_t t;
   memset(&t, 0, sizeof(t));
   if (tune) t = *tune;
+  // the layer's expanded int8 weights (qqq_expand_int8): used where the plan is the wide kernel's; tune.w8 = -1 ignores them
+  t.w8 = (W8 != nullptr && t.w8 >= 0) ? 1 : -1;
   const int M = prob_m, N = prob_n, K = prob_k;
   // the device this call runs on decides the CU count the plan and the launch work with (not "the current device"); `sms`
   // (reference: the number of persistent threadblocks, -1 = every SM) caps it
@@ -1229,7 +1303,7 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
   if (dev < 0) (void)hipGetDevice(&cur_dev);
   const int cus_dev = device_cus_of(cur_dev);
   const bool capped = sms > 0 && sms < cus_dev;
-  CallCus call_cus(capped ? sms : cus_dev);
+  CallCus call_cus(capped ? masked_cus(sms) : cus_dev);
   if (handoff_env_flags() & 4) t.fused |= 16;  // QQQ_AMD_NO_LOCAL_DEPOSITS=1: every split-K deposit is written through
   double est = -1.0;
   const Plan pl = make_plan(M, N, K, grouped, max_par, C != nullptr, workspace != nullptr, t, &est);
@@ -1238,12 +1312,12 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
     // offset pointer 16-byte aligned
     qqq_tune_t tn = t;
     tn.split_m = -1;
-    const int rc0 = qqq_w4a8_gemm_ex(A, B, C, D, s1, s2, s3, M0, N, K, workspace, groupsize, dev, stream, thread_k, thread_n, sms, max_par, &tn,
-                                     acc_out, bias);
+    const int rc0 = qqq_w4a8_gemm_ex2(A, B, C, D, s1, s2, s3, M0, N, K, workspace, groupsize, dev, stream, thread_k, thread_n, sms, max_par, &tn,
+                                      acc_out, bias, W8);
     if (rc0 != QQQ_OK) return rc0;
-    return qqq_w4a8_gemm_ex(static_cast<const int8_t*>(A) + (size_t)M0 * K, B, C, static_cast<_Float16*>(D) + (size_t)M0 * N,
-                            static_cast<const float*>(s1) + M0, s2, s3, M - M0, N, K, workspace, groupsize, dev, stream, thread_k, thread_n, sms,
-                            max_par, &tn, acc_out ? acc_out + (size_t)M0 * N : nullptr, bias);
+    return qqq_w4a8_gemm_ex2(static_cast<const int8_t*>(A) + (size_t)M0 * K, B, C, static_cast<_Float16*>(D) + (size_t)M0 * N,
+                             static_cast<const float*>(s1) + M0, s2, s3, M - M0, N, K, workspace, groupsize, dev, stream, thread_k, thread_n, sms,
+                             max_par, &tn, acc_out ? acc_out + (size_t)M0 * N : nullptr, bias, W8);
   }
 
   LaunchArgs a;
@@ -1263,6 +1337,7 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
   a.stream = static_cast<hipStream_t>(stream);
   a.skew = pl.skew;
   a.hflags = (pl.kernel == 2 || pl.kernel == 4 || pl.kernel == 5) ? ((t.fused >> 2) & (pl.kernel == 4 ? 15 : 7)) : 0;  // (panel: bit 3 = plain grid order, the slices of a tile NOT gathered on one XCD)
+  if (pl.kernel == 5 && pl.exch) a.hflags |= 8;  // (wide: bit 3 = exchange hand-off of a two-slice split)
 
   DeviceGuard guard(dev);
   hipError_t e = hipSuccess;
@@ -1271,22 +1346,28 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
     snprintf(g_err, sizeof(g_err), "m=%d exceeds the grid of the small-m kernels (forced by tune)", M);
     return QQQ_ERR_ARG;
   }
-  // sms < CUs: the kernels of this call go to the CU-masked stream of (device, sms), between a fork from and a join into `stream`
-  MaskedStream* ms = nullptr;
-  std::unique_lock<std::mutex> ms_lock;
+  // sms < CUs: the kernels of this call go to the CU-masked stream of (device, sms, caller stream), between a fork from and a join into `stream`
+  MaskedFork mf;
   if (capped) {
-    ms = masked_stream(cur_dev, sms, cus_dev);
-    if (!ms) {
-      snprintf(g_err, sizeof(g_err), "sms=%d: could not create a CU-masked stream", sms);
-      return QQQ_ERR_HIP;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(a.stream, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
+    if (cap == hipStreamCaptureStatusNone) {
+      MaskedStream* ms = masked_stream(cur_dev, sms, cus_dev, a.stream);
+      if (!ms) {
+        snprintf(g_err, sizeof(g_err), "sms=%d: could not create a CU-masked stream", sms);
+        return QQQ_ERR_HIP;
+      }
+      mf.lock = std::unique_lock<std::mutex>(ms->mu);
+      if ((e = hipEventRecord(ms->fork, a.stream)) != hipSuccess || (e = hipStreamWaitEvent(ms->s, ms->fork, 0)) != hipSuccess)
+        return fail_hip(e, "fork into the CU-masked stream");
+      mf.ms = ms;
+      mf.caller = a.stream;
+      a.stream = ms->s;
     }
-    ms_lock = std::unique_lock<std::mutex>(ms->mu);
-    if ((e = hipEventRecord(ms->fork, a.stream)) != hipSuccess || (e = hipStreamWaitEvent(ms->s, ms->fork, 0)) != hipSuccess)
-      return fail_hip(e, "fork into the CU-masked stream");
-    a.stream = ms->s;
   }
   if (pl.kernel == 5) {
-    e = launch_wide(a, grouped, pl.mt, pl.bm, pl.pf, pl.pw, pl.ksplit, pl.chain != 0);
+    if (pl.w8) a.B = static_cast<const unsigned char*>(W8);  // the loop reads the expanded weights; s3 is not touched
+    e = launch_wide(a, pl.w8 ? 2 : (grouped ? 1 : 0), pl.mt, pl.bm, pl.pf, pl.pw, pl.ksplit, pl.chain != 0);
     if (e != hipSuccess) return fail_hip(e, "qqq_wide_kernel launch");
     reduce_launch = false;
   } else if (pl.kernel == 4) {
@@ -1317,11 +1398,7 @@ extern "C" int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, 
     e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "qqq_reduce_kernel launch");
   }
-  if (ms) {
-    hipStream_t caller = static_cast<hipStream_t>(stream);
-    if ((e = hipEventRecord(ms->join, ms->s)) != hipSuccess || (e = hipStreamWaitEvent(caller, ms->join, 0)) != hipSuccess)
-      return fail_hip(e, "join from the CU-masked stream");
-  }
+  if ((e = mf.join()) != hipSuccess) return fail_hip(e, "join from the CU-masked stream");
   return QQQ_OK;
 }
 
@@ -1382,6 +1459,37 @@ extern "C" int qqq_quantlinear_forward(const void* x, void* xq, void* s1, const 
   if (rc != QQQ_OK) return rc;
   return qqq_w4a8_gemm_ex(xq, B, C, D, s1, s2, s3, m, n, k, workspace, groupsize, dev, stream, -1, -1, -1, max_par,
                           nullptr, nullptr, bias);
+}
+
+extern "C" int qqq_quantlinear_forward2(const void* x, void* xq, void* s1, const void* B, void* C, void* D,
+                                        const void* s2, const void* s3, int m, int n, int k, void* workspace,
+                                        int groupsize, int dev, void* stream, int max_par, const void* bias, const void* W8) {
+  const int rc = qqq_dynamic_quant(x, xq, s1, m, k, dev, stream);
+  if (rc != QQQ_OK) return rc;
+  return qqq_w4a8_gemm_ex2(xq, B, C, D, s1, s2, s3, m, n, k, workspace, groupsize, dev, stream, -1, -1, -1, max_par,
+                           nullptr, nullptr, bias, W8);
+}
+
+// ---- load-time expansion of per-group weights (opt-in): B + s3 -> W8, once per layer; see qqq_small.hip.h for the layout
+extern "C" int qqq_expand_int8(const void* B, const void* s3, void* W8, int k, int n, int groupsize, int dev, void* stream) {
+  g_err[0] = 0;
+  if (k == 0 || n == 0) return QQQ_OK;
+  const bool grouped = groupsize != -1;
+  if (!B || (grouped && !s3) || !W8 || (grouped && groupsize != 128) || k < 0 || n < 0 || (k % 128) != 0 || (n % 64) != 0 || (k / 64) > 65535 ||
+      (long long)n * k >= (1ll << 32) || (((uintptr_t)B | (uintptr_t)W8) & 15) != 0 || (grouped && ((uintptr_t)s3 & 3) != 0)) {
+    snprintf(g_err, sizeof(g_err), "qqq_expand_int8: need groupsize -1 or 128, k %% 128 == 0, n %% 64 == 0, n * k < 4 GiB, 16-byte aligned B / W8");
+    return QQQ_ERR_ARG;
+  }
+  DeviceGuard guard(dev);
+  if (grouped)
+    hipLaunchKernelGGL(qqq_expand_int8_kernel<true>, dim3(n / 64, k / 64), dim3(128), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const unsigned*>(B), static_cast<const _Float16*>(s3), static_cast<v4u*>(W8), n);
+  else
+    hipLaunchKernelGGL(qqq_expand_int8_kernel<false>, dim3(n / 64, k / 64), dim3(128), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const unsigned*>(B), static_cast<const _Float16*>(nullptr), static_cast<v4u*>(W8), n);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail_hip(e, "qqq_expand_int8_kernel launch");
+  return QQQ_OK;
 }
 
 // ---- int4 packer / unpacker: device buffers go through the HIP kernels, host buffers through the

@@ -108,23 +108,34 @@ __host__ __device__ constexpr int wide_item_slots_before(int hw, int k) {  // nu
 // inline asm and the waits are placed by hand from the static schedule below: loads complete in issue order, so "the load I
 // need is done" == "at most <number of loads issued after it> are outstanding".
 // Vector-memory loads slot k of a step (parity t = second step of its stage) issues, in the order the slot issues them.
-__host__ __device__ constexpr int wide_loads_in_slot(bool grouped, int mt, int hw, int t, int k) {
+// mode: 0 per-channel int4, 1 per-group int4 (re-quantised in the loop), 2 expanded int8 weights (W8: one 16-byte load per column set and step)
+__host__ __device__ constexpr int wide_w8_refill_index(int mt, int hw, int k) {  // W8: the column set whose operand slot k refills, -1: none
+  const int per = (2 * hw * mt) / (2 * hw);
+  return k % per == 2 ? k / per : -1;
+}
+__host__ __device__ constexpr int wide_loads_in_slot(int mode, int mt, int hw, int t, int k) {
   int n = 0;
-  if (grouped && t == 1 && k == wide_scale_slot(hw) && !(QQQ_WIDE_ABLATE & 8)) n += 2;            // the group scales of stage i + P
-  if ((wide_refill_slot(hw, k, 0) || wide_refill_slot(hw, k, 1)) && !(QQQ_WIDE_ABLATE & 8)) n += 1;  // weight-ring refill
+  if (mode == 1 && t == 1 && k == wide_scale_slot(hw) && !(QQQ_WIDE_ABLATE & 8)) n += 2;            // the group scales of stage i + P
+  if (mode != 2 && (wide_refill_slot(hw, k, 0) || wide_refill_slot(hw, k, 1)) && !(QQQ_WIDE_ABLATE & 8)) n += 1;  // weight-ring refill
+  if (mode == 2 && wide_w8_refill_index(mt, hw, k) >= 0 && !(QQQ_WIDE_ABLATE & 8)) n += 1;
   if (wide_dma_slot(mt, hw, k) && !(QQQ_WIDE_ABLATE & 2)) n += 1;                                  // one activation chunk per lane
   return n;
 }
-__host__ __device__ constexpr int wide_loads_in_step(bool grouped, int mt, int hw, int t, int from, int to) {  // slots [from, to)
+__host__ __device__ constexpr int wide_loads_in_step(int mode, int mt, int hw, int t, int from, int to) {  // slots [from, to)
   int n = 0;
-  for (int k = from; k < to && k < 2 * hw * mt; ++k) n += wide_loads_in_slot(grouped, mt, hw, t, k);
+  for (int k = from; k < to && k < 2 * hw * mt; ++k) n += wide_loads_in_slot(mode, mt, hw, t, k);
   return n;
 }
 // Loads issued after slot k0 of a step with parity t0 and before slot k1 of the step `steps` later (>= 1).
-__host__ __device__ constexpr int wide_loads_between(bool grouped, int mt, int hw, int t0, int k0, int steps, int k1) {
-  int n = wide_loads_in_step(grouped, mt, hw, t0, k0 + 1, 2 * hw * mt);
-  for (int j = 1; j < steps; ++j) n += wide_loads_in_step(grouped, mt, hw, (t0 + j) & 1, 0, 2 * hw * mt);
-  return n + wide_loads_in_step(grouped, mt, hw, (t0 + steps) & 1, 0, k1);
+__host__ __device__ constexpr int wide_loads_between(int mode, int mt, int hw, int t0, int k0, int steps, int k1) {
+  int n = wide_loads_in_step(mode, mt, hw, t0, k0 + 1, 2 * hw * mt);
+  for (int j = 1; j < steps; ++j) n += wide_loads_in_step(mode, mt, hw, (t0 + j) & 1, 0, 2 * hw * mt);
+  return n + wide_loads_in_step(mode, mt, hw, (t0 + steps) & 1, 0, k1);
+}
+__host__ __device__ constexpr int wide_w8_last_refill_slot(int mt, int hw) {
+  int last = 0;
+  for (int k = 0; k < 2 * hw * mt; ++k) last = wide_w8_refill_index(mt, hw, k) >= 0 ? k : last;
+  return last;
 }
 __host__ __device__ constexpr int wide_last_dma_slot(int mt, int hw) {
   int last = 0;
@@ -142,7 +153,13 @@ __host__ __device__ constexpr int wide_last_dma_slot(int mt, int hw) {
 // rotating through the P LDS buffers / RS ring slots across seams (a tile need not be a multiple of P stages), so the seam
 // exists once per stage position of the unrolled trip.  The counterpart of the reference's stripe walk
 // (csrc/qqq_gemm.cu:261-338, :729-760, :792-812), without partial tiles: ksplit == 1 only.
-template <bool GROUPED, int MT, int P, int RS, int HW, bool CHAIN = false>
+//
+// MODE 2 (round 6, SURVEY 8 f-3's opt-in load-time re-layout): `B` is the EXPANDED weight tensor W8 of qqq_expand_int8 -- the per-group weights re-quantised to
+// int8 ONCE at load time (the bit-exact dequant_group4), stored in the MFMA operand order: [64-k step][64-column group][column set q = 2 hf + b][lane][16 bytes],
+// lane (h, c, jt) holding k = 64 step + 16 h + 0..15 of column 64 ng + 16 jt + 8 b + 4 hf + c.  One 16-byte load per column set and step IS the operand: no
+// transpose, no unpack, no re-quantiser, no group scales in the loop -- the MFMAs read the ring registers directly, and a ring slot is refilled (with step
+// s - 1 + RS) during the step AFTER the one that consumed it: RS - 1 steps of lead.  s3 is not read.
+template <int MODE, int MT, int P, int RS, int HW, bool CHAIN = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void qqq_wide_kernel(
     const int8_t* __restrict__ A, const unsigned char* __restrict__ B, int32_t* __restrict__ C, _Float16* __restrict__ D,
     const float* __restrict__ s1, const float* __restrict__ s2, const _Float16* __restrict__ s3,
@@ -152,6 +169,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // fence in front of the fold, 2 = agent-scope RELEASE on the depositor's completion count; see qqq_common.hip.h)
   // (bits 24..29: `skew`, the 128-k stages the LAST K slice gets on top of an even share, as in the panel kernel)
   const int ksplit = ksplit_hf & 0xffff, hflags = (ksplit_hf >> 16) & 0xff, skew = (ksplit_hf >> 24) & 0x3f;
+  constexpr bool GROUPED = MODE == 1, W8 = MODE == 2;
+  static_assert(MODE >= 0 && MODE <= 2, "0 per-channel, 1 per-group, 2 expanded int8");
+  static_assert(!W8 || RS >= 3, "W8: a slot is refilled one step after its use -- RS - 1 steps of lead, the wait count needs at least one whole step in between");
+  constexpr int RL = W8 ? RS - 1 : RS;   // the ring refill of step s fetches step s + RL
   static_assert(MT == 16 || MT == 8, "m-tiles of 16 tokens per wave (= per workgroup): 256 or 128 tokens");
   static_assert(HW == 2 || HW == 1, "a wave owns both 32-column halves of a 64-column group, or (128-column tiles) one");
   constexpr int ROWS = 16 * MT;
@@ -236,6 +257,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int whalf = HW == 2 ? 0 : (cb & 1);
   if (ng >= ngroups) ng = ngroups - 1;   // N % BN != 0: surplus waves of the last strip compute on clamped columns, store nothing
   const unsigned rowbytes = (unsigned)N * 8u;
+  const unsigned wstep = W8 ? (unsigned)N * 64u : 4u * rowbytes;  // bytes of B per 64-k step: four k-tiles of packed int4, or (W8) N x 64 int8
 
   // K slice [st0, st0 + NST) in 128-k stages (K % 128 == 0); steps and stages below are relative to it
   // (uneven slices: the last one is `skew` stages longer, so that it arrives last and finds the other deposits complete)
@@ -254,8 +276,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                  0x00020000u};
   };
   // (CHAIN: one descriptor over the whole tensor, the tile's column group goes into the scalar offset -- ng * 512 / ng * 128 bytes)
-  const v4u wdesc = descriptor(CHAIN ? (const void*)B : (const void*)(B + (size_t)ng * 512));
-  const unsigned woff = (unsigned)h * rowbytes + (unsigned)(cq * 64 + q4 * 16 + 256 * whalf);   // + step * 4 * rowbytes (scalar) + 256 * hf
+  const v4u wdesc = descriptor(CHAIN ? (const void*)B : (const void*)(B + (size_t)ng * (W8 ? 4096 : 512)));
+  const unsigned woff = W8 ? (unsigned)(lane * 16 + 2048 * whalf)                                // + step * wstep (scalar) + 1024 * q
+                           : (unsigned)h * rowbytes + (unsigned)(cq * 64 + q4 * 16 + 256 * whalf);   // + step * wstep (scalar) + 256 * hf
   const v4u sdesc = descriptor(GROUPED ? (CHAIN ? (const void*)s3 : (const void*)(s3 + (size_t)ng * 64)) : (const void*)B);
   const unsigned soff_l = (unsigned)((cq * 8 + 2 * q4) * 2 + 64 * whalf);         // + stage * N * 2 (scalar) + 64 * hf
   // Activation staging by LDS-DMA: instruction q of wave wn fills the 1 KiB [rows 8 wn + 32 q .. + 8) x 128 bytes of the stage
@@ -289,7 +312,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // v_readfirstlane one instruction ahead of it, inside the 5 wait states a VALU-written SGPR needs before a vector-memory
     // instruction may read it; hipcc's hazard bookkeeping does not see through the inline-asm MFMA in between.  Seen as stale
     // offsets in the first load behind every such copy: column half 0 and the first LDS-DMA chunk of every stage.)
-    w_so = (unsigned)__builtin_amdgcn_readfirstlane(g * 512);
+    w_so = (unsigned)__builtin_amdgcn_readfirstlane(g * (W8 ? 4096 : 512));
     s_so = (unsigned)__builtin_amdgcn_readfirstlane(g * 128);
   };
   // the tile being computed (its epilogue needs the coordinates) and the one after it (which the loads cross into over the last
@@ -306,7 +329,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   auto sgpr = [](const unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
   auto cursors_at_stage0 = [&]() {
     cx_so = (unsigned)LA * 128u;
-    cr_so = sgpr(cu_w_so + (unsigned)RS * 4u * rowbytes);
+    cr_so = sgpr(cu_w_so + (unsigned)RL * wstep);
     cc_so = sgpr(cu_s_so + (unsigned)P * (unsigned)N * 2u);
     xdesc[0] = sgpr(cu_a_lo), xdesc[1] = sgpr(cu_a_hi), xdesc[2] = sgpr(cu_a_rec);
   };
@@ -349,16 +372,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     so = __builtin_amdgcn_readfirstlane(so);
     asm("" : "+s"(so));
     if constexpr ((QQQ_W_NT & 8) != 0)  // (measurement builds: non-temporal weight refills)
-      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4 nt" : "=v"(dst) : "v"(woff), "s"(wdesc), "s"(so), "n"(256 * decltype(hfc)::value));
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4 nt" : "=v"(dst) : "v"(woff), "s"(wdesc), "s"(so), "n"((W8 ? 1024 : 256) * decltype(hfc)::value));
     else
-      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=v"(dst) : "v"(woff), "s"(wdesc), "s"(so), "n"(256 * decltype(hfc)::value));
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=v"(dst) : "v"(woff), "s"(wdesc), "s"(so), "n"((W8 ? 1024 : 256) * decltype(hfc)::value));
   };
-  auto load_w_so = [&](const unsigned so, v4u (&dst)[HW]) __attribute__((always_inline)) {
-    qqq_static_for<HW>([&](auto hfc) { asm_load_w(dst[decltype(hfc)::value], hfc, so); });
+  constexpr int WRN = W8 ? NQ : HW;      // 16-byte loads per step and lane: one per 32-column half of packed int4, or (W8) one per column set
+  auto load_w_so = [&](const unsigned so, v4u (&dst)[WRN]) __attribute__((always_inline)) {
+    qqq_static_for<WRN>([&](auto hfc) { asm_load_w(dst[decltype(hfc)::value], hfc, so); });
   };
-  auto load_w = [&](const int step_rel, v4u (&dst)[HW]) __attribute__((always_inline)) {
+  auto load_w = [&](const int step_rel, v4u (&dst)[WRN]) __attribute__((always_inline)) {
     const int s = step_rel < KS ? step_rel : KS - 1;
-    load_w_so((unsigned)(4 * (2 * st0 + s)) * rowbytes, dst);
+    load_w_so((unsigned)(2 * st0 + s) * wstep, dst);
   };
   // (the scales of a stage are always fetched as two words -- HW = 1 needs only the first -- so that the load counts of the
   // static schedule do not depend on HW)
@@ -379,7 +403,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int q = 0; q < NQ; ++q) acc[mt][q] = (v4i){0, 0, 0, 0};
 
-  v4u wr[RS][HW];
+  v4u wr[RS][WRN];
   unsigned scr[GROUPED ? P : 1][2];  // group scales (two fp16 each) of P stages, as loaded
   v4i x[MT];     // activation fragments of the current step; x[mt] is re-read for the next step right behind its last MFMA
   v4i aop[2][NQ]; // weight operands [set][2 * hf + b]: the current step's and the next step's
@@ -480,7 +504,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
     }
   };
-  auto mfma = [&](v4i& c, const v4i& wa, const v4i& xb) {
+  auto mfma = [&](v4i& c, const auto& wa, const v4i& xb) {
     // inline asm: the accumulator is updated IN PLACE in the accumulation registers.  (The builtin selects the untied
     // form there, and with all 256 of them live hipcc's allocator bounces accumulators through VGPRs and scratch.)
     asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+a"(c) : "v"(wa), "v"(xb));
@@ -504,8 +528,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr int NI = HW * (4 + UPARTS);
     auto slot = [&](auto kc) __attribute__((always_inline)) {
       constexpr int k = decltype(kc)::value, mt = k / NQ, q = k % NQ;
-      mfma(acc[mt][q], aop[cur][q], x[mt]);
-      if constexpr (!(QQQ_WIDE_ABLATE & 4)) {
+      if constexpr (W8) mfma(acc[mt][q], wr[sl][q], x[mt]);
+      else mfma(acc[mt][q], aop[cur][q], x[mt]);
+      if constexpr (W8) {
+        // the operands of step s + 1 (ring slot sn): fetched during step s + 1 - RL, the last of them at that step's last refill slot; landed once at
+        // most the loads issued since are outstanding.  One wait per step, behind the step's last MFMA.
+        if constexpr (k == NSLOT - 1) {
+          constexpr int younger_all = wide_loads_between(MODE, MT, HW, 0, wide_w8_last_refill_slot(MT, HW), RL - 1, NSLOT);
+          constexpr int younger = younger_all < 63 ? younger_all : 63;
+          if constexpr (HW == 2) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(wr[sn][0]), "+v"(wr[sn][1]), "+v"(wr[sn][2]), "+v"(wr[sn][3]) : "n"(younger));
+          else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(wr[sn][0]), "+v"(wr[sn][1]) : "n"(younger));
+        }
+      } else if constexpr (!(QQQ_WIDE_ABLATE & 4)) {
         // MT == 16: the NI items go to the NE = 34 memory-free slots of the step (per-channel one each, per-group 2-3 each)
         constexpr bool MAPPED = HW == 1 || ((QQQ_WIDE_SLOTMAP & (GROUPED ? 2 : 1)) != 0 && (MT == 16 || (QQQ_WIDE_SLOTMAP & 4) != 0));
         constexpr int NE = wide_item_slots_before(HW, NSLOT), e = wide_item_slots_before(HW, k);
@@ -520,7 +554,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
               // ring slot sn, half hf: loaded RS - 1 steps ago at slot 2 + 4 hf; everything older (the group scales of this
               // stage among it) has landed once at most the loads issued since are outstanding
               // (vmcnt is a 6-bit counter: a deeper ring than 63 loads waits a little early, never late)
-              constexpr int younger_all = wide_loads_between(GROUPED, MT, HW, (t + RS - 1) & 1, 2 + 4 * hf, RS - 1, k);
+              constexpr int younger_all = wide_loads_between(MODE, MT, HW, (t + RS - 1) & 1, 2 + 4 * hf, RS - 1, k);
               constexpr int younger = younger_all < 63 ? younger_all : 63;
               // (CHAIN, 32-column waves: the second scale word is fetched -- the load counts do not depend on HW -- and never
               // used; tied in here it stays allocated until it has landed.  The plain kernel keeps it live by using it behind its loop.)
@@ -547,10 +581,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         else load_sc(i + P, scr[u]);
       }
       if constexpr (!(QQQ_WIDE_ABLATE & 8)) {  // ring refill, one 16-byte load per slot
-        const int sw = step_abs + RS < KS ? step_abs + RS : KS - 1;
-        const unsigned swo = CHAIN ? cswo : (unsigned)(4 * (2 * st0 + sw)) * rowbytes;
-        if constexpr (wide_refill_slot(HW, k, 0)) asm_load_w(wr[sl][0], std::integral_constant<int, 0>{}, swo);
-        if constexpr (wide_refill_slot(HW, k, 1)) asm_load_w(wr[sl][HW - 1], std::integral_constant<int, 1>{}, swo);
+        const int sw = step_abs + RL < KS ? step_abs + RL : KS - 1;
+        const unsigned swo = CHAIN ? cswo : (unsigned)(2 * st0 + sw) * wstep;
+        if constexpr (W8) {  // column set j of the slot the PREVIOUS step consumed
+          constexpr int j = wide_w8_refill_index(MT, HW, k);
+          if constexpr (j >= 0) asm_load_w(wr[(sl + RS - 1) % RS][j], std::integral_constant<int, j>{}, swo);
+        } else {
+          if constexpr (wide_refill_slot(HW, k, 0)) asm_load_w(wr[sl][0], std::integral_constant<int, 0>{}, swo);
+          if constexpr (wide_refill_slot(HW, k, 1)) asm_load_w(wr[sl][HW - 1], std::integral_constant<int, 1>{}, swo);
+        }
       }
       constexpr int DP = wide_dma_period(MT, HW);  // chunk (XPT / 2) t + k / DP of stage i + LA: M0, then the DMA
       if constexpr (wide_m0_slot(MT, HW, k) && !(QQQ_WIDE_ABLATE & 2))
@@ -709,7 +748,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     scale_dma(tile_m, tile_n, 0);
     qqq_static_for<LA>([&](auto jc) { dma_stage_so(jc, (unsigned)decltype(jc)::value * 128u); });
 #pragma unroll
-    for (int j = 0; j < RS; ++j) load_w_so(cu_w_so + (unsigned)j * 4u * rowbytes, wr[j]);
+    for (int j = 0; j < RL; ++j) load_w_so(cu_w_so + (unsigned)j * wstep, wr[j]);
     if constexpr (GROUPED) {
 #pragma unroll
       for (int j = 0; j < P; ++j) load_sc_so(cu_s_so + (unsigned)j * (unsigned)N * 2u, scr[j]);
@@ -717,17 +756,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   } else {
     qqq_static_for<LA>([&](auto jc) { dma_stage(jc, decltype(jc)::value); });
 #pragma unroll
-    for (int j = 0; j < RS; ++j) load_w(j, wr[j]);
+    for (int j = 0; j < RL; ++j) load_w(j, wr[j]);
     if constexpr (GROUPED) {
 #pragma unroll
       for (int j = 0; j < P; ++j) load_sc(j, scr[j]);
     }
   }
-  qqq_static_for<RS>([&](auto jc) {  // (the asm loads' results are tied to the wait: nothing may read them before it)
+  qqq_static_for<RL>([&](auto jc) {  // (the asm loads' results are tied to the wait: nothing may read them before it)
     constexpr int j = decltype(jc)::value;
     (void)wr[0];
     // (HW = 1: ONE operand -- the same variable tied twice gets two registers and a copy in front of the wait)
-    if constexpr (HW == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(wr[j][0]), "+v"(wr[j][HW - 1]));
+    if constexpr (W8 && HW == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(wr[j][0]), "+v"(wr[j][1]), "+v"(wr[j][2]), "+v"(wr[j][3]));
+    else if constexpr (W8 || HW == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(wr[j][0]), "+v"(wr[j][1]));
     else asm volatile("s_waitcnt vmcnt(0)" : "+v"(wr[j][0]));
   });
   if constexpr (GROUPED) {
@@ -739,12 +779,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   __syncthreads();
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) read_x(0, 0, mt);
-  qqq_static_for<HW>([&](auto hfc) {  // both halves of step 0 into operand set 0
-    constexpr int hf = decltype(hfc)::value;
-    un_setup(__builtin_bit_cast(h2, scr[0][hf]));
-    qqq_static_for<4>([&](auto pc) { tr_piece(pc, wr[0][hf]); __builtin_amdgcn_sched_barrier(0); });
-    qqq_static_for<UPARTS>([&](auto pc) { un_part(pc, hfc, aop[0]); });
-  });
+  if constexpr (!W8) {
+    qqq_static_for<HW>([&](auto hfc) {  // both halves of step 0 into operand set 0
+      constexpr int hf = decltype(hfc)::value;
+      un_setup(__builtin_bit_cast(h2, scr[0][hf]));
+      qqq_static_for<4>([&](auto pc) { tr_piece(pc, wr[0][hf]); __builtin_amdgcn_sched_barrier(0); });
+      qqq_static_for<UPARTS>([&](auto pc) { un_part(pc, hfc, aop[0]); });
+    });
+  }
   __builtin_amdgcn_sched_barrier(0);
 
   auto do_stage = [&](const int i, auto uc) __attribute__((always_inline)) {  // one 128-k stage: two steps and the barrier that publishes stage i + LA
@@ -752,7 +794,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     step(i, uc, std::integral_constant<int, 1>{});
     // the LDS-DMA of stage i + 2, issued during stage i + 3 - P: done when at most the loads issued since its last chunk
     // (the last DMA slot of that stage's second step) are outstanding, i.e. those of the P - 3 stages since
-    constexpr int since = wide_loads_between(GROUPED, MT, HW, 1, wide_last_dma_slot(MT, HW), 2 * (P - 3), NSLOT);
+    constexpr int since = wide_loads_between(MODE, MT, HW, 1, wide_last_dma_slot(MT, HW), 2 * (P - 3), NSLOT);
     static_assert(since < 64, "vmcnt is a 6-bit counter");
     asm volatile("s_waitcnt vmcnt(%0)" : : "n"(since) : "memory");
     if constexpr (!(QQQ_WIDE_ABLATE & 1)) __syncthreads();  // stage i + 2 is in LDS for everybody; buffer (i % P) is free
@@ -764,7 +806,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     static_assert(!CHAIN || P == 4, "the trip is written out for four stage buffers");
     int left = NST;
     auto do_stage_chain = [&](auto uc) __attribute__((always_inline)) {
-      const unsigned wstep = 4u * rowbytes, sstep = (unsigned)N * 2u;
+      const unsigned sstep = (unsigned)N * 2u;
       if (__builtin_expect(left > P, 1)) {  // every load of this stage stays inside the tile
         // (sgpr(): a no-op on a value that is scalar already; it only tells hipcc so where it cannot see it)
         st_xso = sgpr(cx_so), st_swo[0] = sgpr(cr_so), st_swo[1] = sgpr(cr_so + wstep), st_sco = sgpr(cc_so);
@@ -777,7 +819,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         xdesc[0] = sgpr(xn ? nx_a_lo : cu_a_lo), xdesc[1] = sgpr(xn ? nx_a_hi : cu_a_hi), xdesc[2] = sgpr(xn ? nx_a_rec : cu_a_rec);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          const int sn_ = 2 * done + t + RS;               // the step the ring refill of step t fetches
+          const int sn_ = 2 * done + t + RL;               // the step the ring refill of step t fetches
           st_swo[t] = sgpr(sn_ < KS ? cu_w_so + (unsigned)sn_ * wstep : nx_w_so + (unsigned)(sn_ - KS) * wstep);
         }
         st_sco = sgpr(cn ? nx_s_so + (unsigned)(P - left) * sstep : 0u);
@@ -788,7 +830,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
       step(0, uc, std::integral_constant<int, 0>{});
       step(0, uc, std::integral_constant<int, 1>{});
-      constexpr int since = wide_loads_between(GROUPED, MT, HW, 1, wide_last_dma_slot(MT, HW), 2 * (P - 3), NSLOT);
+      constexpr int since = wide_loads_between(MODE, MT, HW, 1, wide_last_dma_slot(MT, HW), 2 * (P - 3), NSLOT);
       static_assert(since < 64, "vmcnt is a 6-bit counter");
       asm volatile("s_waitcnt vmcnt(%0)" : : "n"(since) : "memory");
       __syncthreads();
@@ -836,7 +878,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   qqq_static_for<RS>([&](auto jc) {
     (void)wr[0];
-    asm volatile("" : : "v"(wr[decltype(jc)::value][0]), "v"(wr[decltype(jc)::value][HW - 1]));
+    asm volatile("" : : "v"(wr[decltype(jc)::value][0]), "v"(wr[decltype(jc)::value][WRN - 1]));
+    if constexpr (W8 && HW == 2) asm volatile("" : : "v"(wr[decltype(jc)::value][1]), "v"(wr[decltype(jc)::value][2]));
   });
   if constexpr (GROUPED) {
     qqq_static_for<P>([&](auto jc) {
@@ -872,29 +915,62 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // write-through) into slot `arrival` of the tile in the caller's reduce buffer C; the last arrival adds the slots to its
   // own image rows (agent-scope sc1 loads) on the way to the fp16 conversion.  Two ticket words per tile in `workspace`
   // (arrivals, completed deposits), zero again on exit. ----
+  // ---- two slices, EXCHANGE (round 6; hflags & 8, tiles whose epilogue runs in two row halves): instead of one slice depositing its whole partial tile and
+  // idling while the other folds 256 KiB and runs the whole epilogue, each slice deposits the row half the OTHER one will finish and finishes its own half
+  // (slice sp owns rows [sp EPR, sp EPR + EPR)) -- both CUs busy, half the fold and half the epilogue on the critical path, even K slices (no skew).
+  // A slice that waits for its partner's deposit must know the partner is RUNNING: HIP promises nothing about dispatch order or co-residency.  The arrival
+  // word already says so: every slice publishes a valid nibble (XCC id) at kernel start.  The FIRST arrival decides -- partner's nibble valid: exchange (bit 16),
+  // else classic (bit 17: it deposits everything and leaves, the partner folds) -- and records the decision with a second atomic; the second arrival reads it
+  // (polling a moment if it arrives between the two atomics: the decider is past its loop and never waits in between).  An exchanging slice deposits before it
+  // waits and waits only for a partner that has provably started and that itself deposits before it waits: no cycle, whatever else occupies the chip. ----
+  constexpr unsigned XB_EXCH = 1u << 16, XB_CLASSIC = 1u << 17;
+  const bool exch_on = ksplit == 2 && (hflags & 8) != 0 && ROWS / EPR == 2;
   int arrival = 0;
+  bool exch = false;
   if (ksplit > 1) {
     int* tk = tickets + 2 * (size_t)tile_lin;
     int* xch = ep + EPR * EP_STRIDE;  // one word behind the image (a second __shared__ object would de-pipeline the main loop)
-    if (tid == 0) *xch = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) {
+      unsigned w = (unsigned)__hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (exch_on) {
+        const unsigned arr = w & 0xffu;
+        if (arr == 0) {  // first arrival: decide, record
+          const unsigned dec = (((w >> (8 + 4 * (1 - sp))) & 8u) != 0) ? XB_EXCH : XB_CLASSIC;
+          (void)__hip_atomic_fetch_or(tk, (int)dec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          w |= dec;
+        } else {         // second arrival: the decision is there, or a moment away
+          int spin = 0;
+          while (!(w & (XB_EXCH | XB_CLASSIC))) {
+            if (++spin > QQQ_SPIN_LIMIT) __builtin_trap();
+            __builtin_amdgcn_s_sleep(1);
+            w = (unsigned)__hip_atomic_load(tk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          w = (w & ~0xffu) | arr;
+        }
+      }
+      *xch = (int)w;
+    }
     __syncthreads();
     const unsigned word = (unsigned)__builtin_amdgcn_readfirstlane(*xch);
     arrival = (int)(word & 0xffu);
+    exch = exch_on && (word & XB_EXCH) != 0;
     const size_t slot_ints = (size_t)ROWS * BN;
-    if (arrival < ksplit - 1) {
+    if (exch || arrival < ksplit - 1) {
       // Same XCD for every slice of this tile, as far as the arrival word shows at MY arrival?  Then the deposit may stay in
       // this XCD's L2.  The set of published nibbles only grows, and the finisher takes its ticket after every depositor: it
       // sees at least what I see.  So if I deposit L2-only, the finisher (and every other slice) is on my XCD and finds my
       // lines in the L2 we share; if any slice is elsewhere -- or has not even started -- I write through, and a write-through
       // store is right for a reader anywhere.  The finisher's loads are the same either way (agent scope: an L1 miss, an L2 hit
       // where the line is, memory otherwise).  hflags & 4 (tune.fused bit 4) forces the write-through path, for A/B timing.
+      // (exchange: the one slot of the tile, each slice writing the row half it does not own; both nibbles are valid by then)
       bool local = ksplit <= 6 && !(hflags & 4);
       for (int j = 0; j < ksplit; ++j) local = local && ((word >> (8 + 4 * j)) & 15u) == (8u | my_xcc);
-      const __amdgpu_buffer_rsrc_t sv = wide_view(C + ((size_t)tile_lin * (ksplit - 1) + arrival) * slot_ints);
+      const __amdgpu_buffer_rsrc_t sv = wide_view(C + ((size_t)tile_lin * (ksplit - 1) + (exch ? 0 : arrival)) * slot_ints);
       auto deposit = [&](auto auxc) __attribute__((always_inline)) {
         constexpr int aux = decltype(auxc)::value;
 #pragma unroll
         for (int pass = 0; pass < ROWS / EPR; ++pass) {
+          if (exch && pass == sp) continue;  // (wave-uniform) my own half stays here
           __syncthreads();
           image(pass);
           __syncthreads();
@@ -914,7 +990,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();  // every wave's part of the deposit is where the finisher will look for it
       if (tid == 0) qqq_publish_add(tk + 1, hflags);
-      return;
+      if (!exch) return;
     }
   }
 
@@ -977,27 +1053,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
     }
   };
+  const int first_pass = exch ? sp : 0;
 #pragma unroll
   for (int pass = 0; pass < ROWS / EPR; ++pass) {
+    if (exch && pass != sp) continue;  // (wave-uniform) exchange: the other half is the partner's
     __syncthreads();
     image(pass);
-    if (pass == 0 && fold) {
+    if (pass == first_pass && fold) {
       // the last arrival: everybody it waits for has arrived already (is depositing) -- short, and bounded as a matter of
       // principle: a depositor that never completes must not end in a silently wrong D (the launch is aborted instead)
+      // (exchange: both slices wait here for BOTH deposits -- their own is counted -- then count once more: whoever counts second knows
+      // that nobody polls the words any longer and zeroes them)
       if (tid == 0) {
         int* tk = tickets + 2 * (size_t)tile_lin;
         int spin = 0;
-        while (__hip_atomic_load(tk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ksplit - 1) {
+        while (__hip_atomic_load(tk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (exch ? 2 : ksplit - 1)) {
           if (++spin > QQQ_SPIN_LIMIT) __builtin_trap();
           __builtin_amdgcn_s_sleep(2);
         }
-        __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // workspace zero on return
-        __hip_atomic_store(tk + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!exch || __hip_atomic_fetch_add(tk + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 3) {
+          __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // workspace zero on return
+          __hip_atomic_store(tk + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
     }
     __syncthreads();
-    if (pass == 0 && fold && qqq_formal_acquire(hflags)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (off by default: qqq_common.hip.h)
-    if (pass == 0) {  // (the pin: behind the first image's LDS writes, which cover the loads' round trip)
+    if (pass == first_pass && fold && qqq_formal_acquire(hflags)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (off by default: qqq_common.hip.h)
+    if (pass == first_pass) {  // (the pin: behind the first image's LDS writes, which cover the loads' round trip)
 #pragma unroll
       for (int p2 = 0; p2 < ROWS / EPR; ++p2)
 #pragma unroll

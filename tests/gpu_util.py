@@ -37,6 +37,12 @@ class GemmHarness:
         # poison the scratch: the kernels must not depend on its previous contents
         self.C = torch.full((max_par * 64, self.N), 0x7B7B7B7B, dtype=torch.int32, device=dev)
         self.ws = torch.zeros(max(self.N // 128, 1) * max_par, dtype=torch.int32, device=dev)
+        self.W8 = None
+
+    def expand(self):
+        """opt-in load-time re-layout (per-group layers): from here on every run() hands the expanded int8 weights to the call"""
+        self.W8 = ops.expand_int8(self.B, self.s3)  # (s3 empty: a per-channel layer)
+        return self
 
     def run(self, A, s1, tune=None, want_acc=True, bias=None):
         A = (torch.from_numpy(np.ascontiguousarray(A)) if isinstance(A, np.ndarray) else A).to(self.dev).contiguous()
@@ -47,7 +53,7 @@ class GemmHarness:
         if bias is not None:
             bias = (torch.from_numpy(np.ascontiguousarray(bias)) if isinstance(bias, np.ndarray) else bias).to(self.dev)
         ops.qqq_gemm_ex(A, self.B, self.C, D, s1, self.s2, self.s3, self.ws, -1, -1, -1, self.max_par,
-                        tune=tune, acc_out=acc, bias=bias)
+                        tune=tune, acc_out=acc, bias=bias, W8=self.W8)
         torch.cuda.synchronize()
         assert int(self.ws.abs().sum().item()) == 0, "workspace must be all-zero on return"
         return D.cpu().numpy(), (acc.cpu().numpy() if want_acc else None)

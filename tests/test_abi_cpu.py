@@ -26,11 +26,12 @@ def _declared(header):
 
 def test_exports_every_declared_symbol(L):
     names = _declared("qqq_amd.h")
-    assert {"qqq_w4a8_gemm", "qqq_w4a8_gemm_ex", "qqq_w4a8_plan", "qqq_w4a8_model_us", "qqq_dynamic_quant", "qqq_quantlinear_forward",
-            "qqq_pack_int4", "qqq_unpack_int4", "qqq_amd_abi_version", "qqq_amd_last_error"} == names
+    assert {"qqq_w4a8_gemm", "qqq_w4a8_gemm_ex", "qqq_w4a8_gemm_ex2", "qqq_expand_int8", "qqq_w4a8_plan", "qqq_w4a8_model_us", "qqq_dynamic_quant",
+            "qqq_quantlinear_forward", "qqq_quantlinear_forward2", "qqq_pack_int4", "qqq_unpack_int4", "qqq_amd_abi_version",
+            "qqq_amd_last_error"} == names
     for n in names:
         assert hasattr(L, n), n
-    assert L.qqq_amd_abi_version() == 3
+    assert L.qqq_amd_abi_version() == 4
     # the operator library is the operator only: measurement loops and hardware probes live in the dev library
     for n in ("qqq_bench_gemm", "qqq_probe_mfma", "qqq_probe_glds", "qqq_probe_fill", "qqq_add_bias", "qqq_dev_bench_gemm"):
         assert not hasattr(L, n), n
@@ -42,8 +43,8 @@ def test_dev_library_exports_every_declared_symbol():
     build.build_dev()
     D = _dev.lib()
     names = _declared("qqq_amd_dev.h")
-    assert {"qqq_dev_bench_gemm", "qqq_dev_probe_mfma", "qqq_dev_probe_glds", "qqq_dev_probe_dequant",
-            "qqq_dev_probe_fill", "qqq_dev_probe_mfma_rate", "qqq_dev_last_error"} == names
+    assert {"qqq_dev_bench_gemm", "qqq_dev_bench_gemm2", "qqq_dev_probe_mfma", "qqq_dev_probe_glds", "qqq_dev_probe_dequant",
+            "qqq_dev_probe_fill", "qqq_dev_probe_mfma_rate", "qqq_dev_probe_placement", "qqq_dev_last_error"} == names
     for n in names:
         assert hasattr(D, n), n
 
@@ -342,7 +343,7 @@ def test_compiled_torch_binding_imports_and_keeps_the_error_contract():
     kb.build()
     kb.build_torch_ext()
     E = ops._ext()
-    assert E is not None and E.abi_version() == 3
+    assert E is not None and E.abi_version() == 4
     assert hasattr(torch.ops.qqq_amd_native, "qqq_gemm") and hasattr(torch.ops.qqq_amd_native, "dynamic_quant")
     A = torch.zeros((4, 128), dtype=torch.int8)
     B = torch.zeros((8, 256), dtype=torch.int32)
@@ -394,9 +395,14 @@ def test_uneven_k_slices_in_the_plan():
         assert sum(lens) == nst and min(lens) >= 4 and lens[-1] - max(lens[:-1]) in (skew, skew - 1, skew + 1), (nst, ks, skew, lens)
     # the wide kernel's two-slice split takes the same knob: 256 KiB deposits, ~20 us from last MFMA to "complete" -> 6 stages per-group at 1024 tokens
     # (173.1 -> 165.9 us, profiles/r05_uneven_k_slices_wide.txt), 7 for the 256 x 128 tiles per-channel at 384 / 512 tokens
+    # (round 6: two slices of 256-column tiles EXCHANGE row halves -- even slices, plan field fused carries bit 64 --; tune.fused bit 64 asks for the classic fold)
     p = _lib.plan(1024, N, K, 128, 16)
-    assert (p["kernel"], p["ksplit"], p["skew"]) == (5, 2, 6), p
-    assert _lib.plan(1024, N, K, 128, 16, tune=dict(skew=5))["skew"] == 5 and _lib.plan(1024, N, K, 128, 16, tune=dict(skew=-1))["skew"] == 0
+    assert (p["kernel"], p["ksplit"], p["skew"], p["fused"] & 64) == (5, 2, 0, 64), p
+    p = _lib.plan(1024, N, K, 128, 16, tune=dict(fused=64))
+    assert (p["kernel"], p["ksplit"], p["skew"], p["fused"] & 64) == (5, 2, 6, 0), p
+    p = _lib.plan(1024, N, K, 128, 16, tune=dict(skew=5))   # a pinned skew is the classic fold with uneven slices
+    assert (p["skew"], p["fused"] & 64) == (5, 0), p
+    assert _lib.plan(1024, N, K, 128, 16, tune=dict(skew=-1))["skew"] == 0
     p = _lib.plan(512, N, K, -1, 16)
     assert (p["kernel"], p["bm"], p["ksplit"], p["skew"]) == (5, 128, 2, 7), p
 

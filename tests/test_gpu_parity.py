@@ -348,7 +348,7 @@ def _with_handoff(tune, hand):
     in front of the fold, an agent-scope release on the depositor's completion count -- and the wide kernel's XCD-local deposits
     switched off (every deposit written through, as in round 3).  The same library runs every variant."""
     t = dict(tune)
-    t["fused"] = (t.get("fused", 1) & 3) | hand
+    t["fused"] = (t.get("fused", 1) & (3 | 64)) | hand  # (bit 6: the wide kernel's two-slice split WITHOUT the exchange hand-off)
     return t
 
 
@@ -451,20 +451,24 @@ def test_panel_inlaunch_splitk_stress_two_streams(dev, hand):
 @HANDOFFS
 def test_wide_inlaunch_splitk_stress_two_streams(dev, hand):
     """The wide kernel's ticket / slot hand-off under load (row-major partial tiles written through to C, folded by the last
-    arrival with agent-scope loads, no acquire fence): two layers with their own scratch hammered from two streams, both tile
-    heights, 2-3 K slices, ragged m; every result equal to the unsplit stream kernel's bit for bit, workspaces all-zero after."""
+    arrival with agent-scope loads, no acquire fence): three layers with their own scratch hammered from two streams, both tile
+    heights, 2-3 K slices, ragged m; every result equal to the unsplit stream kernel's bit for bit, workspaces all-zero after.
+    Round 6: two slices of 256-column tiles EXCHANGE row halves by default (the first arrival decides from the partner's started
+    bit; under this load some pairs fall back to the classic fold), fused = 65 forces the classic protocol; the third layer is
+    per-group with expanded int8 weights (the loop that reads them has the same epilogue)."""
     from qqq_amd import pack as P
 
     g = torch.Generator(device="cpu").manual_seed(321)
     N, K = 2048, 4096
     layers = []
-    for i in range(2):
-        grouped = i == 1
+    for i in range(3):
+        grouped = i >= 1
         codes = torch.randint(0 if grouped else -7, 16 if grouped else 8, (K, N), generator=g, dtype=torch.int8)
         B = P.pack_codes(codes.to(dev), grouped)
         s2 = (torch.rand((1, N), generator=g) * 2e-4 + 1e-5).to(torch.float32)
         s3 = (torch.rand((K // 128, N), generator=g) * 15.0 + 0.5).to(torch.float16) if grouped else None
         layers.append(GemmHarness(B, s2, s3, dev))
+    layers[2].expand()
     Ms = [129, 256, 300, 512, 700, 1024]
     toks, want = {}, {}
     for M in Ms:
@@ -484,10 +488,10 @@ def test_wide_inlaunch_splitk_stress_two_streams(dev, hand):
                 M = Ms[(it + 2 * li) % len(Ms)]
                 A, s1 = toks[M]
                 tune = [dict(kernel=5, ksplit=2), dict(kernel=5, mt=8, ksplit=2), dict(kernel=5, ksplit=3), dict(kernel=5, mt=8, ksplit=3, pf=8),
-                        dict(kernel=5, ksplit=2, pw=4), dict(kernel=5, bm=128, ksplit=2)][it % 6]
+                        dict(kernel=5, ksplit=2, pw=4), dict(kernel=5, bm=128, ksplit=2), dict(kernel=5, ksplit=2, fused=65), dict(kernel=5, mt=8, ksplit=2, fused=65, skew=2)][it % 8]
                 D = torch.empty((M, N), dtype=torch.float16, device=dev)
-                with torch.cuda.stream(streams[li]):
-                    ops.qqq_gemm_ex(A, h.B, h.C, D, s1, h.s2, h.s3, h.ws, -1, -1, -1, 16, tune=(_with_handoff(tune, hand) if tune else tune))
+                with torch.cuda.stream(streams[li % 2]):
+                    ops.qqq_gemm_ex(A, h.B, h.C, D, s1, h.s2, h.s3, h.ws, -1, -1, -1, 16, tune=(_with_handoff(tune, hand) if tune else tune), W8=h.W8)
                 outs.append((li, M, D, tune))
         torch.cuda.synchronize()
         for li, M, D, tune in outs:

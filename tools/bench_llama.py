@@ -54,12 +54,13 @@ def time_fn(fn, iters=10, reps=8):
 TOKENS = (1024, 8192, 32768)  # batch 1 / 8 / 32 x seq 1024
 
 
-def llama_matrix(dev, tokens=TOKENS, modes=(-1, 128), budget_s=None, merged=True):
+def llama_matrix(dev, tokens=TOKENS, modes=(-1, 128, (128, True)), budget_s=None, merged=True):
     """BASELINE configs[3] as a dict: per linear / token count / mode the QuantLinear time (fused dynamic quant + W4A8 GEMM),
     the GEMM alone, the fp16 nn.Linear, `gemm_tops` and `speedup_vs_fp16`; the sum over the 7 linears of a block; and (merged)
     the same block with the projections that share an input fused.  One implementation for `python
     tools/bench_llama.py` and for bench.py's `llama7b` object.  budget_s: wall-clock bound; what did not fit is listed under
-    "skipped" (nothing is extrapolated)."""
+    "skipped" (nothing is extrapolated).  A mode is a group size or (group size, True): the layers with expand_for_prefill() -- the
+    opt-in load-time int8 expansion (round 6) -- under the key "g128_expanded"; the fp16 time of a (layer, token count) is measured once."""
     import time
     from qqq_amd import fuse_quant_linears, ops
 
@@ -70,8 +71,10 @@ def llama_matrix(dev, tokens=TOKENS, modes=(-1, 128), budget_s=None, merged=True
     def over():
         return budget_s is not None and time.perf_counter() - t_start > budget_s
 
-    for gs in modes:
-        mode = "per_channel" if gs == -1 else "g128"
+    fp16_us = {}
+    for spec in modes:
+        gs, expand = spec if isinstance(spec, tuple) else (spec, False)
+        mode = ("per_channel" if gs == -1 else "g128") + ("_expanded" if expand else "")
         tot = {}
         complete = True
         for (name, N, K) in LAYERS:
@@ -80,14 +83,18 @@ def llama_matrix(dev, tokens=TOKENS, modes=(-1, 128), budget_s=None, merged=True
                 complete = False
                 continue
             ql = make_ql(dev, N, K, gs, hash((name, gs)) & 0xFFFF)
+            if expand:
+                ql.expand_for_prefill(per_channel=True)
             lin = torch.nn.Linear(K, N, bias=False).half().to(dev)
             for M in tokens:
                 x = torch.randn((M, K), device=dev, dtype=torch.float16)
                 t_q = time_fn(lambda: ql(x))
                 xq, s1 = ql.dynamic_quant(x)
                 D = torch.empty((M, N), dtype=torch.float16, device=dev)
-                t_g = time_fn(lambda: ops.mul(xq, ql.B, ql.reduce_buffer, D, s1, ql.s_channel, ql.s_group, ql.workspace, max_par=16))
-                t_f = time_fn(lambda: lin(x))
+                t_g = time_fn(lambda: ops.qqq_gemm_w8(xq, ql.B, ql.reduce_buffer, D, s1, ql.s_channel, ql.s_group, ql.workspace, None, ql.W8, 16))
+                if (N, K, M) not in fp16_us:
+                    fp16_us[(N, K, M)] = time_fn(lambda: lin(x))
+                t_f = fp16_us[(N, K, M)]
                 out["layers"].setdefault(mode, {}).setdefault(name, {})[str(M)] = {
                     "quantlinear_us": t_q, "gemm_only_us": t_g, "fp16_linear_us": t_f,
                     "gemm_tops": 2.0 * M * N * K / t_g / 1e6, "speedup_vs_fp16": t_f / t_q}
@@ -111,12 +118,16 @@ def llama_matrix(dev, tokens=TOKENS, modes=(-1, 128), budget_s=None, merged=True
                 continue
             qls = [make_ql(dev, n, K, gs, hash((name, i, gs)) & 0xFFFF) for i, n in enumerate(parts)]
             ql = fuse_quant_linears(qls) if len(qls) > 1 else qls[0]
+            if expand:
+                ql.expand_for_prefill(per_channel=True)
             N = sum(parts)
             lin = torch.nn.Linear(K, N, bias=False).half().to(dev)
             for M in tokens:
                 x = torch.randn((M, K), device=dev, dtype=torch.float16)
                 t_q = time_fn(lambda: ql(x))
-                t_f = time_fn(lambda: lin(x))
+                if (N, K, M) not in fp16_us:
+                    fp16_us[(N, K, M)] = time_fn(lambda: lin(x))
+                t_f = fp16_us[(N, K, M)]
                 out.setdefault("fused_layers", {}).setdefault(mode, {}).setdefault(name, {})[str(M)] = {
                     "quantlinear_us": t_q, "fp16_linear_us": t_f, "speedup_vs_fp16": t_f / t_q}
                 ftot.setdefault(M, [0.0, 0.0])

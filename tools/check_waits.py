@@ -37,6 +37,7 @@ def tail_paths(lines, limit=64):
     end = next(i for i in range(len(lines)) if lines[i : i + len(body)] == body) + len(body)
     labels = {m.group(1): i for i, l in enumerate(lines) if (m := re.match(r"^(\.LBB\d+_\d+):", l))}
     paths = []
+    has_marker = any(l.split(";")[0].strip() == "s_nop 15" for l in lines[end:])
 
     def walk(i, acc, depth):
         while i < len(lines) and len(paths) < limit:
@@ -45,7 +46,9 @@ def tail_paths(lines, limit=64):
             if not t or t.startswith(".") and not t.endswith(":") or t.endswith(":"):
                 continue
             acc.append(t)
-            if re.fullmatch(r"s_waitcnt vmcnt\(0\)", t) or t.startswith("s_endpgm"):
+            # the end of the tail: the wide kernel marks it (`s_nop 15` in front of its epilogue's first accumulator read, behind the drain); without the
+            # marker the first full drain.  (A drain INSIDE the tail -- hipcc's own wait for a scratch reload it placed there -- does not end the path.)
+            if (t == "s_nop 15" if has_marker else re.fullmatch(r"s_waitcnt vmcnt\(0\)", t)) or t.startswith("s_endpgm"):
                 paths.append(acc)
                 return
             m = re.match(r"s_cbranch_\w+ (\.LBB\d+_\d+)", t)
