@@ -546,6 +546,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # QQQ_BENCH_FORCE_DIST=1: take the N > 1 code path (process group, M-sharding, in-place all_gather_into_tensor on the side stream, --check) with whatever
+    # world size the launcher gave -- ONE rank on a 1-GPU box: how RCCL, the side-stream gather and the CU-capped GEMM beside it are smoke-tested before the 8-GPU run
+    is_multi = world > 1 or os.environ.get("QQQ_BENCH_FORCE_DIST", "0") == "1"
+    bench_sms = int(os.environ.get("QQQ_BENCH_SMS", "-1"))  # the reference's `sms` for the GEMMs of the sharded points (a CU cap: leaves CUs to RCCL's kernels); -1 = all
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
@@ -555,10 +559,14 @@ def main():
     dev = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     dist = None
-    if world > 1:
+    if is_multi:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:  # (the forced one-rank run needs no launcher)
+            os.environ.setdefault("MASTER_PORT", "29517")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         backend = os.environ.get("QQQ_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -576,7 +584,7 @@ def main():
     # (single GPU: step t binds sweep point j to weight copy (5 t + j) % NBUF -- inside a multi-step graph as well as eagerly --, so a copy is
     #  re-read only after the other NBUF - 1 have passed through the Infinity Cache: what `config.weights` says)
     step_no = [0]
-    if world == 1:
+    if not is_multi:
         def step_body(t=None):
             if t is None:
                 t = step_no[0]
@@ -592,7 +600,7 @@ def main():
                 Bj = layer.Bs[j % NBUF]
 
                 def gemm_fn(a_rows, s1_rows, d_rows, Bj=Bj):
-                    ops.qqq_gemm(a_rows, Bj, layer.C, d_rows, s1_rows, layer.s2, layer.s3, layer.ws, -1, -1, -1, MAX_PAR)
+                    ops.qqq_gemm(a_rows, Bj, layer.C, d_rows, s1_rows, layer.s2, layer.s3, layer.ws, -1, -1, bench_sms, MAX_PAR)
 
                 sg = ShardedGemm(gemm_fn, K=K_FULL)  # chunk count from the shard size and the layer (qqq_amd.parallel.pick_chunks)
                 spans = sg.spans(M, N_FULL)
@@ -612,7 +620,7 @@ def main():
     torch.cuda.synchronize()
     graph = None
     by_size, spg = {}, 1  # graphs holding 1, (K - 1) % spg and spg consecutive steps: fewer replay boundaries in the timed region
-    if world == 1:
+    if not is_multi:
         try:
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream())
@@ -655,7 +663,7 @@ def main():
     # capture that goes wrong inside the collective library can hang instead of raising, and no multi-GPU box was available to
     # try it on; the eager N = 1 figure (`eager`) is printed so that a 1 -> N curve can compare like with like either way.
     n_launch = "eager"
-    if world > 1 and os.environ.get("QQQ_BENCH_NGRAPH", "0") == "1" and os.environ.get("QQQ_BENCH_BACKEND", "nccl") == "nccl":
+    if is_multi and os.environ.get("QQQ_BENCH_NGRAPH", "0") == "1" and os.environ.get("QQQ_BENCH_BACKEND", "nccl") == "nccl":
         try:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
@@ -700,7 +708,7 @@ def main():
     dt = time.perf_counter() - t0
     # per-step spread, measured AFTER the timed region with stream events (diagnostic only; `value` uses `dt`)
     step_us = []
-    if world == 1:
+    if not is_multi:
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(args.steps, 50))]
         for a, b in evs:
             a.record()
@@ -709,7 +717,7 @@ def main():
         torch.cuda.synchronize()
         step_us = [a.elapsed_time(b) * 1e3 for a, b in evs]
     eager = None
-    if world == 1 and graph is not None:
+    if not is_multi and graph is not None:
         # the same K steps launched eagerly (Python loop, compiled binding): what an N > 1 run, whose step is eager, should be
         # compared with -- the graph figure above removes ~5 host calls per step that the N > 1 loop still pays
         for _ in range(3):
@@ -729,7 +737,7 @@ def main():
     # N > 1: where the step's time goes at the sharded points: GEMM-only, all-gather-only, overlapped total;
     # event-timed on the launch stream after the timed region, max over ranks
     multi = None
-    if world > 1:
+    if is_multi:
         multi = {}
         for j, M in enumerate(SWEEP_M):
             if M not in sharded:
@@ -756,7 +764,7 @@ def main():
             res["rows_per_rank"] = -(-M // world)
             multi[str(M)] = res
 
-    if args.check and world > 1:
+    if args.check and is_multi:
         for j, M in enumerate(SWEEP_M):
             if M in sharded:
                 A, s1 = toks[M]
@@ -785,11 +793,11 @@ def main():
             "tokens": "x ~ N(0,1) fp16 through the fused dynamic int8 quantiser",
             "launch": (f"hipGraph replay: a one-step graph opens the timed region, then {spg} step(s) per graph (step t of a graph binds sweep point j to weight copy "
                        f"(5 t + j) % {NBUF}: a copy is re-read only after the other {NBUF - 1}, {(NBUF - 1) * 89} MB, have passed through the 256 MiB Infinity Cache)"
-                       if world == 1 else "hipGraph replay, one step per graph (each sweep point bound to one of the weight copies)") if graph is not None else "eager",
+                       if not is_multi else "hipGraph replay, one step per graph (each sweep point bound to one of the weight copies)") if graph is not None else "eager",
             "weights_short": f"{NBUF} rotating 89 MB int4 buffers (cold Infinity Cache), " + ("GPTQ-style N(0,0.02^2)" if os.environ.get("QQQ_BENCH_WEIGHTS", "gptq") != "uniform" else "uniform int4 codes"),
-            "launch_short": (f"hipGraph replay, 1-step opener then {spg} steps/graph" if graph is not None and world == 1 else n_launch),
-            "parallelism_short": "single GPU" if world == 1 else f"M-sharded over {world} GPUs + RCCL all-gather (M >= {64*world})",
-            "parallelism": "single GPU" if world == 1 else f"M-sharded over {world} GPUs + RCCL all-gather of fp16 shards (points with M >= {64*world}); step launch: {n_launch}",
+            "launch_short": (f"hipGraph replay, 1-step opener then {spg} steps/graph" if graph is not None and not is_multi else n_launch),
+            "parallelism_short": "single GPU" if not is_multi else f"M-sharded over {world} GPUs + RCCL all-gather (M >= {64*world})",
+            "parallelism": "single GPU" if not is_multi else f"M-sharded over {world} GPUs + RCCL all-gather of fp16 shards (points with M >= {64*world}); step launch: {n_launch}",
         },
     }
 
@@ -808,7 +816,7 @@ def main():
     if step_us:
         result["step_us"] = {"min": float(np.min(step_us)), "median": float(np.median(step_us)), "max": float(np.max(step_us)),
                              "n": len(step_us), "note": "event-timed replays after the timed region"}
-    if rank == 0 and world == 1:
+    if rank == 0 and not is_multi:
         # ---- per-point detail, HIP event pairs around every launch (cold = rotating weights) ----
         per_m = {}
         it = args.detail_iters

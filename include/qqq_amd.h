@@ -9,7 +9,12 @@
  * `stream` (a hipStream_t passed as void*; NULL = the legacy default stream) and returns without
  * synchronising -- the same contract as the reference (csrc/qqq_gemm.cu:1089).
  * The library allocates no device memory, frees nothing and keeps no state between calls (reference ownership rules:
- * qlinear_marlin.py:97-133) -- except one CU-masked stream + two events per (device, sms) once a caller passes an `sms` cap.
+ * qlinear_marlin.py:97-133) -- except one CU-masked stream + two events per (device, sms, caller stream) once a caller passes an `sms` cap.
+ *
+ * ABI history.  2: tune fields glds .. split_m.  3: tune.skew; stream tune.fused = 3 changed meaning -- it WAS the in-launch fold over write-through slabs, it IS the
+ * arrival-order slot protocol (the last arrival keeps its tile in LDS and adds the others' slots; early ticket, uneven slices by `skew`); measured level with slabs + reduce
+ * launch (22.2 vs 21.8 us at 16 tokens), reachable through tune only.  4 (round 6): tune.w8, tune.fused bit 64, qqq_expand_int8 / qqq_w4a8_gemm_ex2 /
+ * qqq_quantlinear_forward2 (the opt-in load-time int8 expansion of a layer); the `sms` CU mask laid out as measured.
  */
 #ifndef QQQ_AMD_H_
 #define QQQ_AMD_H_
@@ -46,7 +51,8 @@ extern "C" {
  *       are validated exactly like the reference (is_valid_config, .cu:867-897; CALL_IF table
  *       :935-945) so the same calls fail with the same code, but they do not select CDNA4 tiles;
  *       sms (reference: the number of persistent threadblocks, -1 = every SM; csrc/qqq_gemm.cu:998) is a CU cap: with 0 < sms < the device's
- *       CU count the call's kernels run on a library-owned CU-masked stream (sms CUs, spread over the XCDs) forked from / joined into `stream`
+ *       CU count the call's kernels run on a library-owned CU-masked stream (max(sms, 8) CUs, spread evenly over the XCDs: mask bit i is a CU of
+ *       XCD i % 8, an XCD without a bit is not restricted) forked from / joined into `stream`; not while `stream` is being captured
  *       (INTEGRATION.md 3); max_par bounds the rows of C that may be used (max_par*64).
  * D[i,j] = fp16_rn( (f32_rn(sum_k A[i,k]*Wq[k,j]) * s2[j]) * s1[i] ), Wq as the reference kernel
  * forms it (csrc/qqq_gemm.cu:146-151, :167-210, :695-700).  int32 accumulators are bit-exact.
@@ -78,9 +84,9 @@ typedef struct qqq_tune {
                   16 = wide: never keep a deposit in the XCD's L2 (as shipped, slices of a tile that find each other on one
                   XCD do: DESIGN.md 3.4.2), 32 = panel: plain grid order (as shipped the grid of a split K is walked so
                   that the slices of a tile run on ONE XCD whatever the number of strips), 64 = wide, two K slices of
-                  256-column tiles: in: never the exchange hand-off (as shipped each slice deposits the row half the other one
-                  finishes and finishes its own, even slices; with the bit: one slice deposits everything, the other folds, uneven
-                  slices); out (qqq_w4a8_plan): set when the plan exchanges                                          */
+                  256-column tiles: the EXCHANGE hand-off (each slice deposits the row half the other one finishes and finishes
+                  its own, even slices; as shipped one slice deposits everything and the other folds, uneven slices -- the two
+                  measure level); out (qqq_w4a8_plan): set when the plan exchanges                                   */
   int bm;      /* tiled: rows per workgroup tile (64, 128, 256); panel: COLUMNS per workgroup (128, 256); wide: COLUMNS per
                   workgroup (256; 128 with mt = 16 only: 32 columns per wave); 0 auto */
   int glds;    /* tiled: 1 = direct global->LDS loads, 2 = register staged; 0 auto.
@@ -107,7 +113,7 @@ typedef struct qqq_tune {
                   instead of waiting a hand-off latency for them (arrival order still decides who folds: a matter of time, never of
                   correctness).  in: -1 = even slices, 0 = automatic, 1..63 stages.  out (qqq_w4a8_plan): the stages used.  ABI 3.
                   stream (fused = 3): the same in 64-k steps (1..255). */
-  int w8;      /* per-group, wide kernel: the expanded int8 weights of qqq_expand_int8 (ABI 4).  in (qqq_w4a8_gemm_ex2): 0 = use them where the call has
+  int w8;      /* wide kernel: the layer's expanded int8 weights of qqq_expand_int8 (ABI 4).  in (qqq_w4a8_gemm_ex2): 0 = use them where the call has
                   them and the plan is the wide kernel's, -1 = ignore them (A/B timing); in (qqq_w4a8_plan): 1 = plan for a call that has them.
                   out (qqq_w4a8_plan): 1 = the planned loop reads the expanded weights. */
 } qqq_tune_t;
@@ -122,7 +128,7 @@ int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, const void*
                      int max_par, const qqq_tune_t* tune, int32_t* acc_out, const void* bias);
 
 /*
- * Opt-in load-time re-layout for per-group layers (sits beside QuantLinear.pack, qlinear_marlin.py:181-262; default OFF: nothing changes
+ * Opt-in load-time re-layout of a layer (sits beside QuantLinear.pack, qlinear_marlin.py:181-262; default OFF: nothing changes
  * for a caller that never calls it, and the packed int4 tensor B stays the layer's checkpoint format).
  * A per-group weight is a pure function of (B, s_group): qqq_expand_int8 runs the reference's in-loop re-quantisation (dequant_per_group,
  * csrc/qqq_gemm.cu:167-210: w8 = low byte of fp16((u - 8) * s + 1152) ^ 0x80, bit for bit, wrap region included) ONCE per weight and stores the int8
@@ -131,8 +137,9 @@ int qqq_w4a8_gemm_ex(const void* A, const void* B, void* C, void* D, const void*
  * (k * n bytes, device memory owned by the caller -- twice the packed tensor; B is still needed: small-m calls keep reading it).
  * qqq_w4a8_gemm_ex2 is qqq_w4a8_gemm_ex with that tensor as a last argument (NULL = none): where the plan of a per-group call is the wide kernel's
  * (MFMA-bound calls, from a few hundred tokens up) its loop reads W8 -- no transpose, no re-quantiser, no group scales: the per-channel loop minus its
- * unpack -- and produces the SAME int32 accumulators and the same D bit for bit; everywhere else W8 is ignored.  groupsize must be 128, k % 128 == 0,
- * n % 64 == 0, k * n < 4 GiB; both enqueue on `stream` and return.
+ * unpack -- and produces the SAME int32 accumulators and the same D bit for bit; everywhere else W8 is ignored.  groupsize 128, or -1: a per-channel
+ * layer expands the same way (the operand `q & 0xF0F0F0F0` / `(q << 4) & 0xF0F0F0F0` = 16 w4 of csrc/qqq_gemm.cu:146-151 as int8; s3 is not read) and
+ * measures level with its packed form -- its loop hides the unpack; k % 128 == 0, n % 64 == 0, k * n < 4 GiB; both enqueue on `stream` and return.
  */
 int qqq_expand_int8(const void* B, const void* s3, void* W8, int k, int n, int groupsize, int dev, void* stream);
 int qqq_w4a8_gemm_ex2(const void* A, const void* B, void* C, void* D, const void* s1, const void* s2,

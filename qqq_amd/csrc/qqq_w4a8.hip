@@ -437,8 +437,9 @@ static int device_cus_of(int dev) {
   return n;
 }
 // The CU count plans and launches of THIS call work with: qqq_w4a8_gemm_ex sets it from the device it was given (capped by the
-// reference's `sms` argument) before it plans, so the plan and the launch grid can never disagree; qqq_w4a8_plan -- pure host
-// logic, no HIP call -- plans for the MI355X's 256 (the persistent tile walk launches one workgroup per CU).
+// reference's `sms` argument) before it plans, so the plan and the launch grid can never disagree -- the cost models' rounds of
+// workgroups, the K splits that fill one round and the tile walk's grid all read it (round 6; ADVICE round 5: a capped call used to be
+// planned for a full chip); qqq_w4a8_plan -- pure host logic, no HIP call -- plans for the MI355X's 256.
 static thread_local int t_call_cus = 256;
 static int device_cus() { return t_call_cus; }
 struct CallCus {
@@ -580,11 +581,11 @@ static double tiled_estimate(int M, int N, int K, bool grouped, bool have_scratc
 //   per-group: bound by the re-quantiser -- g1 per 1000 k per round, flat up to 16 tokens, g2 for the second 16-token tile (growing as ((m - 16) / 16)^0.75) -- + the weights;
 //   stream: a + b weight passes at 5 TB/s up to 16 tokens, a + c (m - 24) / 16 + b passes from 17; per mode.
 static double column_small_estimate(int M, int N, int K, bool grouped) {
-  const int wgs = N / 32, rounds = (wgs + 255) / 256;
+  const int wgs = N / 32, rounds = (wgs + device_cus() - 1) / device_cus();  // (CUs of THIS call: the device's, or the `sms` cap)
   const double mb = (double)N * K / 2.0e6;
   if (!grouped) {
     const double* c = kQqqSmall.col_pc;
-    const double idle = wgs < 256 ? 1.0 - wgs / 256.0 : 0.0;
+    const double idle = wgs < device_cus() ? 1.0 - wgs / (double)device_cus() : 0.0;
     return c[0] + c[1] * mb + c[2] * 1e-6 * (double)K * M * rounds + c[3] * 1e-3 * K * idle;
   }
   const double* g = kQqqSmall.col_g;
@@ -602,8 +603,8 @@ static double stream_small_estimate(int M, int N, int K, bool grouped) {
   // per-group a slice is also bound by its re-quantiser: 9.7 us + 2.1 us per 1000 k of the slice -- what a wide layer's unsplit strips pay
   // (N = 20480, K = 7168: 24.9 us against the column kernel's 21.1; profiles/r04_stream_ksplit_wide_n.txt).  The K split as make_plan picks it:
   const long long base = (long long)((N + 127) / 128) * (M <= 16 ? 1 : (M + 31) / 32);
-  int ks = (int)((256 + base / 2) / base);
-  if (ks > 1 && base * ks > 256) --ks;
+  int ks = (int)((device_cus() + base / 2) / base);
+  if (ks > 1 && base * ks > device_cus()) --ks;
   if (M <= 16 && base >= 128) ks = 1;
   const int cap = K / 64 / (M <= 16 ? 8 : 16);
   if (ks > cap) ks = cap;
@@ -627,7 +628,7 @@ static double stream_mid_estimate(int M, int N, int K, bool grouped, int ks_cap,
   const double* c = kQqqSmall.stmid[grouped ? 1 : 0];
   for (int ks = 1; ks <= 8 && ks <= ks_cap; ++ks) {
     if (ks > 1 && KS / ks < 8) break;  // (8-wave bodies: at least a step per wave)
-    const double rounds = (double)((base * ks + 255) / 256);
+    const double rounds = (double)((base * ks + device_cus() - 1) / device_cus());
     const double steps = rounds * (rounds > 1.0 ? 1.2 : 1.0) * KS / ks, slab_mb = (double)M * N * 4.0 * ks / 1.0e6;
     const double rule = 8.65 + 0.153 * (grouped ? 1.235 : 1.0) * steps + (ks > 1 ? 2.0 + 0.4 * slab_mb : 0.0);
     if (rule < best_rule) {
@@ -658,7 +659,7 @@ static double stream_estimate(int M, int N, int K, bool grouped, bool have_scrat
   // per pass; 2 blocks: 16.3 / 18.9 / 43.5; profiles/r02_dispatch_check_handoff.txt); more than 256 workgroups even unsplit
   // (n = 11008: 86 strips x 3) is a second round
   double us = ((mblocks == 2 || mblocks == 3) ? 10.6 : 9.0 + 2.0 * mblocks) + per_block * passes;
-  if ((long long)((N + 127) / 128) * mblocks > 256) us *= 1.35;
+  if ((long long)((N + 127) / 128) * mblocks > device_cus()) us *= 1.35;
   if (mblocks == 1 && M > 32) {
     // 33 ... 64 tokens: per token count a line in the weight bytes (no floor: the 8 MB layers sit ON the line), with a step where the fourth 16-token tile
     // starts (49 tokens); one form per mode, coefficients generated (qqq_rates.h, kQqqSmall.st64: 68 points per mode, 3 % mean error)
@@ -691,7 +692,7 @@ static double panel_estimate(int M, int N, int K, bool grouped, bool have_scratc
     const long long tl = mblocks * ((N + bn - 1) / bn);
     for (int ks = 1; ks <= 4; ++ks) {
       if (ks > 1 && (!have_scratch || 2 * tl > cap_tickets || tl * rows * bn * (ks - 1) > cap_rows * (long long)N || ks > NST / 4)) break;  // slots: tiles x (ks-1) x rows x bn ints inside C
-      const double rounds = (double)((tl * ks + 255) / 256);
+      const double rounds = (double)((tl * ks + device_cus() - 1) / device_cus());
       const double us = rounds * (r.a + (ks > 1 ? r.c : 0.0) + (ks > 2 ? r.d * (ks - 2) : 0.0) + r.b * (double)NST / ks);
       if (us < best) {
         best = us;
@@ -710,7 +711,7 @@ static double panel_estimate(int M, int N, int K, bool grouped, bool have_scratc
   if (mt == 8 && mt_out) {
     const long long mb4 = (M + 63) / 64, tl = mb4 * ((N + 127) / 128);
     for (int ks = 1; ks <= 4; ++ks) {
-      if (tl * ks > 256) break;
+      if (tl * ks > device_cus()) break;
       if (ks > 1 && (!have_scratch || 2 * tl > cap_tickets || tl * 64 * 128 * (ks - 1) > cap_rows * (long long)N || ks > NST / 4)) break;
       // (rates GENERATED -- qqq_rates.h, kQqqSmall.panel64, tools/fit_rates.py: the single-round points of the column panel64 in profiles/r05_dispatch_check_*.txt,
       //  165 per mode, 2.5 - 2.7 % mean error: launch + fill + epilogue unsplit / split, us per stage, every further m-block a share of a weight pass at bw MB/us)
@@ -768,8 +769,8 @@ static double wide_estimate(int M, int N, int K, bool grouped, bool have_scratch
       // rounds: workgroups of later rounds start as CUs free up, but the XCDs' queues drain unevenly -- close to the ceiling of
       // the ratio (288-344 tiles measured 1.7-1.8 rounds, 688 tiles 2.8-3).  A partly filled single round runs each tile
       // faster: the part is power-limited (half the CUs busy: 0.8 of the full-chip stage time, 0.85 per-group; then quadratic)
-      const double x = (double)(tl * ks) / 256.0;
-      const double cx = (double)((tl * ks + 255) / 256);
+      const double x = (double)(tl * ks) / (double)device_cus();
+      const double cx = (double)((tl * ks + device_cus() - 1) / device_cus());
       const double rounds = x <= 1.0 ? 1.0 : cx - 0.3 * (cx - x);
       const double lo = grouped ? 0.85 : 0.80, rel = x <= 0.5 ? 0.0 : (x - 0.5) / 0.5;
       const double load = x <= 1.0 ? lo + (1.0 - lo) * rel * rel : 1.0;
@@ -960,8 +961,10 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
     pl.ksplit = ksplit;
     pl.fused = 1;
     pl.skew = 0;
-    // two slices of 256-column tiles: the exchange hand-off (qqq_wide.hip.h; tune.fused bit 64 = never, a forced skew = the classic fold with uneven slices)
-    pl.exch = (ksplit == 2 && pl.bm == 256 && t.skew <= 0 && !(t.fused & 64)) ? 1 : 0;
+    // two slices of 256-column tiles: the exchange hand-off (qqq_wide.hip.h) on request -- tune.fused bit 64.  Measured level with the classic fold over uneven
+    // slices or up to 2 % behind it (N = 8192, K = 21760 at 768 / 1024 tokens, both modes, and 4096 x 11008: profiles/r06_wide_exchange_handoff.txt): either way the
+    // tile's partial sums -- 33.5 MB chip-wide at 1024 tokens -- cross the fabric once out and once back at the chip's write bandwidth, which is what the hand-off costs.
+    pl.exch = (ksplit == 2 && pl.bm == 256 && t.skew <= 0 && (t.fused & 64)) ? 1 : 0;
     if (ksplit > 1 && !pl.exch) {  // uneven K slices (tune.skew: -1 never, 0 automatic, else stages): every slice keeps at least 4 stages
       int sk = t.skew > 0 ? t.skew : (t.skew == 0 ? wide_auto_skew(pl.mt, pl.bm, grouped, K / 128, ksplit, pl.w8 != 0) : 0);
       const int room = K / 128 - 4 * ksplit;
@@ -986,7 +989,7 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
     const long long mblocks = (M + rows - 1) / rows, strips = (N + bn - 1) / bn;
     const int NST = (K / 64 + 1) / 2;
     ksplit = t.ksplit;
-    if (ksplit <= 0) ksplit = clampi((int)(256 / (strips * mblocks)), 1, 4);  // never more than one round of workgroups
+    if (ksplit <= 0) ksplit = clampi((int)(device_cus() / (strips * mblocks)), 1, 4);  // never more than one round of workgroups (on the CUs this call may use)
     ksplit = clampi(ksplit, 1, NST / 4 > 0 ? NST / 4 : 1);
     if (!have_scratch || workspace == nullptr) ksplit = 1;
     if (ksplit > 1) {
@@ -1055,10 +1058,10 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
     if (ksplit <= 0) {
       // one workgroup per CU: (strips x m-blocks x K-slices) ~ 256, at least 2 steps per wave
       const long long base = (long long)strips * mblocks;
-      ksplit = (int)((256 + base / 2) / base);
+      ksplit = (int)((device_cus() + base / 2) / base);
       // a 257th workgroup is a second round (n = 11008: 86 strips x 3 slices) -- for the 4-wave bodies of <= 16 tokens as well (N = 7168, K = 20480:
       // 56 strips x 5 slices 25.5 us, x 4 slices 18.9; profiles/r04_stream_ksplit_wide_n.txt)
-      if (ksplit > 1 && base * ksplit > 256) --ksplit;
+      if (ksplit > 1 && base * ksplit > device_cus()) --ksplit;
       // up to 16 tokens (4-wave bodies): 128 workgroups or more already pull the weights at the HBM's pace, a second K slice only adds the reduce
       // launch (N = 18944, K = 3584 at 16 tokens: 10.9 us unsplit, 14.9 in two slices; N = 16384, K = 4096: 11.5 / 12.7; profiles/r04_stream_ksplit_wide_n.txt)
       if (mt == 1 && base >= 128) ksplit = 1;

@@ -862,7 +862,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // ---- steady state: P stages per iteration (ring slots and LDS buffers are compile-time), branch-free ----
   int i0 = 0;
   for (; i0 + P <= NST; i0 += P) {
-#ifdef QQQ_PANEL_TRACE
+#if defined(QQQ_PANEL_TRACE) && defined(QQQ_WIDE_TRACE_TRIPS)  // (perturbs the loop: an s_memtime per trip drains the LDS queue; without it the trace build's loop is the shipped one)
     if (i0 < 12 * P) QQQ_WTRV(4 + i0 / P, __builtin_amdgcn_s_memtime());  // shader clock at the top of the first 12 trips
 #endif
     qqq_static_for<P>([&](auto uc) __attribute__((always_inline)) { do_stage(i0 + decltype(uc)::value, uc); });
@@ -954,6 +954,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const unsigned word = (unsigned)__builtin_amdgcn_readfirstlane(*xch);
     arrival = (int)(word & 0xffu);
     exch = exch_on && (word & XB_EXCH) != 0;
+#ifndef QQQ_WIDE_TRACE_TRIPS
+    QQQ_WTR(4);                                   // split K: ticket taken
+    QQQ_WTRV(7, (arrival << 1) | (exch ? 1 : 0)); // ... arrival index, exchange decided
+#endif
     const size_t slot_ints = (size_t)ROWS * BN;
     if (exch || arrival < ksplit - 1) {
       // Same XCD for every slice of this tile, as far as the arrival word shows at MY arrival?  Then the deposit may stay in
@@ -990,6 +994,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();  // every wave's part of the deposit is where the finisher will look for it
       if (tid == 0) qqq_publish_add(tk + 1, hflags);
+#ifndef QQQ_WIDE_TRACE_TRIPS
+      QQQ_WTR(5);                                 // deposit drained and published
+#endif
       if (!exch) return;
     }
   }
@@ -1078,6 +1085,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
     }
     __syncthreads();
+#ifndef QQQ_WIDE_TRACE_TRIPS
+    if (pass == first_pass && fold) QQQ_WTR(6);   // the deposits this workgroup folds are complete
+#endif
     if (pass == first_pass && fold && qqq_formal_acquire(hflags)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (off by default: qqq_common.hip.h)
     if (pass == first_pass) {  // (the pin: behind the first image's LDS writes, which cover the loads' round trip)
 #pragma unroll

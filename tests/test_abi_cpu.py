@@ -395,14 +395,14 @@ def test_uneven_k_slices_in_the_plan():
         assert sum(lens) == nst and min(lens) >= 4 and lens[-1] - max(lens[:-1]) in (skew, skew - 1, skew + 1), (nst, ks, skew, lens)
     # the wide kernel's two-slice split takes the same knob: 256 KiB deposits, ~20 us from last MFMA to "complete" -> 6 stages per-group at 1024 tokens
     # (173.1 -> 165.9 us, profiles/r05_uneven_k_slices_wide.txt), 7 for the 256 x 128 tiles per-channel at 384 / 512 tokens
-    # (round 6: two slices of 256-column tiles EXCHANGE row halves -- even slices, plan field fused carries bit 64 --; tune.fused bit 64 asks for the classic fold)
     p = _lib.plan(1024, N, K, 128, 16)
-    assert (p["kernel"], p["ksplit"], p["skew"], p["fused"] & 64) == (5, 2, 0, 64), p
-    p = _lib.plan(1024, N, K, 128, 16, tune=dict(fused=64))
     assert (p["kernel"], p["ksplit"], p["skew"], p["fused"] & 64) == (5, 2, 6, 0), p
-    p = _lib.plan(1024, N, K, 128, 16, tune=dict(skew=5))   # a pinned skew is the classic fold with uneven slices
+    # (round 6: tune.fused bit 64 = two slices of 256-column tiles EXCHANGE row halves -- even slices, the plan's fused field carries the bit; measured level, not the default)
+    p = _lib.plan(1024, N, K, 128, 16, tune=dict(fused=64))
+    assert (p["kernel"], p["ksplit"], p["skew"], p["fused"] & 64) == (5, 2, 0, 64), p
+    p = _lib.plan(1024, N, K, 128, 16, tune=dict(skew=5, fused=64))   # a pinned skew is the classic fold with uneven slices
     assert (p["skew"], p["fused"] & 64) == (5, 0), p
-    assert _lib.plan(1024, N, K, 128, 16, tune=dict(skew=-1))["skew"] == 0
+    assert _lib.plan(1024, N, K, 128, 16, tune=dict(skew=5))["skew"] == 5 and _lib.plan(1024, N, K, 128, 16, tune=dict(skew=-1))["skew"] == 0
     p = _lib.plan(512, N, K, -1, 16)
     assert (p["kernel"], p["bm"], p["ksplit"], p["skew"]) == (5, 128, 2, 7), p
 

@@ -57,3 +57,33 @@ def test_bench_two_ranks_rccl_when_two_gpus():
     p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
     assert "identical to local full GEMMs" in p.stderr
+
+
+@pytest.mark.parametrize("extra", [{}, {"QQQ_BENCH_NGRAPH": "1"}, {"QQQ_BENCH_SMS": "224"}], ids=["eager", "hipgraph", "sms224"])
+def test_bench_one_rank_rccl_through_the_sharded_path(dev, extra):
+    """ONE rank over RCCL (torch "nccl") through bench.py's N > 1 code path (QQQ_BENCH_FORCE_DIST=1): process group on a 1-GPU box, the
+    M-sharded GEMM, the in-place all_gather_into_tensor on the side stream, --check -- eagerly, captured into a hipGraph (QQQ_BENCH_NGRAPH=1)
+    and with the GEMMs capped to 224 CUs on the library's CU-masked stream beside RCCL's stream (QQQ_BENCH_SMS) -- so that the driver's
+    8-GPU run is not the first time RCCL, the capture and the masked stream meet this code.  No curve: a smoke."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, QQQ_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", **extra)
+    env.pop("QQQ_BENCH_BACKEND", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu", "--no-fp16", "--check"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert "identical to local full GEMMs" in p.stderr
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 1 and out["value"] > 0
+    mg = out["multi_gpu"]
+    assert mg["world_seen"] == 1 and mg["backend"].startswith("nccl")
+    assert all(mg["4096"][k] > 0 for k in ("gemm_only_us", "allgather_only_us", "overlapped_us"))
+    if "QQQ_BENCH_NGRAPH" in extra:
+        assert "hipGraph" in mg["launch"], mg["launch"]   # the capture of the collective really held
+    else:
+        assert mg["launch"] == "eager"
+    assert len(line) < 4000

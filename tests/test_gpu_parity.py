@@ -453,9 +453,9 @@ def test_wide_inlaunch_splitk_stress_two_streams(dev, hand):
     """The wide kernel's ticket / slot hand-off under load (row-major partial tiles written through to C, folded by the last
     arrival with agent-scope loads, no acquire fence): three layers with their own scratch hammered from two streams, both tile
     heights, 2-3 K slices, ragged m; every result equal to the unsplit stream kernel's bit for bit, workspaces all-zero after.
-    Round 6: two slices of 256-column tiles EXCHANGE row halves by default (the first arrival decides from the partner's started
-    bit; under this load some pairs fall back to the classic fold), fused = 65 forces the classic protocol; the third layer is
-    per-group with expanded int8 weights (the loop that reads them has the same epilogue)."""
+    Round 6: with fused bit 64 two slices of 256-column tiles EXCHANGE row halves (the first arrival decides from the partner's
+    started bit; under this load some pairs fall back to the classic fold); the third layer is per-group with expanded int8
+    weights (the loop that reads them has the same epilogue)."""
     from qqq_amd import pack as P
 
     g = torch.Generator(device="cpu").manual_seed(321)

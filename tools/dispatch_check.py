@@ -15,10 +15,11 @@ modes = os.environ.get("MODES", "pc,g128").split(",")
 iters = int(os.environ.get("ITERS", "10"))
 for (N, K) in shapes:
     for mode in modes:
-        grouped = mode == "g128"
+        grouped = mode.startswith("g128")
+        expand = mode == "g128x"  # per-group with the opt-in expanded int8 weights (every weight copy expanded; every variant's calls get them)
         # enough weight copies that a rotation is longer (1.1 GB) than what the 256 MB Infinity Cache can hold: below ~64 tokens a launch is one pass over the weights,
         # and with the 4 / 12 copies of rounds 2-4 the plain-load kernels were partly served from that cache (profiles/r05_nt_weight_loads.txt)
-        layer = Bn.Layer(dev, grouped=grouped, nbuf=Bn.copies_for(N, K) if min(Ms) <= 128 else (4 if N * K > 6e7 else 12), N=N, K=K)
+        layer = Bn.Layer(dev, grouped=grouped, nbuf=Bn.copies_for(N, K) if min(Ms) <= 128 else (4 if N * K > 6e7 else 12), N=N, K=K, expand=expand)
         for M in Ms:
             A, s1 = Bn.make_tokens(dev, M, M, K=K)
             D = torch.empty((M, N), dtype=torch.float16, device=dev)
@@ -45,14 +46,14 @@ for (N, K) in shapes:
                 random.Random(hash((N, K, M, grouped, r)) & 0xffffffff).shuffle(order)
                 for k, tune in order:
                     samples[k].extend(layer.time_calls(A, s1, D, max(2, iters // 3), tune=tune) * 1e3)
-            p = _lib.plan(M, N, K, 128 if grouped else -1, 16)
+            p = _lib.plan(M, N, K, 128 if grouped else -1, 16, tune=dict(w8=1) if expand else None)
             res = {k: float(np.median(v)) for k, v in samples.items()}
             for k in ("column", "stream", "tiled", "panel", "panel256", "panel256x2", "panel64", "wide"):
                 res.setdefault(k, float("nan"))
             best = min((v, k) for k, v in res.items() if v == v and k != "auto")
             flag = "" if res["auto"] <= best[0] * 1.03 else f"   <-- {best[1]} is {100 * (res['auto'] / best[0] - 1):.0f}% faster"
             extra = "".join(f" {k} {res[k]:7.1f}" for k in ("w16x2", "w8", "w128", "w128x2", "walk", "plain") if k in res)
-            print(f"N={N:5d} K={K:5d} {mode:4s} M={M:4d}  auto(k{p['kernel']},ks{p['ksplit']}{',walk' if p['kernel'] == 5 and p['glds'] == 2 else ''}{',split@' + str(p['split_m']) if p.get('split_m') else ''}) {res['auto']:7.1f} | column {res['column']:7.1f} stream {res['stream']:7.1f} tiled {res['tiled']:7.1f} panel {res['panel']:7.1f} panel256 {res['panel256']:7.1f} panel256x2 {res['panel256x2']:7.1f} panel64 {res['panel64']:7.1f} wide {res['wide']:7.1f}{extra}{flag}")
+            print(f"N={N:5d} K={K:5d} {mode:5s} M={M:4d}  auto(k{p['kernel']},ks{p['ksplit']}{',walk' if p['kernel'] == 5 and p['glds'] == 2 else ''}{',split@' + str(p['split_m']) if p.get('split_m') else ''}) {res['auto']:7.1f} | column {res['column']:7.1f} stream {res['stream']:7.1f} tiled {res['tiled']:7.1f} panel {res['panel']:7.1f} panel256 {res['panel256']:7.1f} panel256x2 {res['panel256x2']:7.1f} panel64 {res['panel64']:7.1f} wide {res['wide']:7.1f}{extra}{flag}")
             sys.stdout.flush()
         del layer
         torch.cuda.empty_cache()

@@ -18,4 +18,6 @@ bash tools/pmc_kernel.sh stream_m16 16 pc '{}' > /dev/null 2>&1
 bash tools/pmc_kernel.sh column_m1 1 pc '{}' > /dev/null 2>&1
 bash tools/pmc_kernel.sh wide_m4096_g128 4096 g128 '{}' > /dev/null 2>&1
 bash tools/pmc_kernel.sh wide_m1024_g128 1024 g128 '{}' > /dev/null 2>&1
-for t in wide_m4096 wide_m1024 panel_m128 stream_m16 column_m1 wide_m4096_g128 wide_m1024_g128; do echo "#### $t"; cat gpurun_out/pmc_$t/summary.txt; done
+bash tools/pmc_kernel.sh wide_m4096_g128x 4096 g128x '{}' > /dev/null 2>&1
+bash tools/pmc_kernel.sh wide_m1024_g128x 1024 g128x '{}' > /dev/null 2>&1
+for t in wide_m4096 wide_m1024 panel_m128 stream_m16 column_m1 wide_m4096_g128 wide_m1024_g128 wide_m4096_g128x wide_m1024_g128x; do echo "#### $t"; cat gpurun_out/pmc_$t/summary.txt; done

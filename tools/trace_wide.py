@@ -46,8 +46,24 @@ for M in [int(x) for x in os.environ.get("MS", "4096").split(",")]:
         print(f"      prologue            {q(us[sel, 1] - us[sel, 0])}")
         print(f"      main loop           {q(us[sel, 2] - us[sel, 1])}   per 128-k stage {np.median(us[sel, 2] - us[sel, 1]) / ((KK // 64 + 1) // 2):.3f}")
         print(f"      epilogue            {q(us[sel, 3] - us[sel, 2])}")
+    if pl["ksplit"] > 1 and (t[:, 4] != 0).any():  # split K (plain trace build): ticket / deposit published / deposits complete, per role
+        u = (t[:, :7] - T0) / 100.0
+        arr, ex = t[:, 7] >> 1, t[:, 7] & 1
+        print(f"   split K: {int(ex.sum())} of {nwg} workgroups exchange; per role, us after the first entry (min / median / max)")
+        for name, sel in (("depositors (classic)", (ex == 0) & (arr < pl['ksplit'] - 1)), ("finishers (classic)", (ex == 0) & (arr == pl['ksplit'] - 1)), ("exchanging", ex == 1)):
+            if sel.sum() == 0:
+                continue
+            print(f"      {name}: {int(sel.sum())}")
+            print(f"         loop end          {q(u[sel, 2])}")
+            print(f"         ticket - loop end {q(u[sel, 4] - u[sel, 2])}")
+            if (t[sel, 5] != 0).any():
+                print(f"         deposit published - ticket   {q(u[sel, 5] - u[sel, 4])}")
+            if (t[sel, 6] != 0).any():
+                print(f"         deposits complete - ticket   {q(u[sel, 6] - u[sel, 4])}")
+                print(f"         end - deposits complete      {q(u[sel, 3] - u[sel, 6])}")
+            print(f"         end - loop end    {q(u[sel, 3] - u[sel, 2])}")
     trips = np.diff(t[:, 4:16], axis=1).astype(np.float64)
-    ok = (t[:, 4:16] != 0).all(axis=1)
+    ok = (t[:, 4:16] != 0).all(axis=1) & (pl["ksplit"] == 1)
     if ok.any():
         print(f"   shader clocks per 3-stage trip (384 MFMAs x 16 = 6144 matrix-pipe clocks), trips 1..11: median over workgroups " + " ".join(f"{np.median(trips[ok, j]):.0f}" for j in range(trips.shape[1])))
         print(f"      min over workgroups " + " ".join(f"{np.min(trips[ok, j]):.0f}" for j in range(trips.shape[1])))
