@@ -1341,6 +1341,7 @@ extern "C" int qqq_w4a8_gemm_ex2(const void* A, const void* B, void* C, void* D,
   a.skew = pl.skew;
   a.hflags = (pl.kernel == 2 || pl.kernel == 4 || pl.kernel == 5) ? ((t.fused >> 2) & (pl.kernel == 4 ? 15 : 7)) : 0;  // (panel: bit 3 = plain grid order, the slices of a tile NOT gathered on one XCD)
   if (pl.kernel == 5 && pl.exch) a.hflags |= 8;  // (wide: bit 3 = exchange hand-off of a two-slice split)
+  if (pl.kernel == 5 && (t.fused & 128)) a.hflags |= 16;  // (wide, measurement: the two slices of a tile on neighbouring XCDs)
 
   DeviceGuard guard(dev);
   hipError_t e = hipSuccess;

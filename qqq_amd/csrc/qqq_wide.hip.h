@@ -77,6 +77,12 @@ __device__ __forceinline__ v4u wide_load16(__amdgpu_buffer_rsrc_t view, const un
 #ifndef QQQ_WIDE_FLUSH_AUX
 #define QQQ_WIDE_FLUSH_AUX 0  // cache policy of the tile walk's D stores (buffer aux bits: 1 sc0, 2 nt, 16 sc1); measurement builds set it
 #endif
+// QQQ_WIDE_STAGGER = d > 0 (round 6): the four waves of a workgroup run d issue slots apart instead of in lock step.  Wave w takes the stage barrier d (3 - w)
+// slots INTO the next stage (wave 3 in front of its first MFMA, wave 0 behind its 3 d-th): all four meet at the same moment, so wave w runs d (3 - w) slots
+// ahead of wave 3 from then on -- and no two waves hand the LDS / the vector-memory unit the same instruction in the same cycle.  0: one common barrier.
+#ifndef QQQ_WIDE_STAGGER
+#define QQQ_WIDE_STAGGER 0
+#endif
 #ifndef QQQ_WIDE_SLOTMAP
 #define QQQ_WIDE_SLOTMAP 5  // bit 0: per-channel, bit 1: per-group, bit 2: the 128-token shape too
 #endif
@@ -99,6 +105,123 @@ __host__ __device__ constexpr int wide_item_slots_before(int hw, int k) {  // nu
   for (int j = 0; j < k; ++j) n += wide_item_slot(hw, j) ? 1 : 0;
   return n;
 }
+
+// QQQ_WIDE_BALANCE (round 6): the issue model of a wave that is alone on its SIMD, measured (tools/mfma_issue_bench.hip, profiles/r06_mfma_issue_model.txt): every
+// instruction -- VALU, SALU, s_nop, a wait that does not block -- takes the wave ~5.2 cycles of issue; behind a 16-cycle MFMA TWO of them are free, the third costs its
+// full 4 - 5 cycles, and an empty slot gives nothing back (3 VALU behind every other MFMA: 18.5 cycles per MFMA, 1.5 behind every one: 16.5).  A ds_read_b128 takes ~12
+// cycles (alone in a slot: free; with two VALU next to it: + 13), an LDS-DMA ~17 (+ 6 whatever shares its slot).  The quad transpose's pieces were 3-instruction blocks
+// (s_mov_b64 vcc + two DPP selects; with hipcc's hazard s_nop and the ring wait in front: 4 - 5 instructions in ONE slot, eight times per 64-k step).  So: every unpack
+// item is ONE instruction (the transpose's thirteen per half: the ring wait, then per piece the VCC write and its two selects, in order -- nothing else in the loop writes
+// VCC, tests/test_code_object_cpu.py checks the compiled code), and the items are dealt to the slots by CAPACITY: 0 where the slot already carries a fragment re-read, an
+// LDS-DMA or a ring refill, 1 next to the DMA's M0 write, 2 elsewhere (scaled up together where a shape has more items than that: per-group, 128-token and 128-column tiles).
+#ifndef QQQ_WIDE_BALANCE
+#define QQQ_WIDE_BALANCE 1
+#endif
+// QQQ_WIDE_CURSORS (round 6): the plain kernel's loop loads read through running scalar offsets (one s_add per load kind and stage, as the tile walk's cursors) instead
+// of offsets worked out per step from the stage index with a clamp (s_add, s_min, s_add, s_mul in ONE issue slot, three times per stage).  The clamp ("past the end of
+// the K slice: re-read its last stage") goes: the descriptors END where their tensors end, so a load past the end of K is either the next slice's / next row's data
+// (in range, never used) or out of range for the buffer unit (returns zeros, never used).
+#ifndef QQQ_WIDE_CURSORS
+#define QQQ_WIDE_CURSORS 1
+#endif
+// Fixed duties that sit in the slot schedule next to the loads (BALANCE): the stage-end wait + barrier (step parity 1) and, with running cursors (QQQ_WIDE_CURSORS),
+// one scalar add per load kind -- each in a slot of its own choosing, its capacity reduced accordingly.
+__host__ __device__ constexpr int wide_w8_refill_index_(int mt, int hw, int k) { return k % ((2 * hw * mt) / (2 * hw)) == 2 ? k / ((2 * hw * mt) / (2 * hw)) : -1; }
+__host__ __device__ constexpr bool wide_plain_slot(int mode, int mt, int hw, int k) {  // no load, no fragment re-read, no M0 write in this slot
+  if (k < 0 || k >= 2 * hw * mt) return false;
+  if (wide_frag_slot(hw, k) || wide_dma_slot(mt, hw, k) || wide_m0_slot(mt, hw, k)) return false;
+  if (mode == 2 ? wide_w8_refill_index_(mt, hw, k) >= 0 : (wide_refill_slot(hw, k, 0) || wide_refill_slot(hw, k, 1))) return false;
+  if (mode == 1 && k == wide_scale_slot(hw)) return false;
+  return true;
+}
+__host__ __device__ constexpr int wide_barrier_slot(int mode, int mt, int hw) {  // step parity 1: the last plain slot of the step
+  for (int k = 2 * hw * mt - 1; k >= 0; --k)
+    if (wide_plain_slot(mode, mt, hw, k)) return k;
+  return 0;
+}
+__host__ __device__ constexpr int wide_plain_after(int mode, int mt, int hw, int k0, int skip) {  // the (skip + 1)-th plain slot behind k0 (not the barrier's), or the last one there is; -1: none
+  int last = -1;
+  for (int k = k0 + 1; k < 2 * hw * mt; ++k)
+    if (wide_plain_slot(mode, mt, hw, k) && k != wide_barrier_slot(mode, mt, hw)) {
+      last = k;
+      if (skip-- == 0) return k;
+    }
+  return last;
+}
+// cursor increments: the ring's after the step's last refill (both parities); the LDS-DMA's in front of the stage's first chunk (parity 0: pre-increment, first plain
+// slot of the step); the scales' (per-group) behind their load (parity 1)
+__host__ __device__ constexpr int wide_ring_inc_slot(int mode, int mt, int hw) {
+  int last = 0;
+  for (int k = 0; k < 2 * hw * mt; ++k)
+    if (mode == 2 ? wide_w8_refill_index_(mt, hw, k) >= 0 : (wide_refill_slot(hw, k, 0) || wide_refill_slot(hw, k, 1))) last = k;
+  return wide_plain_after(mode, mt, hw, last, 1);
+}
+__host__ __device__ constexpr int wide_dma_inc_slot(int, int, int) { return 0; }  // (slot 0 carries no load, no fragment re-read and no M0 write in any shape)
+__host__ __device__ constexpr int wide_scale_inc_slot(int mode, int mt, int hw) { return wide_plain_after(mode, mt, hw, wide_scale_slot(hw), 2); }
+__host__ __device__ constexpr int wide_bal_cap(int mode, int mt, int hw, int t, int k, bool cursors) {
+  if (!wide_plain_slot(mode, mt, hw, k)) return wide_m0_slot(mt, hw, k) && !wide_frag_slot(hw, k) && !wide_dma_slot(mt, hw, k) ? 1 : 0;
+  int c = 2;
+  if (t == 1 && k == wide_barrier_slot(mode, mt, hw)) c -= 2;
+  if (cursors) {
+    if (k == wide_ring_inc_slot(mode, mt, hw)) c -= 1;
+    if (t == 0 && k == wide_dma_inc_slot(mode, mt, hw)) c -= 1;
+    if (mode == 1 && t == 1 && k == wide_scale_inc_slot(mode, mt, hw)) c -= 1;
+  }
+  return c < 0 ? 0 : c;
+}
+__host__ __device__ constexpr int wide_bal_items(int mode) { return 13 + (mode == 1 ? 32 : 12); }  // per 32-column half: wait, 4 x (VCC write, 2 selects), unpack parts
+__host__ __device__ constexpr int wide_bal_cost(int mode, int w) { return w < 13 ? 1 : (mode == 1 ? 2 : 1); }  // instructions of item w of a half
+// number of items (of the hw * wide_bal_items(mode) of a step, in order) dealt to slots [0, k): item i goes to the first slot whose cumulative share of the capacity
+// reaches the item's cumulative share of the instructions
+__host__ __device__ constexpr int wide_bal_before(int mode, int mt, int hw, int t, int k, bool cursors) {
+  const int nslot = 2 * hw * mt, per = wide_bal_items(mode), ni = hw * per;
+  int ct = 0, cb = 0, tc = 0;
+  for (int j = 0; j < nslot; ++j) ct += wide_bal_cap(mode, mt, hw, t, j, cursors);
+  for (int j = 0; j < k; ++j) cb += wide_bal_cap(mode, mt, hw, t, j, cursors);
+  for (int i = 0; i < ni; ++i) tc += wide_bal_cost(mode, i % per);
+  if (k >= nslot) return ni;
+  int n = 0, e = 0;
+  for (int i = 0; i < ni; ++i) {
+    e += wide_bal_cost(mode, i % per);
+    if ((long long)e * ct <= (long long)cb * tc) ++n;  // item ends inside the capacity of the slots before k
+  }
+  return n;
+}
+
+// (the dealing worked out ONCE per shape and step parity: clang's constant evaluator walks the loops above per call, and the slot bodies ask 2 x 64 x 8 times per instantiation)
+template <int MODE, int MT, int HW, int T, bool CURSORS>
+struct WideBalTable {
+  struct Tab {
+    int before[2 * HW * MT + 1];
+  };
+  static constexpr Tab make() {
+    Tab r{};
+    constexpr int nslot = 2 * HW * MT, per = wide_bal_items(MODE), ni = HW * per;
+    int cap[nslot] = {};
+    int ct = 0, tc = 0;
+    for (int j = 0; j < nslot; ++j) {
+      cap[j] = wide_bal_cap(MODE, MT, HW, T, j, CURSORS);
+      ct += cap[j];
+    }
+    for (int i = 0; i < ni; ++i) tc += wide_bal_cost(MODE, i % per);
+    int cb = 0, n = 0, e = wide_bal_cost(MODE, 0);  // e: cumulative cost up to and including item n
+    for (int k = 0; k < nslot; ++k) {
+      while (n < ni && (long long)e * ct <= (long long)cb * tc) {
+        ++n;
+        if (n < ni) e += wide_bal_cost(MODE, n % per);
+      }
+      r.before[k] = n;
+      cb += cap[k];
+    }
+    r.before[nslot] = ni;
+    return r;
+  }
+  static constexpr Tab tab = make();
+};
+
+static_assert(WideBalTable<0, 16, 2, 0, true>::tab.before[17] == wide_bal_before(0, 16, 2, 0, 17, true) && WideBalTable<0, 16, 2, 1, true>::tab.before[63] == wide_bal_before(0, 16, 2, 1, 63, true) &&
+                  WideBalTable<1, 8, 2, 1, false>::tab.before[9] == wide_bal_before(1, 8, 2, 1, 9, false) && WideBalTable<1, 16, 1, 0, true>::tab.before[30] == wide_bal_before(1, 16, 1, 0, 30, true),
+              "the table is the function");
 
 // LDS-DMA staging: the activations go global -> LDS directly (buffer_load_dwordx4 ... lds, one
 // 16-byte chunk per lane and instruction, lane-linear destination M0 + 16 * lane; the row swizzle is applied on the SOURCE
@@ -232,6 +355,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       sp = 0;
       tile_lin = lin2;
       locate(lin2, tile_m, tile_n);
+    } else if (ksplit == 2 && (hflags & 16) != 0 && ((tiles_m * tiles_n) & 3) == 0) {
+      // (measurement, tune.fused bit 7: the two slices of a tile on NEIGHBOURING XCDs -- XCD pair p walks a quarter of the tiles, the even XCD their first K
+      // halves, the odd one the second: an L2 then streams half of K of its activation panels and weight strips instead of all of it for half as many
+      // tiles; the deposits cross the fabric)
+      const int per = (tiles_m * tiles_n) >> 2;
+      sp = xcd & 1;
+      tile_lin = (xcd >> 1) * per + idx;
+      locate(tile_lin, tile_m, tile_n);
     } else {
       const int lin = lin2 / ksplit;
       sp = lin2 - lin * ksplit;
@@ -276,10 +407,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                  0x00020000u};
   };
   // (CHAIN: one descriptor over the whole tensor, the tile's column group goes into the scalar offset -- ng * 512 / ng * 128 bytes)
-  const v4u wdesc = descriptor(CHAIN ? (const void*)B : (const void*)(B + (size_t)ng * (W8 ? 4096 : 512)));
+  v4u wdesc = descriptor(CHAIN ? (const void*)B : (const void*)(B + (size_t)ng * (W8 ? 4096 : 512)));
+  constexpr bool CUR = !CHAIN && QQQ_WIDE_CURSORS != 0;
+  if constexpr (CUR) {  // the descriptor ends with the tensor (packed: K / 16 rows of 8 N bytes; expanded: K x N bytes -- below 4 GiB, the host sends larger ones elsewhere)
+    const unsigned long long total = W8 ? (unsigned long long)K * (unsigned)N : ((unsigned long long)K * (unsigned)N) >> 1;
+    wdesc[2] = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(total - (unsigned long long)ng * (W8 ? 4096u : 512u)));
+  }
   const unsigned woff = W8 ? (unsigned)(lane * 16 + 2048 * whalf)                                // + step * wstep (scalar) + 1024 * q
                            : (unsigned)h * rowbytes + (unsigned)(cq * 64 + q4 * 16 + 256 * whalf);   // + step * wstep (scalar) + 256 * hf
-  const v4u sdesc = descriptor(GROUPED ? (CHAIN ? (const void*)s3 : (const void*)(s3 + (size_t)ng * 64)) : (const void*)B);
+  v4u sdesc = descriptor(GROUPED ? (CHAIN ? (const void*)s3 : (const void*)(s3 + (size_t)ng * 64)) : (const void*)B);
+  if constexpr (CUR && GROUPED) sdesc[2] = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(K >> 7) * (unsigned)N * 2u - (unsigned)ng * 128u));
   const unsigned soff_l = (unsigned)((cq * 8 + 2 * q4) * 2 + 64 * whalf);         // + stage * N * 2 (scalar) + 64 * hf
   // Activation staging by LDS-DMA: instruction q of wave wn fills the 1 KiB [rows 8 wn + 32 q .. + 8) x 128 bytes of the stage
   // image, lane l -> byte 16 l of it = (row l >> 3, slot l & 7).  The image keeps the XOR swizzle of the fragment reads
@@ -287,6 +424,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // (CHAIN: the descriptor follows the LDS-DMA cursor from tile to tile; its size field ends at the tile's last valid row, so
   // rows past M are out of range for the buffer unit -- whatever lands in their LDS rows is computed on and never stored)
   v4u xdesc = descriptor(A + (size_t)mbase * K);
+  if constexpr (CUR) {  // ends at the last valid row of A (rows of this tile past M are clamped below; a stage past K in the tensor's last row is out of range)
+    const unsigned long long rest = (unsigned long long)(M - mbase) * (unsigned)K;
+    xdesc[2] = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(rest < 0xffffffffull ? rest : 0xffffffffull));
+  }
   const int xr0 = tid >> 3, xslot = tid & 7;
   unsigned xoff[XPT];
 #pragma unroll
@@ -355,6 +496,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     asm("" : "+s"(so));
     asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(xoff[decltype(qc)::value]), "s"(xdesc), "s"(so) : "memory");
   };
+  // (cursors: the running offset IS the operand -- no copy, and its last write is slots away: no s_nop in front of the load)
+  auto dma_go_cur = [&](auto qc) __attribute__((always_inline)) {
+    (void)xoff[0], (void)xdesc, (void)cx_so;
+    asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(xoff[decltype(qc)::value]), "s"(xdesc), "s"(cx_so) : "memory");
+  };
   auto dma_x = [&](auto bufc, auto qc, const unsigned so) __attribute__((always_inline)) {  // chunk q of a stage -> LDS buffer buf
     dma_m0(bufc, qc);
     asm volatile("s_nop 0");
@@ -376,6 +522,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     else
       asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=v"(dst) : "v"(woff), "s"(wdesc), "s"(so), "n"((W8 ? 1024 : 256) * decltype(hfc)::value));
   };
+  auto asm_load_w_cur = [&](v4u& dst, auto hfc) __attribute__((always_inline)) {
+    (void)woff, (void)wdesc, (void)cr_so;
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=v"(dst) : "v"(woff), "s"(wdesc), "s"(cr_so), "n"((W8 ? 1024 : 256) * decltype(hfc)::value));
+  };
   constexpr int WRN = W8 ? NQ : HW;      // 16-byte loads per step and lane: one per 32-column half of packed int4, or (W8) one per column set
   auto load_w_so = [&](const unsigned so, v4u (&dst)[WRN]) __attribute__((always_inline)) {
     qqq_static_for<WRN>([&](auto hfc) { asm_load_w(dst[decltype(hfc)::value], hfc, so); });
@@ -391,6 +541,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     asm("" : "+s"(so));
     asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(dst[0]) : "v"(soff_l), "s"(sdesc), "s"(so));
     asm volatile("buffer_load_dword %0, %1, %2, %3 offen offset:%4" : "=v"(dst[1]) : "v"(soff_l), "s"(sdesc), "s"(so), "n"(HW == 2 ? 64 : 0));
+  };
+  auto load_sc_cur = [&](unsigned (&dst)[2]) __attribute__((always_inline)) {
+    (void)cc_so;
+    asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(dst[0]) : "v"(soff_l), "s"(sdesc), "s"(cc_so));
+    asm volatile("buffer_load_dword %0, %1, %2, %3 offen offset:%4" : "=v"(dst[1]) : "v"(soff_l), "s"(sdesc), "s"(cc_so), "n"(HW == 2 ? 64 : 0));
   };
   auto load_sc = [&](const int st_rel, unsigned (&dst)[2]) __attribute__((always_inline)) {
     const int st = st_rel < NST ? st_rel : NST - 1;
@@ -446,6 +601,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                    "v_cndmask_b32_dpp %1, %3, %5, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
                    : "=&v"(y[2]), "=&v"(y[3]) : "v"(z[0]), "v"(z[1]), "v"(z[2]), "v"(z[3]), "s"(kmc) : "vcc");
   };
+  // the same four pieces one INSTRUCTION at a time (QQQ_WIDE_BALANCE): si = 0 the piece's VCC write, 1 / 2 its two selects.  VCC carries from one statement to the
+  // next: nothing else in the steady-state loop writes it (the asm statements keep their order; the compiled loop is checked by tests/test_code_object_cpu.py)
+  auto tr_single = [&](auto pc, auto sc, const v4u& w) {
+    constexpr int pi = decltype(pc)::value, si = decltype(sc)::value;
+    (void)y[0];
+    (void)z[0];
+    if constexpr (si == 0) {
+      asm volatile("s_mov_b64 vcc, %0" : : "s"(pi == 0 ? km5 : pi == 1 ? kma : pi == 2 ? km3 : kmc) : "vcc");
+    } else if constexpr (pi == 0) {
+      if constexpr (si == 1) asm volatile("v_cndmask_b32_dpp %0, %2, %1, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=&v"(z[0]) : "v"(w[0]), "v"(w[1]));
+      else asm volatile("v_cndmask_b32_dpp %0, %2, %1, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=&v"(z[2]) : "v"(w[2]), "v"(w[3]));
+    } else if constexpr (pi == 1) {
+      if constexpr (si == 1) asm volatile("v_cndmask_b32_dpp %0, %1, %2, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=&v"(z[1]) : "v"(w[0]), "v"(w[1]));
+      else asm volatile("v_cndmask_b32_dpp %0, %1, %2, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=&v"(z[3]) : "v"(w[2]), "v"(w[3]));
+    } else if constexpr (pi == 2) {
+      if constexpr (si == 1) asm volatile("v_cndmask_b32_dpp %0, %2, %1, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=&v"(y[0]) : "v"(z[0]), "v"(z[2]));
+      else asm volatile("v_cndmask_b32_dpp %0, %2, %1, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=&v"(y[1]) : "v"(z[1]), "v"(z[3]));
+    } else {
+      if constexpr (si == 1) asm volatile("v_cndmask_b32_dpp %0, %1, %2, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=&v"(y[2]) : "v"(z[0]), "v"(z[2]));
+      else asm volatile("v_cndmask_b32_dpp %0, %1, %2, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=&v"(y[3]) : "v"(z[1]), "v"(z[3]));
+    }
+  };
   // per-channel: 12 VALU (and | shift, and per packed word); per-group: 8 x dequant_group4 in 4 two-instruction parts
   const unsigned nmask = QQQ_NIB_MASK;
   h2 sb[2];                    // per-group: the half's two group scales, broadcast
@@ -482,6 +659,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         ghb[b] = __builtin_elementwise_fma(ghb[b], sb[b], c_mag);
       } else {
         int w = (int)(__builtin_amdgcn_perm(__builtin_bit_cast(unsigned, ghb[b]), __builtin_bit_cast(unsigned, gha[b]), 0x06040200u) ^ 0x80808080u);
+        // (per-group: no holds in the plain kernel -- the slots' sched_barriers keep a part where it was dealt, and an asm statement that so much as READS the result
+        // of a v_pk_fma_f16 makes hipcc put an s_nop in front of it: 105 of them per trip when tried)
         if constexpr (CHAIN) asm volatile("" : "+v"(w));  // (see below)
         a[2 * hf + b][kq] = w;
       }
@@ -492,14 +671,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       constexpr int kq = pi / 3, part = pi % 3;
       if constexpr (part == 0) {
         int w = (int)(y[kq] & nmask);                                            // odd nibbles  -> 16*w4 of column n      (b = 0)
-        if constexpr (CHAIN) asm volatile("" : "+v"(w));
+        if constexpr (QQQ_WIDE_BALANCE != 0) asm volatile("" : : "v"(w));  // (a USE only: behind an asm that DEFINES a register hipcc puts an s_nop in front of its next reader)
+        else if constexpr (CHAIN) asm volatile("" : "+v"(w));
         a[2 * hf][kq] = w;
       } else if constexpr (part == 1) {
         gt0[0] = y[kq] << 4;
-        if constexpr (CHAIN) asm volatile("" : "+v"(gt0[0]));
+        if constexpr (QQQ_WIDE_BALANCE != 0) asm volatile("" : : "v"(gt0[0]));
+        else if constexpr (CHAIN) asm volatile("" : "+v"(gt0[0]));
       } else {
         int w = (int)(gt0[0] & nmask);                                           // even nibbles -> 16*w4 of column n + 8  (b = 1)
-        if constexpr (CHAIN) asm volatile("" : "+v"(w));
+        if constexpr (QQQ_WIDE_BALANCE != 0) asm volatile("" : : "v"(w));
+        else if constexpr (CHAIN) asm volatile("" : "+v"(w));
         a[2 * hf + 1][kq] = w;
       }
     }
@@ -523,13 +705,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int step_abs = 2 * i + t;
     constexpr int su = GROUPED ? ((t == 1) ? (u + 1) % P : u) : 0;  // scales of the NEXT step's stage
     const int st_x = i + LA < NST ? i + LA : NST - 1;
-    const unsigned xso = CHAIN ? st_xso : (unsigned)(st0 + st_x) * 128u;  // (CHAIN: i is not used; do_stage_chain says where the loads read)
+    // (CHAIN: i is not used, do_stage_chain says where the loads read; plain kernel with cursors: the running offsets themselves, advanced in slots of their own below)
     const unsigned cswo = st_swo[t], csco = st_sco;
+    constexpr int BSLOT = wide_barrier_slot(MODE, MT, HW);
+    static_assert(!CUR || (wide_ring_inc_slot(MODE, MT, HW) > 0 && (!GROUPED || wide_scale_inc_slot(MODE, MT, HW) > wide_scale_slot(HW))), "every cursor has a slot behind its last use");
     constexpr int NI = HW * (4 + UPARTS);
     auto slot = [&](auto kc) __attribute__((always_inline)) {
       constexpr int k = decltype(kc)::value, mt = k / NQ, q = k % NQ;
+      constexpr int SD = QQQ_WIDE_STAGGER <= 0 ? 1 : (HW == 2 ? QQQ_WIDE_STAGGER : 1);  // (128-column tiles: the first M0 slot is slot 4)
+      if constexpr (QQQ_WIDE_STAGGER > 0 && t == 0 && k % SD == 0 && k / SD < 4) {
+        // the barrier that ends the PREVIOUS stage, taken by wave 3 - k / d only (wave-uniform scalar branch around one s_barrier).  What it orders is a stage away
+        // on both sides: the buffer this stage's LDS-DMA overwrites (first chunk: slot wide_dma_slot > 3 d) was last read a step before the previous stage ended,
+        // the buffer it publishes is first read in this stage's second step; the wave's own share of that buffer has landed (vmcnt wait at the end of the
+        // previous stage).  No LDS drain in front of it: the fragment reads in flight belong to this step.
+        static_assert(3 * SD < (HW == 2 ? 8 : 4), "every wave passes the barrier before the stage's first LDS-DMA (M0 slot)");
+        (void)wn;
+        asm volatile("s_cmp_lg_u32 %0, %1\n\ts_cbranch_scc1 1f\n\ts_barrier\n1:" : : "s"(wn), "n"(3 - k / SD) : "scc");
+      }
       if constexpr (W8) mfma(acc[mt][q], wr[sl][q], x[mt]);
       else mfma(acc[mt][q], aop[cur][q], x[mt]);
+      if constexpr (QQQ_WIDE_BALANCE != 0) __builtin_amdgcn_sched_barrier(0);  // (the slot's other instructions BEHIND its MFMA: hipcc likes to hoist a free VALU instruction in front of it, i.e. into the previous slot)
       if constexpr (W8) {
         // the operands of step s + 1 (ring slot sn): fetched during step s + 1 - RL, the last of them at that step's last refill slot; landed once at
         // most the loads issued since are outstanding.  One wait per step, behind the step's last MFMA.
@@ -539,6 +734,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           if constexpr (HW == 2) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(wr[sn][0]), "+v"(wr[sn][1]), "+v"(wr[sn][2]), "+v"(wr[sn][3]) : "n"(younger));
           else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(wr[sn][0]), "+v"(wr[sn][1]) : "n"(younger));
         }
+      } else if constexpr (!(QQQ_WIDE_ABLATE & 4) && QQQ_WIDE_BALANCE != 0) {
+        // one-instruction items dealt by slot capacity (see QQQ_WIDE_BALANCE above)
+        constexpr int PER = wide_bal_items(MODE);
+        constexpr int lo = WideBalTable<MODE, MT, HW, t, CUR>::tab.before[k], hi = WideBalTable<MODE, MT, HW, t, CUR>::tab.before[k + 1];
+        qqq_static_for<(hi - lo)>([&](auto jc) {
+          constexpr int it = lo + decltype(jc)::value;
+          constexpr int hf = it / PER, w_ = it % PER;
+          if constexpr (w_ == 0) {
+            // ring slot sn, half hf: loaded RS - 1 steps ago at slot 2 + 4 hf; everything older (the group scales of this stage among it) has landed once at
+            // most the loads issued since are outstanding (vmcnt is a 6-bit counter: a deeper ring than 63 loads waits a little early, never late)
+            constexpr int younger_all = wide_loads_between(MODE, MT, HW, (t + RS - 1) & 1, 2 + 4 * hf, RS - 1, k);
+            constexpr int younger = younger_all < 63 ? younger_all : 63;
+            if constexpr (GROUPED && CHAIN && HW == 1) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(wr[sn][hf]), "+v"(scr[su][0]), "+v"(scr[su][1]) : "n"(younger));
+            else if constexpr (GROUPED) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(wr[sn][hf]), "+v"(scr[su][hf]) : "n"(younger));
+            else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(wr[sn][hf]) : "n"(younger));
+            un_setup(__builtin_bit_cast(h2, scr[su][hf]));
+          } else if constexpr (w_ < 13) {
+            tr_single(std::integral_constant<int, (w_ - 1) / 3>{}, std::integral_constant<int, (w_ - 1) % 3>{}, wr[sn][hf]);
+          } else {
+            un_part(std::integral_constant<int, w_ - 13>{}, std::integral_constant<int, hf>{}, aop[nxt]);
+          }
+        });
       } else if constexpr (!(QQQ_WIDE_ABLATE & 4)) {
         // MT == 16: the NI items go to the NE = 34 memory-free slots of the step (per-channel one each, per-group 2-3 each)
         constexpr bool MAPPED = HW == 1 || ((QQQ_WIDE_SLOTMAP & (GROUPED ? 2 : 1)) != 0 && (MT == 16 || (QQQ_WIDE_SLOTMAP & 4) != 0));
@@ -577,15 +794,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       if constexpr (wide_frag_slot(HW, k) && !(QQQ_WIDE_ABLATE & 16)) read_x(t == 0 ? (u % P) : ((u + 1) % P), t == 0 ? 1 : 0, mt);
       // (the order of the loads inside a slot is the order wide_loads_in_slot counts them in)
       if constexpr (GROUPED && t == 1 && k == wide_scale_slot(HW) && !(QQQ_WIDE_ABLATE & 8)) {
-        if constexpr (CHAIN) load_sc_so(csco, scr[u]);
+        if constexpr (CUR) load_sc_cur(scr[u]);
+        else if constexpr (CHAIN) load_sc_so(csco, scr[u]);
         else load_sc(i + P, scr[u]);
+      }
+      if constexpr (CUR) {  // the cursors' scalar adds, one per slot (wide_bal_cap leaves room for them)
+        (void)cx_so, (void)cr_so, (void)cc_so;
+        if constexpr (k == wide_ring_inc_slot(MODE, MT, HW)) {
+          cr_so += wstep;
+          asm volatile("" : "+s"(cr_so));
+        }
+        if constexpr (t == 0 && k == wide_dma_inc_slot(MODE, MT, HW)) {
+          cx_so += 128u;
+          asm volatile("" : "+s"(cx_so));
+        }
+        if constexpr (GROUPED && t == 1 && k == wide_scale_inc_slot(MODE, MT, HW)) {
+          cc_so += (unsigned)N * 2u;
+          asm volatile("" : "+s"(cc_so));
+        }
       }
       if constexpr (!(QQQ_WIDE_ABLATE & 8)) {  // ring refill, one 16-byte load per slot
         const int sw = step_abs + RL < KS ? step_abs + RL : KS - 1;
-        const unsigned swo = CHAIN ? cswo : (unsigned)(2 * st0 + sw) * wstep;
+        const unsigned swo = CUR ? cr_so : CHAIN ? cswo : (unsigned)(2 * st0 + sw) * wstep;
         if constexpr (W8) {  // column set j of the slot the PREVIOUS step consumed
           constexpr int j = wide_w8_refill_index(MT, HW, k);
-          if constexpr (j >= 0) asm_load_w(wr[(sl + RS - 1) % RS][j], std::integral_constant<int, j>{}, swo);
+          if constexpr (j >= 0 && CUR) asm_load_w_cur(wr[(sl + RS - 1) % RS][j], std::integral_constant<int, j>{});
+          else if constexpr (j >= 0) asm_load_w(wr[(sl + RS - 1) % RS][j], std::integral_constant<int, j>{}, swo);
+        } else if constexpr (CUR) {
+          if constexpr (wide_refill_slot(HW, k, 0)) asm_load_w_cur(wr[sl][0], std::integral_constant<int, 0>{});
+          if constexpr (wide_refill_slot(HW, k, 1)) asm_load_w_cur(wr[sl][HW - 1], std::integral_constant<int, 1>{});
         } else {
           if constexpr (wide_refill_slot(HW, k, 0)) asm_load_w(wr[sl][0], std::integral_constant<int, 0>{}, swo);
           if constexpr (wide_refill_slot(HW, k, 1)) asm_load_w(wr[sl][HW - 1], std::integral_constant<int, 1>{}, swo);
@@ -594,7 +831,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       constexpr int DP = wide_dma_period(MT, HW);  // chunk (XPT / 2) t + k / DP of stage i + LA: M0, then the DMA
       if constexpr (wide_m0_slot(MT, HW, k) && !(QQQ_WIDE_ABLATE & 2))
         dma_m0(std::integral_constant<int, (u + LA) % P>{}, std::integral_constant<int, (XPT / 2) * t + k / DP>{});
-      if constexpr (wide_dma_slot(MT, HW, k) && !(QQQ_WIDE_ABLATE & 2)) dma_go(std::integral_constant<int, (XPT / 2) * t + k / DP>{}, xso);
+      if constexpr (wide_dma_slot(MT, HW, k) && !(QQQ_WIDE_ABLATE & 2)) {
+        if constexpr (CUR) dma_go_cur(std::integral_constant<int, (XPT / 2) * t + k / DP>{});
+        else dma_go(std::integral_constant<int, (XPT / 2) * t + k / DP>{}, CHAIN ? st_xso : (unsigned)(st0 + st_x) * 128u);
+      }
+      if constexpr (QQQ_WIDE_BALANCE != 0 && QQQ_WIDE_STAGGER == 0 && t == 1 && k == BSLOT) {
+        // the stage's end, in a slot of its own (BALANCE): the LDS-DMA of stage i + 2, issued during stage i + 3 - P, is done when at most the loads issued since
+        // its last chunk are outstanding; then the barrier.  A bare s_barrier: what it orders is this wave's share of that DMA (waited for here) and the fragment reads of
+        // the buffer the next stage's DMA overwrites -- consumed by MFMAs a step ago; the reads in flight belong to the next stage and need no drain.
+        constexpr int since = wide_loads_between(MODE, MT, HW, 1, wide_last_dma_slot(MT, HW), 2 * (P - 3), k + 1);
+        static_assert(since < 64, "vmcnt is a 6-bit counter");
+        if constexpr (!(QQQ_WIDE_ABLATE & 1)) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" : : "n"(since) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(since) : "memory");
+      }
       __builtin_amdgcn_sched_barrier(0);
     };
     qqq_static_for<NSLOT>(slot);
@@ -789,15 +1038,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
   __builtin_amdgcn_sched_barrier(0);
 
+  if constexpr (CUR) {  // the loop's loads of stage 0: LDS-DMA LA stages ahead, ring RL steps ahead, scales P stages ahead (relative to the slice's first stage)
+    cx_so = sgpr((unsigned)(st0 + LA - 1) * 128u);  // (advanced in front of the stage's first chunk)
+    cr_so = sgpr((unsigned)(2 * st0 + RL) * wstep);
+    cc_so = sgpr((unsigned)(st0 + P) * (unsigned)N * 2u);
+  }
   auto do_stage = [&](const int i, auto uc) __attribute__((always_inline)) {  // one 128-k stage: two steps and the barrier that publishes stage i + LA
     step(i, uc, std::integral_constant<int, 0>{});
     step(i, uc, std::integral_constant<int, 1>{});
+    if constexpr (QQQ_WIDE_BALANCE != 0 && QQQ_WIDE_STAGGER == 0) return;  // (the stage-end wait and barrier sit in slot BSLOT of the second step)
     // the LDS-DMA of stage i + 2, issued during stage i + 3 - P: done when at most the loads issued since its last chunk
     // (the last DMA slot of that stage's second step) are outstanding, i.e. those of the P - 3 stages since
     constexpr int since = wide_loads_between(MODE, MT, HW, 1, wide_last_dma_slot(MT, HW), 2 * (P - 3), NSLOT);
     static_assert(since < 64, "vmcnt is a 6-bit counter");
     asm volatile("s_waitcnt vmcnt(%0)" : : "n"(since) : "memory");
-    if constexpr (!(QQQ_WIDE_ABLATE & 1)) __syncthreads();  // stage i + 2 is in LDS for everybody; buffer (i % P) is free
+    if constexpr (!(QQQ_WIDE_ABLATE & 1) && QQQ_WIDE_STAGGER == 0) __syncthreads();  // stage i + 2 is in LDS for everybody; buffer (i % P) is free
   };
   QQQ_WTR(1);
   if constexpr (CHAIN) {
@@ -830,10 +1085,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
       step(0, uc, std::integral_constant<int, 0>{});
       step(0, uc, std::integral_constant<int, 1>{});
+      if constexpr (QQQ_WIDE_BALANCE != 0 && QQQ_WIDE_STAGGER == 0) return;  // (the stage-end wait and barrier sit in slot BSLOT of the second step)
       constexpr int since = wide_loads_between(MODE, MT, HW, 1, wide_last_dma_slot(MT, HW), 2 * (P - 3), NSLOT);
       static_assert(since < 64, "vmcnt is a 6-bit counter");
       asm volatile("s_waitcnt vmcnt(%0)" : : "n"(since) : "memory");
-      __syncthreads();
+      if constexpr (QQQ_WIDE_STAGGER == 0) __syncthreads();
     };
     bool more = true;
     // (the expectations put the seams and the tile-end offset code out of line: the common stage falls through from one MFMA

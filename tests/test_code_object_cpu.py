@@ -146,6 +146,7 @@ def test_wide_kernel_hand_counted_waits_replayed_on_the_compiled_code():
     touches a register a load still in flight is going to write (a too-large count, or hipcc reusing the destination of a dead
     load: both happened while this was written).  All twelve instantiations; and at each barrier exactly the current stage's
     loads may be in flight (the previous stage's DMAs, which the barrier publishes, have retired)."""
+    # (round 6, balanced issue slots: the waits moved with the items they belong to -- the replay is what says the new positions are right)
     import check_waits
     import code_object
     from qqq_amd import build
@@ -164,14 +165,14 @@ def test_wide_kernel_hand_counted_waits_replayed_on_the_compiled_code():
                     problems += check_waits.check(body, path)[0]
                 problems += check_waits.check_prologue(text.split("\n"))
                 assert not problems, (name, sorted(set(problems))[:4])
-                if mode == 2:  # expanded weights: 2 hw operand loads per step, spread over it between the activation chunks
-                    one = {(16, 2): "rDrDrDrD", (8, 2): "rDrrDr", (16, 1): "rDDrDD"}[(mt, hw)]
-                    per_step = one + one
-                else:
-                    per_step = "r" * hw + "D" * (mt // 4)  # ring refill(s), then the step's activation chunks
-                    second = ("rr" if grouped else "") + per_step if hw == 2 else "r" + ("rr" if grouped else "") + "D" * (mt // 4)
-                    per_step = per_step + second
-                assert at_barrier == [per_step] * 4, (name, at_barrier)
+                # at the barrier exactly the CURRENT stage's activation chunks may be in flight -- the stage it publishes (issued P - 3 stages earlier) has
+                # retired -- next to ring refills / scale loads of the last steps.  (Round 6: the stage's wait + barrier sit in the last plain slot of its second
+                # step: in the 128-column shape that is slot 26 of 32, in front of the step's last chunk.)
+                chunks = 2 * (mt // 4) - (1 if hw == 1 else 0)
+                assert len(at_barrier) == 4 and all(b == at_barrier[0] for b in at_barrier), (name, at_barrier)
+                assert at_barrier[0].count("D") == chunks and set(at_barrier[0]) <= set("rD"), (name, at_barrier)
+                refills = (2 * hw if mode == 2 else hw) * 2 + (2 if grouped else 0)  # per stage
+                assert refills - 1 <= at_barrier[0].count("r") <= refills + 2 * hw, (name, at_barrier)
                 # what hipcc's own bookkeeping cannot see around the inline asm (tools/check_vmem.py): M0 is written nowhere but
                 # in front of the LDS-DMA that reads it (hipcc reserves M0 -- a clobber is refused as "reserved register" -- so the
                 # discipline is checked on the code instead), and no vector-memory instruction reads an SGPR inside the 5 wait
@@ -273,3 +274,37 @@ def test_check_vmem_flags_planted_faults():
         ".LBB0_1:", "\tbuffer_load_dwordx4 v[10:13], v1, s[4:7], s8 offen", "\ts_mov_b64 s[24:25], 0", "\ts_and_b64 vcc, exec, s[24:25]",
         "\ts_cbranch_vccz .LBB0_9", "\tv_mov_b32_e32 v40, v12", ".LBB0_9:", "\ts_waitcnt vmcnt(0)", "\ts_endpgm"])
     assert check_vmem.run(check_vmem.parse(flagged))[0] == {}
+
+
+def test_wide_transpose_selects_find_their_vcc_mask():
+    """Round 6 (balanced issue slots): the quad transpose's pieces are issued one instruction at a time -- `s_mov_b64 vcc, <lane mask>` in one slot, its two
+    `v_cndmask_b32_dpp ... vcc` selects in later ones, MFMAs and other items in between -- so VCC carries a value across asm statements hipcc knows nothing about.
+    On the compiled code of every wide-kernel instantiation: each mask write is followed by exactly its two selects before the next one, no select runs without a mask,
+    and nothing else writes VCC in between."""
+    import re
+
+    import code_object
+    from qqq_amd import build
+
+    ks = {k["demangled"]: k["name"] for k in code_object.kernels(build.LIB)}
+    names = [n for n in ks if n.startswith("qqq_wide_kernel<") and not n.startswith("qqq_wide_kernel<2,")]  # (expanded weights: no transpose in the loop)
+    assert len(names) >= 12
+    for name in names:
+        pending, selects, problems = 0, 0, []
+        for line in code_object.disassemble(build.LIB, ks[name]).split("\n"):
+            if not line.startswith("\t"):
+                continue
+            op, _, args = line.strip().partition(" ")
+            first = args.split(",")[0].strip()
+            if op == "s_mov_b64" and first == "vcc":
+                if pending:
+                    problems.append(("mask rewritten with selects outstanding", line))
+                pending = 2
+            elif op == "v_cndmask_b32_dpp":
+                if not pending:
+                    problems.append(("select without its mask", line))
+                pending = max(0, pending - 1)
+                selects += 1
+            elif pending and (first == "vcc" or (("_co_" in op or op.startswith("v_div_scale") or op.startswith("v_cmp")) and re.search(r"\bvcc\b", args))):
+                problems.append(("VCC written between a mask and its selects", line))
+        assert not problems and pending == 0 and selects >= 32, (name, problems[:3], pending, selects)
