@@ -158,10 +158,49 @@ __host__ __device__ constexpr int wide_ring_inc_slot(int mode, int mt, int hw) {
 }
 __host__ __device__ constexpr int wide_dma_inc_slot(int, int, int) { return 0; }  // (slot 0 carries no load, no fragment re-read and no M0 write in any shape)
 __host__ __device__ constexpr int wide_scale_inc_slot(int mode, int mt, int hw) { return wide_plain_after(mode, mt, hw, wide_scale_slot(hw), 2); }
+// QQQ_WIDE_XWAIT (round 6): the fragment re-reads are inline asm as well, their lgkmcnt waits hand-placed.  hipcc put a wait behind 8 of the 16 re-reads of a step --
+// INTO the slot that already carries the ds_read_b128 (~12 cycles of issue): MFMA + ds_read + wait = 22 cycles, 6 lost eight times per step.  Here: one wait per group of
+// four m-tiles, in the last plain slot in front of the group's first MFMA of the NEXT step (group 0: in the tail of the step that issued the reads).  LDS reads return in
+// issue order (nothing else in the loop counts in lgkmcnt), so "group j has landed" == "at most <reads issued since its last one> are outstanding"; tools/check_waits.py
+// replays the compiled loop (every instruction against the reads still in flight).
+// Built, replayed clean on every instantiation, GPU suite green -- and measured LEVEL (profiles/r06_wide_balanced_slots.txt: 4096 tokens 423.2 - 427.3 us without, 422.9 -
+// 425.9 with): once the slots are balanced the launch sits on the part's power limit again, and issue cycles saved come back as clock lost.  Off; the compiler's waits stay.
+#ifndef QQQ_WIDE_XWAIT
+#define QQQ_WIDE_XWAIT 0
+#endif
+__host__ __device__ constexpr int wide_frag_slot_of(int hw, int m) { return 2 * hw * m + 2 * hw - 1; }  // the slot whose extras re-read x[m]
+// the wait slot of group j (m-tiles 4 j .. 4 j + 3): as an ABSOLUTE slot on the two-step timeline (step 0 issues the reads, step 1 uses them); -1: no such group
+__host__ __device__ constexpr int wide_xw_abs(int mode, int mt, int hw, int j) {
+  const int nslot = 2 * hw * mt;
+  if (4 * j >= mt) return -1;
+  const int use = nslot + 2 * hw * 4 * j;  // first MFMA of the group in step 1
+  for (int a = use - 2; a > wide_frag_slot_of(hw, 4 * j + 3); --a) {
+    const int k = a % nslot;
+    if (wide_plain_slot(mode, mt, hw, k) && k != wide_barrier_slot(mode, mt, hw)) return a;
+  }
+  return -1;
+}
+__host__ __device__ constexpr int wide_xw_count(int mode, int mt, int hw, int j) {  // re-reads issued behind the group's last one and in front of its wait
+  const int nslot = 2 * hw * mt, a = wide_xw_abs(mode, mt, hw, j), last = wide_frag_slot_of(hw, 4 * j + 3);
+  int n = 0;
+  for (int step = 0; step < 2; ++step)
+    for (int m = 0; m < mt; ++m) {
+      const int at = step * nslot + wide_frag_slot_of(hw, m);
+      if (at > last && at < a) ++n;
+    }
+  return n;
+}
+__host__ __device__ constexpr int wide_xw_count_at(int mode, int mt, int hw, int k) {  // the wait of slot k of a step: lgkmcnt(n) (the strictest of the groups that wait here); -1: none
+  int n = -1;
+  for (int j = 0; 4 * j < mt; ++j)
+    if (wide_xw_abs(mode, mt, hw, j) >= 0 && wide_xw_abs(mode, mt, hw, j) % (2 * hw * mt) == k && (n < 0 || wide_xw_count(mode, mt, hw, j) < n)) n = wide_xw_count(mode, mt, hw, j);
+  return n;
+}
 __host__ __device__ constexpr int wide_bal_cap(int mode, int mt, int hw, int t, int k, bool cursors) {
   if (!wide_plain_slot(mode, mt, hw, k)) return wide_m0_slot(mt, hw, k) && !wide_frag_slot(hw, k) && !wide_dma_slot(mt, hw, k) ? 1 : 0;
   int c = 2;
   if (t == 1 && k == wide_barrier_slot(mode, mt, hw)) c -= 2;
+  if (QQQ_WIDE_XWAIT != 0 && wide_xw_count_at(mode, mt, hw, k) >= 0) c -= 1;
   if (cursors) {
     if (k == wide_ring_inc_slot(mode, mt, hw)) c -= 1;
     if (t == 0 && k == wide_dma_inc_slot(mode, mt, hw)) c -= 1;
@@ -569,6 +608,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   auto read_x = [&](const int buf, const int t, const int mt) {
     x[mt] = *reinterpret_cast<const v4i*>(smem + buf * XB + xrd_t[t] + mt * 2048);
   };
+  // the loop's re-reads as inline asm (QQQ_WIDE_XWAIT): LDS byte address (the dynamic LDS starts at 0, as the LDS-DMA's M0 presumes) = lane part + a 16-bit
+  // immediate; the stage buffers span more than 64 KiB, so there is a second lane part 64 KiB up
+  // (not in the tile walk: with asm-defined fragments in every stage's basic block hipcc's allocator gives up -- 167 - 227 spilled registers when tried)
+  constexpr bool XW = QQQ_WIDE_XWAIT != 0 && QQQ_WIDE_BALANCE != 0 && !(QQQ_WIDE_ABLATE & 16) && !CHAIN;
+  static_assert(!XW || (wide_xw_abs(MODE, MT, HW, 0) >= 0 && wide_xw_abs(MODE, MT, HW, MT / 4 - 1) >= 0), "every group of four m-tiles has a slot for its wait");
+  const unsigned xrd_hi[2] = {xrd_t[0] + 65536u, xrd_t[1] + 65536u};
+  auto read_x_asm = [&](auto bufc, auto tc, auto mtc) __attribute__((always_inline)) {
+    constexpr int imm = decltype(bufc)::value * XB + decltype(mtc)::value * 2048, tt = decltype(tc)::value;
+    (void)xrd_hi[0], (void)xrd_t[0], (void)x[0];
+    if constexpr (imm >= 65536) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x[decltype(mtc)::value]) : "v"(xrd_hi[tt]), "n"(imm - 65536));
+    else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x[decltype(mtc)::value]) : "v"(xrd_t[tt]), "n"(imm));
+  };
 
   // ---- the unpack of one 32-column half (hf) of a step, cut into pieces that are placed one by one between the MFMAs ----
   // transpose: the two butterfly stages of quad_transpose4 (qqq_common.hip.h) as four 3-instruction pieces (lane masks kept
@@ -686,6 +737,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
     }
   };
+  // behind the loop: the last step's re-reads are never used -- their registers must stay theirs until they have landed
+  auto drain_x = [&]() __attribute__((always_inline)) {
+    if constexpr (XW) {
+      qqq_static_for<MT / 4>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        (void)x[0];  // (odr-use: clang does not capture what only an asm operand of a generic lambda names)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[4 * j]), "+v"(x[4 * j + 1]), "+v"(x[4 * j + 2]), "+v"(x[4 * j + 3]));
+      });
+    }
+  };
   auto mfma = [&](v4i& c, const auto& wa, const v4i& xb) {
     // inline asm: the accumulator is updated IN PLACE in the accumulation registers.  (The builtin selects the untied
     // form there, and with all 256 of them live hipcc's allocator bounces accumulators through VGPRs and scratch.)
@@ -791,7 +852,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           aop[nxt][qq] = (v4i){(int)wr[sn][qq / 2][0], (int)wr[sn][qq / 2][1], (int)wr[sn][qq / 2][2], (int)wr[sn][qq / 2][3]};
         });
       }
-      if constexpr (wide_frag_slot(HW, k) && !(QQQ_WIDE_ABLATE & 16)) read_x(t == 0 ? (u % P) : ((u + 1) % P), t == 0 ? 1 : 0, mt);
+      if constexpr (XW) {
+        if constexpr (wide_frag_slot(HW, k)) read_x_asm(std::integral_constant<int, (t == 0 ? (u % P) : ((u + 1) % P))>{}, std::integral_constant<int, (t == 0 ? 1 : 0)>{}, std::integral_constant<int, mt>{});
+        constexpr int n = wide_xw_count_at(MODE, MT, HW, k);
+        if constexpr (n >= 0) {  // the re-reads of the group(s) that wait here (issued a step ago; group 0: in this step) have landed
+          // (not tied to the registers: their only readers are the MFMA statements, which keep their place behind this one -- and behind an asm that DEFINES a
+          // register hipcc puts an s_nop in front of the next statement that reads it)
+          asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(n));
+        }
+      } else if constexpr (wide_frag_slot(HW, k) && !(QQQ_WIDE_ABLATE & 16)) {
+        read_x(t == 0 ? (u % P) : ((u + 1) % P), t == 0 ? 1 : 0, mt);
+      }
       // (the order of the loads inside a slot is the order wide_loads_in_slot counts them in)
       if constexpr (GROUPED && t == 1 && k == wide_scale_slot(HW) && !(QQQ_WIDE_ABLATE & 8)) {
         if constexpr (CUR) load_sc_cur(scr[u]);
@@ -1026,8 +1097,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     });
   }
   __syncthreads();
+  if constexpr (XW) {
+    // (asm as well, and drained here: a compiler-visible LDS read pending at the loop's entry makes hipcc wait for it INSIDE the loop body -- lgkmcnt(14) ... (0) in
+    // front of the first step's MFMAs of EVERY trip, each of which also drains the asm re-reads in flight)
+    qqq_static_for<MT>([&](auto mc) { read_x_asm(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, mc); });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  } else {
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) read_x(0, 0, mt);
+    for (int mt = 0; mt < MT; ++mt) read_x(0, 0, mt);
+  }
   if constexpr (!W8) {
     qqq_static_for<HW>([&](auto hfc) {  // both halves of step 0 into operand set 0
       constexpr int hf = decltype(hfc)::value;
@@ -1102,6 +1180,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       left = NST;                                             \
       if (ch_pos == ch_tiles) {                               \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      \
+        drain_x();                                            \
         more = false;                                         \
       }                                                       \
     }                                                         \
@@ -1132,6 +1211,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // destination of a dead asm load to the next value -- which the load then overwrites when it lands (seen: the transposed words of
   // column half 0 in the ragged tail).
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  drain_x();
   qqq_static_for<RS>([&](auto jc) {
     (void)wr[0];
     asm volatile("" : : "v"(wr[decltype(jc)::value][0]), "v"(wr[decltype(jc)::value][WRN - 1]));

@@ -93,20 +93,32 @@ def check(body, tail=()):
         return [x for x in ins if x and not x.startswith(".") and not x.endswith(":")]
     insts, tail_insts = clean(body), clean(tail)
     queue = []  # [dest regs (set) or None for an LDS-DMA]
+    lds = []    # LDS reads in flight (round 6: the fragment re-reads are inline asm too, their lgkmcnt waits hand-placed): destination registers, issue order = return order
     problems, barrier_counts = [], []
     for rep in range(3 if tail_insts else 2):
         for ins in (insts if rep < 2 else tail_insts):
             op, _, rest = ins.partition(" ")
             toks = [t.strip() for t in rest.split(",")]
             m = re.search(r"vmcnt\((\d+)\)", ins)
-            if op == "s_waitcnt" and m:
-                n = int(m.group(1))
-                if len(queue) > n:
-                    queue = queue[len(queue) - n :]
+            ml = re.search(r"lgkmcnt\((\d+)\)", ins)
+            if op == "s_waitcnt" and (m or ml):
+                if m:
+                    n = int(m.group(1))
+                    if len(queue) > n:
+                        queue = queue[len(queue) - n :]
+                if ml:
+                    n = int(ml.group(1))
+                    lds = lds[len(lds) - n :] if n and len(lds) > n else ([] if n == 0 else lds)
                 continue
             used = set()
             for t in toks:
                 used |= regs(t.split()[0] if t else "")
+            for q in lds:  # reads or overwrites the destination of an LDS read that has not returned
+                if q & used:
+                    problems.append("LDS: " + ins)
+            if op.startswith("ds_read"):
+                lds.append(regs(toks[0]))
+                continue
             if op.startswith("buffer_load") or op.startswith("global_load"):
                 if " lds" in ins:
                     queue.append(None)
