@@ -86,7 +86,9 @@ typedef struct qqq_tune {
                   that the slices of a tile run on ONE XCD whatever the number of strips), 64 = wide, two K slices of
                   256-column tiles: the EXCHANGE hand-off (each slice deposits the row half the other one finishes and finishes
                   its own, even slices; as shipped one slice deposits everything and the other folds, uneven slices -- the two
-                  measure level); out (qqq_w4a8_plan): set when the plan exchanges                                   */
+                  measure level); out (qqq_w4a8_plan): set when the plan exchanges; 128 = wide, two K slices (measurement): the
+                  slices of a tile on NEIGHBOURING XCDs instead of one (less fabric traffic in the loop, deposits across the
+                  fabric: 5 - 10 % slower, profiles/r06_wide_slices_neighbour_xcds.txt)                               */
   int bm;      /* tiled: rows per workgroup tile (64, 128, 256); panel: COLUMNS per workgroup (128, 256); wide: COLUMNS per
                   workgroup (256; 128 with mt = 16 only: 32 columns per wave); 0 auto */
   int glds;    /* tiled: 1 = direct global->LDS loads, 2 = register staged; 0 auto.

@@ -1181,16 +1181,20 @@ static int choose_split(const int M, const int N, const int K, const bool groupe
   const int rows = 16 * pl.mt;
   const long long tiles_n = (N + pl.bm - 1) / pl.bm;
   const int cus = device_cus() > 0 ? device_cus() : 256;
-  int cand[2] = {(M / rows) * rows, 0};
+  int cand[3] = {(M / rows) * rows, 0, 0};
   const long long tiles = (long long)((M + rows - 1) / rows) * tiles_n;
   if (tiles > cus) cand[1] = (int)((tiles / cus) * cus / tiles_n) * rows;  // the m-blocks that whole rounds cover
+  // ... and the whole rounds of 256 x 256 tiles, whatever shape the whole call was planned in (round 6: with the refitted rates 5000 tokens at the BASELINE layer are
+  // planned as 256 x 128 tiles -- five full rounds, 598 us by the model -- whose own candidates do not contain 4096 + 904: 545 us, measured 560 against 620)
+  const long long tiles256 = (long long)((M + 255) / 256) * ((N + 255) / 256);
+  if (tiles256 > cus) cand[2] = (int)((tiles256 / cus) * cus / ((N + 255) / 256)) * 256;
   int best_m0 = 0;
   double best = 0.93 * est_whole;
   qqq_tune_t tn = t;
   tn.split_m = -1;
-  for (int c = 0; c < 2; ++c) {
+  for (int c = 0; c < 3; ++c) {
     const int M0 = cand[c];
-    if (M0 <= 0 || M0 >= M || M - M0 > split_remainder_cap() || (c == 1 && M0 == cand[0])) continue;
+    if (M0 <= 0 || M0 >= M || M - M0 > split_remainder_cap() || (c >= 1 && M0 == cand[0]) || (c == 2 && M0 == cand[1])) continue;
     double e0 = -1.0, er = -1.0;
     (void)make_plan(M0, N, K, grouped, max_par, have_C, have_ws, tn, &e0);
     (void)make_plan(M - M0, N, K, grouped, max_par, have_C, have_ws, tn, &er);

@@ -275,7 +275,9 @@ def test_dispatch_of_the_baseline_sweep(L):
         p, g = _lib.plan(m, N, K, -1, 16), _lib.plan(m, N, K, 128, 16)
         # (round 5: with the 256 x 256 tiles' ring depth 8 and uneven slices two K slices of them overtook the 256 x 128 tiles at 1024 tokens: 133.8 vs 135.6 us,
         #  profiles/r05_m_split_refit.txt)
-        assert (p["kernel"], p["mt"], p["bm"], p["ksplit"]) == ((5, 8, 256, 1) if m == 640 else (5, 16, 128, 1) if m == 768 else (5, 16, 256, 2)), (m, p)
+        # (round 6, rates refitted on the rebuilt loop: 768 and 1024 tokens are the unsplit 128 x 256 tiles' as well -- 105.9 vs 107.7 us (256 x 128) at 768,
+        #  124.6 / 126.2 vs 128.7 / 127.9 (256 x 256 in two slices) at 1024: profiles/r06_dispatch_check_mid.txt, r06_dispatch_check_main.txt)
+        assert (p["kernel"], p["mt"], p["bm"], p["ksplit"]) == (5, 8, 256, 1), (m, p)
         assert (g["kernel"], g["mt"], g["bm"], g["ksplit"]) == (5, 16, 256, 2), (m, g)
     p = _lib.plan(1024, N, K, -1, 16, tune=dict(kernel=4, bm=256, mt=8, pw=2))  # the round-2 choice stays available
     assert (p["kernel"], p["bm"], p["mt"], p["pw"], p["ksplit"]) == (4, 256, 8, 2, 1), p
@@ -396,7 +398,7 @@ def test_uneven_k_slices_in_the_plan():
     # the wide kernel's two-slice split takes the same knob: 256 KiB deposits, ~20 us from last MFMA to "complete" -> 6 stages per-group at 1024 tokens
     # (173.1 -> 165.9 us, profiles/r05_uneven_k_slices_wide.txt), 7 for the 256 x 128 tiles per-channel at 384 / 512 tokens
     p = _lib.plan(1024, N, K, 128, 16)
-    assert (p["kernel"], p["ksplit"], p["skew"], p["fused"] & 64) == (5, 2, 6, 0), p
+    assert (p["kernel"], p["ksplit"], p["skew"], p["fused"] & 64) == (5, 2, 7, 0), p  # (round 6, rates refitted on the rebuilt loop: the same hand-off time is 7 of its shorter stages)
     # (round 6: tune.fused bit 64 = two slices of 256-column tiles EXCHANGE row halves -- even slices, the plan's fused field carries the bit; measured level, not the default)
     p = _lib.plan(1024, N, K, 128, 16, tune=dict(fused=64))
     assert (p["kernel"], p["ksplit"], p["skew"], p["fused"] & 64) == (5, 2, 0, 64), p

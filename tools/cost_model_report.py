@@ -75,5 +75,7 @@ def main(files):
 
 
 if __name__ == "__main__":
-    files = sys.argv[1:] or sorted(glob.glob(os.path.join(ROOT, "profiles", "r05_dispatch_check_*.txt")))
+    import dispatch_regret as R
+
+    files = sys.argv[1:] or R.grid_files()
     main(files)

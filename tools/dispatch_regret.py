@@ -17,6 +17,19 @@ FAMILY = {1: "stream", 2: "tiled", 3: "column", 4: "panel", 5: "wide"}
 WIDE = {(16, 256, 1): "wide", (16, 256, 2): "w16x2", (8, 256, 1): "w8", (16, 128, 1): "w128", (16, 128, 2): "w128x2"}
 
 
+def grid_files(root=ROOT):
+    """the committed dispatch grids, ONE file per grid name: the newest round's measurement of it (profiles/r06_dispatch_check_<name>.txt where round 6 measured the
+    grid again -- the seven grids that price the wide kernel, whose loop changed -- otherwise round 5's)"""
+    import glob
+
+    best = {}
+    for f in sorted(glob.glob(os.path.join(root, "profiles", "r0[5-9]_dispatch_check_*.txt"))):
+        m = re.match(r"r(\d+)_dispatch_check_(.*)\.txt", os.path.basename(f))
+        if m and (m.group(2) not in best or int(m.group(1)) > best[m.group(2)][0]):
+            best[m.group(2)] = (int(m.group(1)), f)
+    return [best[k][1] for k in sorted(best)]
+
+
 def column_of(plan, measured, M=0):
     """the dispatch_check column a plan corresponds to"""
     name = FAMILY[plan["kernel"]]

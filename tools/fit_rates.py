@@ -249,10 +249,12 @@ def fit_panel64(files):
 
 
 def main():
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r05_dispatch_check_*.txt")))
+    import dispatch_regret as R
+
+    files = R.grid_files()  # one file per grid: round 6's measurement where there is one (the wide kernel's grids), else round 5's
     data = collect(files)
     names = ("128-column strips, 32 columns per wave", "256-column strips, 32 columns per wave", "256-column strips, 64 columns per wave (128-token m-blocks only)")
-    lines = ["// qqq_rates.h -- GENERATED by tools/fit_rates.py from profiles/r05_dispatch_check_*.txt (%d files); do not edit by hand." % len(files),
+    lines = ["// qqq_rates.h -- GENERATED by tools/fit_rates.py from the newest profiles/r0N_dispatch_check_<grid>.txt of every grid (%d files); do not edit by hand." % len(files),
              "// panel kernel: us = rounds * (a + c * [ksplit > 1] + d * max(0, ksplit - 2) + b * stages per workgroup), rounds = ceil(workgroups / 256); per group: points, mean |error|, worst.",
              "#ifndef QQQ_AMD_QQQ_RATES_H_", "#define QQQ_AMD_QQQ_RATES_H_", "",
              "struct QqqPanelRate { double a, c, d, b; };", "// [shape][log2(16-token tiles per m-block)][per-group]", "static const QqqPanelRate kQqqPanelRates[3][4][2] = {"]
