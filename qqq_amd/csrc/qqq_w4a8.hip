@@ -743,7 +743,7 @@ static double panel_estimate(int M, int N, int K, bool grouped, bool have_scratc
 // Two K slices (256-token tiles): hand-off 15 us per 256 KiB of partial tile (kept in the XCD's L2 when its slices share one -- round 4 --,
 // folded by the last arrival; 20 us written through).
 // (w8: the call has the expanded int8 weights.  The loop is then the per-channel loop minus its unpack, with two more 16-byte
-//  loads per step: priced with the per-channel rates until it has a fit of its own; profiles/r06_w8_first_numbers.txt.)
+//  loads per step: priced like a per-channel call (load rule) with rates of its own -- the third column of kQqqWideRates, fitted from profiles/r06_w8_dispatch_check_main.txt.)
 static double wide_estimate(int M, int N, int K, bool grouped, bool have_scratch, long long cap_rows, long long cap_tickets, int* ks_out,
                             int* mt_out, int* bn_out, bool w8 = false) {
   *ks_out = 1;
@@ -760,7 +760,7 @@ static double wide_estimate(int M, int N, int K, bool grouped, bool have_scratch
     // (round 5: fixed / t_stage / hand-off per shape and mode from the GENERATED table qqq_rates.h -- tools/fit_rates.py, least squares over every forced wide variant of
     //  profiles/r05_dispatch_check_*.txt, 2.3 ... 3.9 % mean error per group; the hand-fitted values above -- 12 / 7 us, 1.25 / 0.70 / 0.725 us per stage, 15 us per
     //  256 KiB -- are the history: the uneven K slices took the hand-off to 11-12.6)
-    const QqqWideRate& wr = kQqqWideRates[shape][grouped ? 1 : 0];
+    const QqqWideRate& wr = kQqqWideRates[shape][w8 ? 2 : grouped ? 1 : 0];  // (round 6: calls that have expanded weights are priced from a fit of their own)
     const double t_stage = wr.t_stage;
     const double fixed = wr.fixed;
     for (int ks = 1; ks <= (mt == 16 ? 2 : 1); ++ks) {
@@ -821,7 +821,7 @@ static int stream_auto_skew(int N, int K, int ksplit) {
 static int wide_auto_skew(int mt, int bn, bool grouped, int NST, int ksplit, bool w8 = false) {
   (void)NST;
   if (w8) grouped = false;
-  const double t_stage = kQqqWideRates[(mt == 16 && bn == 256) ? 0 : (mt == 16) ? 1 : 2][grouped ? 1 : 0].t_stage;
+  const double t_stage = kQqqWideRates[(mt == 16 && bn == 256) ? 0 : (mt == 16) ? 1 : 2][w8 ? 2 : grouped ? 1 : 0].t_stage;
   const double latency = 20.0 * (16.0 * mt * bn) / 65536.0;
   const int sk = (int)(latency / (t_stage * ksplit / (ksplit - 1.0)) + 0.5);
   return sk < 1 ? 1 : sk;

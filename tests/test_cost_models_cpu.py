@@ -82,13 +82,13 @@ def test_rate_tables_are_what_the_tool_generates():
                 i += 1
     assert fitted == 18
     wrows = [tuple(float(v) for v in m) for m in re.findall(r"\{(-?[\d.]+), (-?[\d.]+), (-?[\d.]+)\}", wide_text)]
-    assert len(wrows) == 6
+    assert len(wrows) == 9  # (round 6: a third column, calls that have the layer's expanded int8 weights -- one grid of four layers)
     wide = F.collect_wide(files)
     for shape in range(3):
-        for gi, g in enumerate((False, True)):
+        for gi, g in enumerate((False, True, "w8")):
             coef, n, mae, bias, worst = F.fit_wide(wide[(shape, g)])
-            got = wrows[2 * shape + gi]
-            assert n >= 150 and mae < 0.05 and abs(coef[0] - got[0]) < 2e-3 and abs(coef[2] - got[2]) < 2e-4, (shape, g, coef, got, mae)
+            got = wrows[3 * shape + gi]
+            assert n >= (25 if g == "w8" else 150) and mae < (0.10 if g == "w8" else 0.05) and abs(coef[0] - got[0]) < 2e-3 and abs(coef[2] - got[2]) < 2e-4, (shape, g, coef, got, mae)
             if coef[1] != 0.0:
                 assert abs(coef[1] - got[1]) < 2e-3
     # the small-m forms of the column / stream kernels and the 64-token m-block form of the panel kernel (kQqqSmall), in the order of the initialiser

@@ -77,18 +77,22 @@ def wide_features(tl, ks, rows, bn, nst, grouped):
     return [rounds, rounds * (ks > 1) * rows * bn / 65536.0, rounds * nst / ks * load]
 
 
+W8_FILE = os.path.join(ROOT, "profiles", "r06_w8_dispatch_check_main.txt")  # the wide shapes on EXPANDED int8 weights (mode g128x): the third column of kQqqWideRates
+
+
 def collect_wide(files):
+    """{(shape, False | True | "w8"): [(features, measured us)]} -- per-channel / per-group from the grids, "w8" (calls that have the layer's expanded weights) from W8_FILE"""
     import dispatch_regret as R
     from qqq_amd import _lib
 
     data = {}
-    for f in files:
+    for f in list(files) + [W8_FILE]:
         for line in open(f):
             m = R.LINE.match(line)
             if not m or "w16x2" not in line:
                 continue
             N, K, mode, M = int(m.group(1)), int(m.group(2)), m.group(3), int(m.group(4))
-            if K % 128:
+            if K % 128 or (mode == "g128x") != (f == W8_FILE):
                 continue
             cells = m.group(8).split("<--")[0].split()
             meas = {cells[i]: float(cells[i + 1]) for i in range(0, len(cells) - 1, 2)}
@@ -96,13 +100,15 @@ def collect_wide(files):
                 v = meas.get(col)
                 if v is None or v != v:
                     continue
-                p = _lib.plan(M, N, K, 128 if mode == "g128" else -1, 16, tune=tune)
-                if p["kernel"] != 5 or p["glds"] == 2 or (col.endswith("x2") and p["ksplit"] != 2):
+                w8 = mode == "g128x"
+                p = _lib.plan(M, N, K, -1 if mode == "pc" else 128, 16, tune=dict(tune, w8=1) if w8 else tune)
+                if p["kernel"] != 5 or p["glds"] == 2 or (col.endswith("x2") and p["ksplit"] != 2) or (w8 and not p["w8"]):
                     continue
                 rows, bn, ks = 16 * p["mt"], p["bm"], p["ksplit"]
                 tl = ((M + rows - 1) // rows) * ((N + bn - 1) // bn)
                 shape = 0 if (p["mt"] == 16 and bn == 256) else 1 if p["mt"] == 16 else 2
-                data.setdefault((shape, mode == "g128"), []).append((wide_features(tl, ks, rows, bn, K // 128, mode == "g128"), v))
+                # (expanded weights: wide_estimate prices the call like a per-channel one -- the loop has no re-quantiser -- with this column's rates)
+                data.setdefault((shape, "w8" if w8 else mode == "g128"), []).append((wide_features(tl, ks, rows, bn, K // 128, mode == "g128"), v))
     return data
 
 
@@ -279,20 +285,22 @@ def main():
     wide = collect_wide(files)
     wnames = ("256 x 256 tiles", "256 x 128 tiles (32 columns per wave)", "128 x 256 tiles")
     lines += ["// wide kernel: us = 3.7 + rounds * (fixed + handoff * [ksplit > 1] * tile KiB / 256 + stages per workgroup * t_stage * load); rounds / load: wide_estimate (qqq_w4a8.hip)",
-              "struct QqqWideRate { double fixed, handoff, t_stage; };", "// [shape][per-group]", "static const QqqWideRate kQqqWideRates[3][2] = {"]
+              "struct QqqWideRate { double fixed, handoff, t_stage; };", "// [shape][per-channel, per-group, expanded int8 weights (profiles/r06_w8_dispatch_check_main.txt)]",
+              "static const QqqWideRate kQqqWideRates[3][3] = {"]
     fitted = {}
     for shape in range(3):
-        for g in (False, True):
+        for g in (False, True, "w8"):
             fitted[(shape, g)] = fit_wide(wide[(shape, g)])
+    label = {False: "per-channel", True: "per-group", "w8": "expanded"}
     for shape in range(3):
         cells = []
-        for g in (False, True):
+        for g in (False, True, "w8"):
             coef, n, mae, bias, worst = fitted[(shape, g)]
             if coef[1] == 0.0:
                 coef = np.array([coef[0], fitted[(1, g)][0][1], coef[2]])  # (never measured split)
-            cells.append("{%.3f, %.3f, %.4f}  /* %s: %d points, %.1f %%, %.0f %% */" % (coef[0], coef[1], coef[2], "per-group" if g else "per-channel", n, 100 * mae, 100 * worst))
-            print(f"wide shape {shape} {'g128' if g else 'pc  '} n={n:4d}  fixed={coef[0]:6.2f} handoff={coef[1]:5.2f} t_stage={coef[2]:.4f}   mean |err| {100 * mae:4.1f}%  bias {100 * bias:+4.1f}%  worst {100 * worst:4.1f}%")
-        lines.append("    {%s,\n     %s},  // %s" % (cells[0], cells[1], wnames[shape]))
+            cells.append("{%.3f, %.3f, %.4f}  /* %s: %d points, %.1f %%, %.0f %% */" % (coef[0], coef[1], coef[2], label[g], n, 100 * mae, 100 * worst))
+            print(f"wide shape {shape} {label[g]:11s} n={n:4d}  fixed={coef[0]:6.2f} handoff={coef[1]:5.2f} t_stage={coef[2]:.4f}   mean |err| {100 * mae:4.1f}%  bias {100 * bias:+4.1f}%  worst {100 * worst:4.1f}%")
+        lines.append("    {%s,\n     %s,\n     %s},  // %s" % (cells[0], cells[1], cells[2], wnames[shape]))
     lines += ["};", ""]
     small = fit_small(files)
 
