@@ -896,7 +896,13 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
       const long long cap_tk = have_ws ? (long long)(N / 128) * (max_par > 0 ? max_par : 0) : 0;
       int pbn = 128, pks = 1, pcw = 1, pmt = 0;
       const double e_panel = ((long long)(M + 127) / 128 <= 65535) ? panel_estimate(M, N, K, grouped, have_scratch && have_ws, cap_rows, cap_tk, &pbn, &pks, &pcw, &pmt) : 1e30;
-      const double e_stream = (M <= 256) ? stream_estimate(M, N, K, grouped, have_scratch, cap_rows) : 1e30;
+      // (round 6: above 64 tokens the stream kernel is a candidate only where its GENERATED form prices it -- 2 ... 4 m-blocks on layers up to ~40 MB, kQqqSmall.stmid.  The
+      //  regime beyond -- larger layers, five m-blocks and more -- was the last hand-fitted branch of the dispatcher (stream_estimate below its first return); in the 48 points of it
+      //  that the committed grids measured the stream kernel is never more than 3 % ahead of the best panel / wide shape, and the plan never chose it: out of the automatic path.
+      //  tune.kernel = 1 still runs it; qqq_w4a8_model_us still prices it.)
+      const int s_mblocks = (M + 63) / 64;
+      const bool stream_candidate = s_mblocks == 1 || (s_mblocks <= 4 && (double)N * K / 2.0 / 5.0e6 < 8.0);
+      const double e_stream = (M <= 256 && stream_candidate) ? stream_estimate(M, N, K, grouped, have_scratch, cap_rows) : 1e30;
       // (the tiled family -- round 1's LDS-tiled 32x32x32 kernel -- is no longer a candidate of the automatic dispatch: in the 903 measured
       // dispatch points of round 4 it never won one (M = 4096: 585.9 vs 449.2 us).  It stays reachable through tune.kernel = 2 -- the
       // differential fuzzers' independent reference -- and as the fallback for packed weights beyond 4 GB, where the wide kernel's 32-bit
