@@ -15,11 +15,25 @@
 // MFMA D: lane l holds column j = l & 15 (token) and rows i = 4*(l >> 4) + r, r = 0..3, i.e.
 //     g = l >> 5, c = 4*((l >> 4) & 1) + r  ->  4 consecutive n.
 
+// QQQ_STREAM_LINES (round 6): whole-line weight loads.  In the mapping above a lane owns a whole 64-byte chunk (4 loads of 16 bytes at a 64-byte stride between lanes): every
+// 128-byte line of the weight stream is touched by FOUR wave instructions, which is why non-temporal loads LOSE 11 % here while they gave the column kernel 10 %.  With
+// LINES the wave loads like four column-kernel waves: load j (0 .. 3) of lane (h = l >> 4, cq = (l >> 2) & 3, q4 = l & 3) is the 16 bytes of piece q4 of chunk 4 (j & 1) + cq
+// of 64-column group j >> 1 -- 256 contiguous bytes (two whole lines) per k-tile row and instruction, each line exactly once -- and a 4 x 4 quad transpose per load
+// (quad_transpose4, as in the column kernel) hands MFMA lane (h, cq, jt = q4) the words kq = 0 .. 3 of its (chunk, jt): the A operand of MFMA (j, b) with rows i = 4 cq + jt,
+// i.e. columns n = 128 strip + 64 (j >> 1) + 16 jt + 8 b + 4 (j & 1) + cq.  D lane l holds rows 4 (l >> 4) + r: cq = l >> 4 of the OUTPUT lane, jt = r -- four consecutive
+// n sit in the four lanes token + 16 cq (the column kernel's write-out).  The loads are non-temporal (QQQ_W_NT bit 1 selects them for this mapping).
+// Built, bit-exact (28 GPU tests on the build), measured cold against the mapping above (profiles/r06b_stream_whole_line_loads.txt): N = 8192, K = 21760 per-channel
+// 16 / 32 / 48 tokens -2 ... -3 %, 64 tokens +1.5 %; per-group 16 tokens +13 %, 64 tokens +7 %; the Llama-2-7B layers +2 ... +11 % -- four quad transposes per step cost more
+// VALU time than the non-temporal loads give back wherever the launch is not purely HBM-bound.  Off.
+#ifndef QQQ_STREAM_LINES
+#define QQQ_STREAM_LINES 0
+#endif
+
 template <int MT>
 struct StreamStep {
   v4u w[4];   // w[kq][jt]
   v4i x[MT];  // activation operands
-  h8 sc;      // per-group scales [2*jt + b]
+  h8 sc;      // per-group scales [2*jt + b]  (LINES: [2*j + b] of this lane's (chunk, jt), load by load)
 };
 
 template <int MT, bool GROUPED, int WAVES, int PF>
@@ -54,7 +68,11 @@ __global__ __launch_bounds__(WAVES * 64) void qqq_stream_kernel(
   int ng = strip * 2 + g;
   if (ng >= ngroups) ng = ngroups - 1;  // clamp (N % 128 == 64): loads stay legal, output dropped
   const size_t rowbytes = (size_t)N * 8;
-  const unsigned char* bptr = B + (size_t)h * rowbytes + (size_t)ng * 512 + c * 64;
+  constexpr bool LINES = QQQ_STREAM_LINES != 0;
+  const int cq = (lane >> 2) & 3, q4 = lane & 3;  // LINES: chunk within the load's four, piece as a load lane / jt as an MFMA lane
+  int ngl[2] = {strip * 2, strip * 2 + 1};        // LINES: the strip's two 64-column groups (loads 0, 1 / 2, 3)
+  if (ngl[1] >= ngroups) ngl[1] = ngroups - 1;
+  const unsigned char* bptr = LINES ? B + (size_t)h * rowbytes + cq * 64 + q4 * 16 : B + (size_t)h * rowbytes + (size_t)ng * 512 + c * 64;
 
   const int8_t* xptr[MT];
 #pragma unroll
@@ -63,7 +81,7 @@ __global__ __launch_bounds__(WAVES * 64) void qqq_stream_kernel(
     if (row >= M) row = M - 1;
     xptr[mt] = A + (size_t)row * K + 16 * h;
   }
-  const _Float16* sptr = GROUPED ? (s3 + (size_t)ng * 64 + c * 8) : nullptr;
+  const _Float16* sptr = GROUPED ? (LINES ? s3 + cq * 8 + 2 * q4 : s3 + (size_t)ng * 64 + c * 8) : nullptr;
 
   const int KS = K >> 6;  // 64-k steps
   const int KSE = KS - skew;  // uneven slices (skew > 0): the last one is longer -- it arrives last and finds the other deposits complete
@@ -81,17 +99,62 @@ __global__ __launch_bounds__(WAVES * 64) void qqq_stream_kernel(
 
   auto load_step = [&](const int s, StreamStep<MT>& r) {
     const unsigned char* p = bptr + (size_t)(4 * s) * rowbytes;
+    if constexpr (LINES) {
 #pragma unroll
-    for (int kq = 0; kq < 4; ++kq) {
-      if constexpr ((QQQ_W_NT & 2) != 0) r.w[kq] = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(p + 16 * kq));  // streamed once
-      else r.w[kq] = *reinterpret_cast<const v4u*>(p + 16 * kq);
+      for (int j = 0; j < 4; ++j) {  // w[j]: load j -- group j >> 1, chunks 4 (j & 1) .. + 3: two whole lines per k-tile row
+        const unsigned char* pj = p + (size_t)ngl[j >> 1] * 512 + (j & 1) * 256;
+        if constexpr ((QQQ_W_NT & 1) != 0) r.w[j] = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(pj));  // streamed once, every line by one instruction
+        else r.w[j] = *reinterpret_cast<const v4u*>(pj);
+      }
+    } else {
+#pragma unroll
+      for (int kq = 0; kq < 4; ++kq) {
+        if constexpr ((QQQ_W_NT & 2) != 0) r.w[kq] = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(p + 16 * kq));  // streamed once
+        else r.w[kq] = *reinterpret_cast<const v4u*>(p + 16 * kq);
+      }
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) r.x[mt] = *reinterpret_cast<const v4i*>(xptr[mt] + 64 * s);
-    if constexpr (GROUPED) r.sc = *reinterpret_cast<const h8*>(sptr + (size_t)(s >> 1) * N);
+    if constexpr (GROUPED && LINES) {
+      const _Float16* ps = sptr + (size_t)(s >> 1) * N;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const h2 v = *reinterpret_cast<const h2*>(ps + (size_t)ngl[j >> 1] * 64 + (j & 1) * 32);
+        r.sc[2 * j] = v[0];
+        r.sc[2 * j + 1] = v[1];
+      }
+    } else if constexpr (GROUPED) {
+      r.sc = *reinterpret_cast<const h8*>(sptr + (size_t)(s >> 1) * N);
+    }
   };
 
   auto compute_step = [&](const StreamStep<MT>& r) {
+    if constexpr (LINES) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        unsigned y[4];
+        quad_transpose4(r.w[j], y);  // y[kq] (lane q4 = jt) = word jt of piece kq of this lane's chunk
+        h2 sb0 = {(_Float16)0, (_Float16)0}, sb1 = sb0;
+        if constexpr (GROUPED) {
+          sb0 = (h2){r.sc[2 * j], r.sc[2 * j]};
+          sb1 = (h2){r.sc[2 * j + 1], r.sc[2 * j + 1]};
+        }
+        v4i a0, a1;
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) {
+          int w0, w1;
+          unpack_pair<GROUPED>(y[kq], sb0, sb1, w0, w1);
+          a0[kq] = w0;
+          a1[kq] = w1;
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          acc[mt][j][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, r.x[mt], acc[mt][j][0], 0, 0, 0);
+          acc[mt][j][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, r.x[mt], acc[mt][j][1], 0, 0, 0);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) {
       v4i a0, a1;
@@ -187,12 +250,24 @@ __global__ __launch_bounds__(WAVES * 64) void qqq_stream_kernel(
   }
 
   // ---- write out: item = (q = (mt, jt, b), lane) -> 4 consecutive n of one token ----
+  // (LINES: item = (q = (mt, j, b), jt, token) as in the column kernel: the 4 consecutive n of a token sit in the lanes token + 16 cq of red[(q * 4 + jt) * 64 ..])
   auto item_coords = [&](const int it, int& m, int& n) {
     const int q = it >> 6, ln = it & 63;
     const int mt = q >> 3, jt = (q >> 1) & 3, b = q & 1;
     const int qd = ln >> 4;
     m = mbase + 16 * mt + (ln & 15);
-    n = strip * 128 + 64 * (qd >> 1) + 16 * jt + 8 * b + 4 * (qd & 1);
+    if constexpr (LINES) n = strip * 128 + 64 * (jt >> 1) + 16 * qd + 8 * b + 4 * (jt & 1);  // (the q field called jt above is the load index j here; qd = the item's jt)
+    else n = strip * 128 + 64 * (qd >> 1) + 16 * jt + 8 * b + 4 * (qd & 1);
+  };
+  auto item_vals = [&](const int it) -> v4i {
+    const int q = it >> 6, ln = it & 63;
+    if constexpr (LINES) {
+      const int* rp = &red[(q * 4 + (ln >> 4)) * 64 + (ln & 15)];
+      return (v4i){rp[0], rp[16], rp[32], rp[48]};
+    } else {
+      const int* rp = &red[(q * 4) * 64 + ln];
+      return (v4i){rp[0], rp[64], rp[128], rp[192]};
+    }
   };
 
   if (ksplit == 1) {
@@ -200,9 +275,8 @@ __global__ __launch_bounds__(WAVES * 64) void qqq_stream_kernel(
       int m, n;
       item_coords(it, m, n);
       if (m < M && n < N) {
-        const int q = it >> 6, ln = it & 63;
-        const int* rp = &red[(q * 4) * 64 + ln];
-        epilogue_store4(rp[0], rp[64], rp[128], rp[192], m, n, N, s1[m], s2, D, acc_out, bias);
+        const v4i v = item_vals(it);
+        epilogue_store4(v[0], v[1], v[2], v[3], m, n, N, s1[m], s2, D, acc_out, bias);
       }
     }
     return;
@@ -224,9 +298,7 @@ __global__ __launch_bounds__(WAVES * 64) void qqq_stream_kernel(
     int32_t* slots = C + tile * (size_t)(ksplit - 1) * SLOT_INTS;
     if (t < ksplit - 1) {
       for (int it = tid; it < NQ * 64; it += WAVES * 64) {
-        const int q = it >> 6, ln = it & 63;
-        const int* rp = &red[(q * 4) * 64 + ln];
-        const v4i v = {rp[0], rp[64], rp[128], rp[192]};
+        const v4i v = item_vals(it);
         int32_t* dst = slots + (size_t)t * SLOT_INTS + (size_t)it * 4;
         asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
       }
@@ -246,9 +318,7 @@ __global__ __launch_bounds__(WAVES * 64) void qqq_stream_kernel(
     for (int it = tid; it < NQ * 64; it += WAVES * 64) {
       int m, n;
       item_coords(it, m, n);
-      const int q = it >> 6, ln = it & 63;
-      const int* rp = &red[(q * 4) * 64 + ln];
-      v4i sum = {rp[0], rp[64], rp[128], rp[192]};
+      v4i sum = item_vals(it);
       const unsigned off = (unsigned)it * 16u;
       for (int p0 = 0; p0 < ksplit - 1; p0 += 4) {  // four slots in flight; surplus loads re-read the last slot, only the add is skipped
         v4i d[4];
@@ -269,9 +339,7 @@ __global__ __launch_bounds__(WAVES * 64) void qqq_stream_kernel(
     int m, n;
     item_coords(it, m, n);
     if (m < M && n < N) {
-      const int q = it >> 6, ln = it & 63;
-      const int* rp = &red[(q * 4) * 64 + ln];
-      v4i v = {rp[0], rp[64], rp[128], rp[192]};
+      v4i v = item_vals(it);
       int32_t* dst = C + ((size_t)sp * M + m) * N + n;
       *reinterpret_cast<v4i*>(dst) = v;
     }
