@@ -98,7 +98,8 @@ typedef struct qqq_tune {
                   (the walk for K <= 8192 when there is more than one 256 x 256 tile per CU)                      */
   int pf;      /* stream: prefetch depth in 4 KiB steps per wave (3, 5, 7); column: 1 KiB steps per wave
                   (2..12); panel: weight ring depth in 128-k stages (2, 3, 4; 8 for mt <= 4); wide: weight ring depth in
-                  64-k steps (4, 8); 0 auto (wide, 256 x 256 tiles: 8 per-channel, 4 per-group; other shapes 4 / 8) */
+                  64-k steps -- 4 since round 6 whatever is asked (the packed weights come in as one-word loads, 8 per step: 8 steps
+                  would pass the 63 loads a wave can have in flight; -DQQQ_WIDE_DWORD=0 builds take 4 or 8) */
   int stages;  /* tiled + LDS-DMA: ring depth 2..7 (0 auto); panel: activation lead in stages -- with pf = 4 it is 2
                   unless 4 is asked for, otherwise it equals pf */
   int mt;      /* stream: 16-token tiles per workgroup (1..4); column: 1..2; panel: 1, 2, 4, 8; wide: 16, 8; 0 auto */

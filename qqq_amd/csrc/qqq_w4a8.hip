@@ -491,9 +491,10 @@ static hipError_t launch_wide_chain(const LaunchArgs& a, int mode, int mt, int b
   // (expanded weights: ring of 4 steps -- 64 registers; with 8 the walk's seam spills inside the stage loop: 32 registers, 75 scratch instructions)
   if (mode == 2) return launch_wide_t<2, 16, 4, 4, 2, true>(a, pw, 1);
   const bool grouped = mode == 1;
-  if (bn == 128) return grouped ? launch_wide_t<1, 16, 4, 8, 1, true>(a, pw, 1) : launch_wide_t<0, 16, 4, 4, 1, true>(a, pw, 1);
-  if (mt == 8) return grouped ? launch_wide_t<1, 8, 4, 8, 2, true>(a, pw, 1) : launch_wide_t<0, 8, 4, 4, 2, true>(a, pw, 1);
-  return grouped ? launch_wide_t<1, 16, 4, 8, 2, true>(a, pw, 1) : launch_wide_t<0, 16, 4, 4, 2, true>(a, pw, 1);
+  constexpr int GRS = QQQ_WIDE_DWORD != 0 ? 4 : 8;  // per-group ring depth of the walk (dword weight loads: 8 loads per step -- a ring of 8 steps would pass vmcnt's 63)
+  if (bn == 128) return grouped ? launch_wide_t<1, 16, 4, GRS, 1, true>(a, pw, 1) : launch_wide_t<0, 16, 4, 4, 1, true>(a, pw, 1);
+  if (mt == 8) return grouped ? launch_wide_t<1, 8, 4, GRS, 2, true>(a, pw, 1) : launch_wide_t<0, 8, 4, 4, 2, true>(a, pw, 1);
+  return grouped ? launch_wide_t<1, 16, 4, GRS, 2, true>(a, pw, 1) : launch_wide_t<0, 16, 4, 4, 2, true>(a, pw, 1);
 }
 // Automatic choice (profiles/r04_tile_walk_sweep.txt: plain vs walk over nine layer shapes x five token counts x both modes).
 // A seam costs 5.5 us (per-group 7) where the plain grid pays 9 us between two tiles of a CU (epilogue 6.3 + relaunch 0.2 +
@@ -954,6 +955,7 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
     const bool big_tile = (pl.mt == 16 && pl.bm == 256);
     pl.w8 = have_w8 ? 1 : 0;
     pl.pf = pl.w8 ? 4 : (t.pf == 8 || t.pf == 4) ? t.pf : (big_tile ? (grouped ? 4 : 8) : (grouped ? 8 : 4));
+    if (QQQ_WIDE_DWORD != 0 && !pl.w8) pl.pf = 4;  // (dword weight loads: 8 loads per step -- a ring of 8 steps would pass vmcnt's 63)
     pl.pw = (t.pw == 4 || t.pw == 8 || t.pw == 16 || t.pw == 32) ? t.pw : 8;
     const int rows = 16 * pl.mt;
     const long long tl = (long long)((M + rows - 1) / rows) * ((N + pl.bm - 1) / pl.bm);
@@ -981,7 +983,7 @@ static Plan make_plan(const int M, const int N, const int K, const bool grouped,
     // the persistent tile walk (t.glds: 1 = never, 2 = whenever it applies, 0 = automatic); its ring depth is the mode's default
     pl.chain = (t.glds != 1 && wide_chain_ok(M, N, K, rows, pl.bm, ksplit) && (t.glds == 2 || wide_chain_pays(tl, K, pl.mt, pl.bm))) ? 1 : 0;
     if (pl.chain && pl.w8 && !big_tile) pl.chain = 0;  // (the walk over expanded weights is instantiated for 256 x 256 tiles only)
-    if (pl.chain) pl.pf = pl.w8 ? 4 : grouped ? 8 : 4;
+    if (pl.chain) pl.pf = pl.w8 ? 4 : (grouped && QQQ_WIDE_DWORD == 0) ? 8 : 4;
     return pl;
   }
 

@@ -92,6 +92,43 @@ __device__ __forceinline__ v4u wide_load16(__amdgpu_buffer_rsrc_t view, const un
 // HW = 1 (32 columns per wave, 256 x 128 tiles): every ODD slot re-reads a fragment, so everything else sits in even ones.
 __host__ __device__ constexpr bool wide_frag_slot(int hw, int k) { return k % (2 * hw) == 2 * hw - 1; }
 __host__ __device__ constexpr bool wide_refill_slot(int hw, int k, int hf) { return hf < hw && k == 2 + 4 * hf; }
+// QQQ_WIDE_DWORD (round 6): the packed weights of a step come in as FOUR 4-byte loads per lane and 32-column half instead of one 16-byte load + a 4 x 4 quad transpose:
+// MFMA lane (h, cq, jt) needs the words jt of the pieces kq = 0 .. 3 of its chunk, i.e. the dwords at chunk + 16 kq + 4 jt -- load kq fetches exactly that (a quad of lanes
+// takes 16 contiguous bytes; the four loads of a half touch the same lines, the first brings them into the L1).  13 issue slots' worth of transpose (4 VCC writes, 8 DPP
+// selects, in a loop that is issue-bound wherever it is not power-bound: per-group everywhere, per-channel in the 128-token / 128-column shapes) against 3 more loads.
+// The loads of a step sit one per slot (wide_dw_load_index); ring of 4 steps only (8 steps x 8 loads would pass vmcnt's 63).
+// Measured (profiles/r06b_wide_dword_loads.txt, interleaved A/B): 4096 tokens 427 - 435 -> 422 - 427 us, 1024 tokens (128 x 256 tiles) 123.5 - 124.5 -> 119.1, 320 ... 768 -1 ... -2 %,
+// per-group 4096 -2 %, 512 -2.5 %; Llama-2-7B layers level ... -2.5 %; no point slower.  Loop: 1.38 -> 1.09 extras per MFMA per-channel, 3.2 -> 2.9 per-group, 2.5 -> 1.8 in the
+// 128-token shape.  On.
+#ifndef QQQ_WIDE_DWORD
+#define QQQ_WIDE_DWORD 1
+#endif
+__host__ __device__ constexpr bool wide_dw(int mode) { return QQQ_WIDE_DWORD != 0 && mode != 2; }
+__host__ __device__ constexpr int wide_dw_load_index(int mt, int hw, int k) {  // DWORD: the load 4 hf + kq that slot k issues; -1: none
+  if (hw == 2) {
+    if (mt == 8) {  // (128-token tiles, 32 slots: slot 30 is the stage's wait + barrier, and the ring cursor needs a plain slot behind the last load)
+      constexpr int at[8] = {2, 5, 6, 10, 14, 18, 22, 26};
+      for (int i = 0; i < 8; ++i)
+        if (at[i] == k) return i;
+      return -1;
+    }
+    return (k % 4 == 2 && k <= 30) ? (k - 2) / 4 : -1;
+  }
+  return k == 2 ? 0 : k == 8 ? 1 : k == 10 ? 2 : k == 16 ? 3 : -1;
+}
+// the ring load(s) of slot k in any mode: >= 0 an index (packed: the half hf; DWORD: 4 hf + kq; expanded: the column set), -1 none
+__host__ __device__ constexpr int wide_ring_load(int mode, int mt, int hw, int k) {
+  if (mode == 2) return k % ((2 * hw * mt) / (2 * hw)) == 2 ? k / ((2 * hw * mt) / (2 * hw)) : -1;
+  if (wide_dw(mode)) return wide_dw_load_index(mt, hw, k);
+  return wide_refill_slot(hw, k, 0) ? 0 : wide_refill_slot(hw, k, 1) ? 1 : -1;
+}
+__host__ __device__ constexpr int wide_ring_last_slot(int mode, int mt, int hw, int hf) {  // the slot that issues the LAST load of half hf of a step (packed modes)
+  if (!wide_dw(mode)) return 2 + 4 * hf;
+  int last = 0;
+  for (int k = 0; k < 2 * hw * mt; ++k)
+    if (wide_dw_load_index(mt, hw, k) == 4 * hf + 3) last = k;
+  return last;
+}
 __host__ __device__ constexpr int wide_dma_period(int mt, int hw) { return (2 * hw * mt) / (mt / 4); }  // slots per DMA chunk: 16 / 8
 __host__ __device__ constexpr bool wide_m0_slot(int mt, int hw, int k) { return k % wide_dma_period(mt, hw) == (hw == 2 ? 8 : 4); }
 __host__ __device__ constexpr bool wide_dma_slot(int mt, int hw, int k) { return k % wide_dma_period(mt, hw) == (hw == 2 ? 9 : 6); }
@@ -130,7 +167,7 @@ __host__ __device__ constexpr int wide_w8_refill_index_(int mt, int hw, int k) {
 __host__ __device__ constexpr bool wide_plain_slot(int mode, int mt, int hw, int k) {  // no load, no fragment re-read, no M0 write in this slot
   if (k < 0 || k >= 2 * hw * mt) return false;
   if (wide_frag_slot(hw, k) || wide_dma_slot(mt, hw, k) || wide_m0_slot(mt, hw, k)) return false;
-  if (mode == 2 ? wide_w8_refill_index_(mt, hw, k) >= 0 : (wide_refill_slot(hw, k, 0) || wide_refill_slot(hw, k, 1))) return false;
+  if (wide_ring_load(mode, mt, hw, k) >= 0) return false;
   if (mode == 1 && k == wide_scale_slot(hw)) return false;
   return true;
 }
@@ -153,7 +190,7 @@ __host__ __device__ constexpr int wide_plain_after(int mode, int mt, int hw, int
 __host__ __device__ constexpr int wide_ring_inc_slot(int mode, int mt, int hw) {
   int last = 0;
   for (int k = 0; k < 2 * hw * mt; ++k)
-    if (mode == 2 ? wide_w8_refill_index_(mt, hw, k) >= 0 : (wide_refill_slot(hw, k, 0) || wide_refill_slot(hw, k, 1))) last = k;
+    if (wide_ring_load(mode, mt, hw, k) >= 0) last = k;
   return wide_plain_after(mode, mt, hw, last, 1);
 }
 __host__ __device__ constexpr int wide_dma_inc_slot(int, int, int) { return 0; }  // (slot 0 carries no load, no fragment re-read and no M0 write in any shape)
@@ -208,8 +245,9 @@ __host__ __device__ constexpr int wide_bal_cap(int mode, int mt, int hw, int t, 
   }
   return c < 0 ? 0 : c;
 }
-__host__ __device__ constexpr int wide_bal_items(int mode) { return 13 + (mode == 1 ? 32 : 12); }  // per 32-column half: wait, 4 x (VCC write, 2 selects), unpack parts
-__host__ __device__ constexpr int wide_bal_cost(int mode, int w) { return w < 13 ? 1 : (mode == 1 ? 2 : 1); }  // instructions of item w of a half
+__host__ __device__ constexpr int wide_bal_head(int mode) { return wide_dw(mode) ? 1 : 13; }  // per 32-column half: the ring wait, then (unless DWORD) 4 x (VCC write, 2 selects)
+__host__ __device__ constexpr int wide_bal_items(int mode) { return wide_bal_head(mode) + (mode == 1 ? 32 : 12); }  // ... then the unpack parts
+__host__ __device__ constexpr int wide_bal_cost(int mode, int w) { return w < wide_bal_head(mode) ? 1 : (mode == 1 ? 2 : 1); }  // instructions of item w of a half
 // number of items (of the hw * wide_bal_items(mode) of a step, in order) dealt to slots [0, k): item i goes to the first slot whose cumulative share of the capacity
 // reaches the item's cumulative share of the instructions
 __host__ __device__ constexpr int wide_bal_before(int mode, int mt, int hw, int t, int k, bool cursors) {
@@ -278,7 +316,7 @@ __host__ __device__ constexpr int wide_w8_refill_index(int mt, int hw, int k) { 
 __host__ __device__ constexpr int wide_loads_in_slot(int mode, int mt, int hw, int t, int k) {
   int n = 0;
   if (mode == 1 && t == 1 && k == wide_scale_slot(hw) && !(QQQ_WIDE_ABLATE & 8)) n += 2;            // the group scales of stage i + P
-  if (mode != 2 && (wide_refill_slot(hw, k, 0) || wide_refill_slot(hw, k, 1)) && !(QQQ_WIDE_ABLATE & 8)) n += 1;  // weight-ring refill
+  if (mode != 2 && wide_ring_load(mode, mt, hw, k) >= 0 && !(QQQ_WIDE_ABLATE & 8)) n += 1;  // weight-ring refill
   if (mode == 2 && wide_w8_refill_index(mt, hw, k) >= 0 && !(QQQ_WIDE_ABLATE & 8)) n += 1;
   if (wide_dma_slot(mt, hw, k) && !(QQQ_WIDE_ABLATE & 2)) n += 1;                                  // one activation chunk per lane
   return n;
@@ -598,6 +636,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int q = 0; q < NQ; ++q) acc[mt][q] = (v4i){0, 0, 0, 0};
 
   v4u wr[RS][WRN];
+  constexpr bool DW = wide_dw(MODE);
+  static_assert(!DW || QQQ_WIDE_BALANCE != 0, "the dword loads are scheduled by the balanced slot plan");
+  unsigned wq[DW ? RS : 1][HW][4];  // DWORD: the ring as words [step][half][kq] -- word jt (this lane's) of piece kq of the lane's chunk
+  const unsigned woff_dw = (unsigned)h * rowbytes + (unsigned)(cq * 64 + q4 * 4 + 256 * whalf);  // + step * wstep (scalar) + 256 hf + 16 kq (immediate)
+  auto asm_load_d = [&](unsigned& dst, auto ic, unsigned so, auto rawc) __attribute__((always_inline)) {  // load index 4 hf + kq; rawc: `so` is a cursor (no copy)
+    constexpr int li = decltype(ic)::value;
+    (void)woff_dw, (void)wdesc;
+    if constexpr (!decltype(rawc)::value) {
+      so = __builtin_amdgcn_readfirstlane(so);
+      asm("" : "+s"(so));
+    }
+    asm volatile("buffer_load_dword %0, %1, %2, %3 offen offset:%4" : "=v"(dst) : "v"(woff_dw), "s"(wdesc), "s"(so), "n"(256 * (li / 4) + 16 * (li % 4)));
+  };
+  auto load_d_step = [&](const unsigned so, unsigned (&dst)[HW][4]) __attribute__((always_inline)) {  // all of a step's words (prologue)
+    qqq_static_for<4 * HW>([&](auto ic) { asm_load_d(dst[decltype(ic)::value / 4][decltype(ic)::value % 4], ic, so, std::false_type{}); });
+  };
   unsigned scr[GROUPED ? P : 1][2];  // group scales (two fp16 each) of P stages, as loaded
   v4i x[MT];     // activation fragments of the current step; x[mt] is re-read for the next step right behind its last MFMA
   v4i aop[2][NQ]; // weight operands [set][2 * hf + b]: the current step's and the next step's
@@ -686,7 +740,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       sb[1] = (h2){sc[1], sc[1]};
     }
   };
-  auto un_part = [&](auto pc, auto hfc, v4i (&a)[NQ]) {
+  auto un_part = [&](auto pc, auto hfc, v4i (&a)[NQ], const unsigned (&y)[4]) {  // y: the half's four words (the transpose's output, or -- DWORD -- the ring registers themselves)
     constexpr int pi = decltype(pc)::value, hf = decltype(hfc)::value;
     if constexpr (GROUPED) {
       // the two re-quantisations of a packed word (b = 0, 1) run in lock step: part p of b = 0, then part p of b = 1 -- a
@@ -803,18 +857,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           constexpr int it = lo + decltype(jc)::value;
           constexpr int hf = it / PER, w_ = it % PER;
           if constexpr (w_ == 0) {
-            // ring slot sn, half hf: loaded RS - 1 steps ago at slot 2 + 4 hf; everything older (the group scales of this stage among it) has landed once at
-            // most the loads issued since are outstanding (vmcnt is a 6-bit counter: a deeper ring than 63 loads waits a little early, never late)
-            constexpr int younger_all = wide_loads_between(MODE, MT, HW, (t + RS - 1) & 1, 2 + 4 * hf, RS - 1, k);
+            // ring slot sn, half hf: loaded RS - 1 steps ago, its last load at slot wide_ring_last_slot (2 + 4 hf; DWORD: the half's fourth word); everything older (the
+            // group scales of this stage among it) has landed once at most the loads issued since are outstanding (vmcnt is a 6-bit counter: more than 63 loads waits a little early, never late)
+            constexpr int younger_all = wide_loads_between(MODE, MT, HW, (t + RS - 1) & 1, wide_ring_last_slot(MODE, MT, HW, hf), RS - 1, k);
             constexpr int younger = younger_all < 63 ? younger_all : 63;
-            if constexpr (GROUPED && CHAIN && HW == 1) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(wr[sn][hf]), "+v"(scr[su][0]), "+v"(scr[su][1]) : "n"(younger));
+            if constexpr (DW) {
+              (void)wq[0][0][0];
+              // (CHAIN, 32-column waves: the second scale word is fetched and never used; tied in here it stays allocated until it has landed -- see the packed branch below)
+              if constexpr (GROUPED && CHAIN && HW == 1) asm volatile("s_waitcnt vmcnt(%6)" : "+v"(wq[sn][hf][0]), "+v"(wq[sn][hf][1]), "+v"(wq[sn][hf][2]), "+v"(wq[sn][hf][3]), "+v"(scr[su][0]), "+v"(scr[su][1]) : "n"(younger));
+              else if constexpr (GROUPED) asm volatile("s_waitcnt vmcnt(%5)" : "+v"(wq[sn][hf][0]), "+v"(wq[sn][hf][1]), "+v"(wq[sn][hf][2]), "+v"(wq[sn][hf][3]), "+v"(scr[su][hf]) : "n"(younger));
+              else asm volatile("s_waitcnt vmcnt(%4)" : "+v"(wq[sn][hf][0]), "+v"(wq[sn][hf][1]), "+v"(wq[sn][hf][2]), "+v"(wq[sn][hf][3]) : "n"(younger));
+            } else if constexpr (GROUPED && CHAIN && HW == 1) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(wr[sn][hf]), "+v"(scr[su][0]), "+v"(scr[su][1]) : "n"(younger));
             else if constexpr (GROUPED) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(wr[sn][hf]), "+v"(scr[su][hf]) : "n"(younger));
             else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(wr[sn][hf]) : "n"(younger));
             un_setup(__builtin_bit_cast(h2, scr[su][hf]));
+          } else if constexpr (DW) {
+            un_part(std::integral_constant<int, w_ - 1>{}, std::integral_constant<int, hf>{}, aop[nxt], wq[sn][hf]);
           } else if constexpr (w_ < 13) {
             tr_single(std::integral_constant<int, (w_ - 1) / 3>{}, std::integral_constant<int, (w_ - 1) % 3>{}, wr[sn][hf]);
           } else {
-            un_part(std::integral_constant<int, w_ - 13>{}, std::integral_constant<int, hf>{}, aop[nxt]);
+            un_part(std::integral_constant<int, w_ - 13>{}, std::integral_constant<int, hf>{}, aop[nxt], y);
           }
         });
       } else if constexpr (!(QQQ_WIDE_ABLATE & 4)) {
@@ -843,7 +905,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
             tr_piece(std::integral_constant<int, w_>{}, wr[sn][hf]);
           } else {
-            un_part(std::integral_constant<int, w_ - 4>{}, std::integral_constant<int, hf>{}, aop[nxt]);
+            un_part(std::integral_constant<int, w_ - 4>{}, std::integral_constant<int, hf>{}, aop[nxt], y);
           }
         });
       } else if constexpr (k == 0) {
@@ -891,6 +953,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           constexpr int j = wide_w8_refill_index(MT, HW, k);
           if constexpr (j >= 0 && CUR) asm_load_w_cur(wr[(sl + RS - 1) % RS][j], std::integral_constant<int, j>{});
           else if constexpr (j >= 0) asm_load_w(wr[(sl + RS - 1) % RS][j], std::integral_constant<int, j>{}, swo);
+        } else if constexpr (DW) {  // one word per slot: load 4 hf + kq of the step this ring slot holds next
+          constexpr int li = wide_dw_load_index(MT, HW, k);
+          if constexpr (li >= 0) {
+            if constexpr (CUR) asm_load_d(wq[sl][li / 4][li % 4], std::integral_constant<int, li>{}, cr_so, std::true_type{});
+            else asm_load_d(wq[sl][li / 4][li % 4], std::integral_constant<int, li>{}, swo, std::false_type{});
+          }
         } else if constexpr (CUR) {
           if constexpr (wide_refill_slot(HW, k, 0)) asm_load_w_cur(wr[sl][0], std::integral_constant<int, 0>{});
           if constexpr (wide_refill_slot(HW, k, 1)) asm_load_w_cur(wr[sl][HW - 1], std::integral_constant<int, 1>{});
@@ -1068,7 +1136,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     scale_dma(tile_m, tile_n, 0);
     qqq_static_for<LA>([&](auto jc) { dma_stage_so(jc, (unsigned)decltype(jc)::value * 128u); });
 #pragma unroll
-    for (int j = 0; j < RL; ++j) load_w_so(cu_w_so + (unsigned)j * wstep, wr[j]);
+    for (int j = 0; j < RL; ++j) {
+      if constexpr (DW) load_d_step(cu_w_so + (unsigned)j * wstep, wq[j]);
+      else load_w_so(cu_w_so + (unsigned)j * wstep, wr[j]);
+    }
     if constexpr (GROUPED) {
 #pragma unroll
       for (int j = 0; j < P; ++j) load_sc_so(cu_s_so + (unsigned)j * (unsigned)N * 2u, scr[j]);
@@ -1076,7 +1147,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   } else {
     qqq_static_for<LA>([&](auto jc) { dma_stage(jc, decltype(jc)::value); });
 #pragma unroll
-    for (int j = 0; j < RL; ++j) load_w(j, wr[j]);
+    for (int j = 0; j < RL; ++j) {
+      if constexpr (DW) load_d_step((unsigned)(2 * st0 + (j < KS ? j : KS - 1)) * wstep, wq[j]);
+      else load_w(j, wr[j]);
+    }
     if constexpr (GROUPED) {
 #pragma unroll
       for (int j = 0; j < P; ++j) load_sc(j, scr[j]);
@@ -1085,6 +1159,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   qqq_static_for<RL>([&](auto jc) {  // (the asm loads' results are tied to the wait: nothing may read them before it)
     constexpr int j = decltype(jc)::value;
     (void)wr[0];
+    if constexpr (DW) {
+      (void)wq[0][0][0];
+      qqq_static_for<HW>([&](auto hfc) {
+        constexpr int hf = decltype(hfc)::value;
+        (void)wq[0][0][0];
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(wq[j][hf][0]), "+v"(wq[j][hf][1]), "+v"(wq[j][hf][2]), "+v"(wq[j][hf][3]));
+      });
+    } else
     // (HW = 1: ONE operand -- the same variable tied twice gets two registers and a copy in front of the wait)
     if constexpr (W8 && HW == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(wr[j][0]), "+v"(wr[j][1]), "+v"(wr[j][2]), "+v"(wr[j][3]));
     else if constexpr (W8 || HW == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(wr[j][0]), "+v"(wr[j][1]));
@@ -1110,8 +1192,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     qqq_static_for<HW>([&](auto hfc) {  // both halves of step 0 into operand set 0
       constexpr int hf = decltype(hfc)::value;
       un_setup(__builtin_bit_cast(h2, scr[0][hf]));
-      qqq_static_for<4>([&](auto pc) { tr_piece(pc, wr[0][hf]); __builtin_amdgcn_sched_barrier(0); });
-      qqq_static_for<UPARTS>([&](auto pc) { un_part(pc, hfc, aop[0]); });
+      if constexpr (DW) {
+        (void)wq[0][0][0];
+        qqq_static_for<UPARTS>([&](auto pc) { un_part(pc, hfc, aop[0], wq[0][hf]); });
+      } else {
+        qqq_static_for<4>([&](auto pc) { tr_piece(pc, wr[0][hf]); __builtin_amdgcn_sched_barrier(0); });
+        qqq_static_for<UPARTS>([&](auto pc) { un_part(pc, hfc, aop[0], y); });
+      }
     });
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -1212,8 +1299,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // column half 0 in the ragged tail).
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   drain_x();
+  if constexpr (DW) {
+    qqq_static_for<RS * HW>([&](auto jc) {
+      constexpr int j = decltype(jc)::value / HW, hf = decltype(jc)::value % HW;
+      (void)wq[0][0][0];
+      asm volatile("" : : "v"(wq[j][hf][0]), "v"(wq[j][hf][1]), "v"(wq[j][hf][2]), "v"(wq[j][hf][3]));
+    });
+  }
   qqq_static_for<RS>([&](auto jc) {
     (void)wr[0];
+    if constexpr (DW) return;
     asm volatile("" : : "v"(wr[decltype(jc)::value][0]), "v"(wr[decltype(jc)::value][WRN - 1]));
     if constexpr (W8 && HW == 2) asm volatile("" : : "v"(wr[decltype(jc)::value][1]), "v"(wr[decltype(jc)::value][2]));
   });

@@ -286,7 +286,7 @@ def test_dispatch_of_the_baseline_sweep(L):
     for m in (1280, 1536, 2048, 4096, 8192):
         for gs in (-1, 128):
             p = _lib.plan(m, N, K, gs, 16)
-            assert (p["kernel"], p["mt"], p["bm"], p["ksplit"], p["pf"], p["stages"], p["pw"]) == (5, 16, 256, 1, 8 if gs < 0 else 4, 1, 8), (m, gs, p)  # ring depth: r05_wide_ring_depth.txt
+            assert (p["kernel"], p["mt"], p["bm"], p["ksplit"], p["pf"], p["stages"], p["pw"]) == (5, 16, 256, 1, 4, 1, 8), (m, gs, p)  # ring depth 4 since the dword weight loads of round 6 (8 loads per step: 8 steps would pass vmcnt's 63)
     # the persistent tile walk (round 4, glds == 2 in the plan): automatic on 4096 / 5120-deep layers with more than one 256 x 256
     # tile per CU, never at K = 21760 unless forced, never with a K split, and only from 8 stages of K up
     assert _lib.plan(8192, 4096, 4096, -1, 16)["glds"] == 2 and _lib.plan(8192, 11008, 4096, 128, 16)["glds"] == 2
@@ -298,9 +298,10 @@ def test_dispatch_of_the_baseline_sweep(L):
     assert p["ksplit"] == 2 and p["glds"] == 1, p
     assert _lib.plan(8192, 4096, 896, -1, 16, tune=dict(kernel=5, glds=2))["glds"] == 1
     assert _lib.plan(1024, N, K, -1, 16, tune=dict(kernel=5, bm=128))["bm"] == 128 and _lib.plan(1024, N, K, -1, 16, tune=dict(kernel=5, mt=8, bm=128))["bm"] == 256
-    assert _lib.plan(4096, N, K, -1, 16, tune=dict(kernel=5, pf=4))["pf"] == 4 and _lib.plan(4096, N, K, 128, 16, tune=dict(kernel=5, pf=8))["pf"] == 8
+    # (round 6, dword weight loads: the ring is 4 steps deep whatever is asked -- 8 steps x 8 loads would pass vmcnt's 63)
+    assert _lib.plan(4096, N, K, -1, 16, tune=dict(kernel=5, pf=4))["pf"] == 4 and _lib.plan(4096, N, K, 128, 16, tune=dict(kernel=5, pf=8))["pf"] == 4
     # ... and the other shapes keep per-channel 4 / per-group 8 (level in the same A/B)
-    assert _lib.plan(1024, N, K, -1, 16, tune=dict(kernel=5, bm=128))["pf"] == 4 and _lib.plan(1024, N, K, 128, 16, tune=dict(kernel=5, mt=8))["pf"] == 8
+    assert _lib.plan(1024, N, K, -1, 16, tune=dict(kernel=5, bm=128))["pf"] == 4 and _lib.plan(1024, N, K, 128, 16, tune=dict(kernel=5, mt=8))["pf"] == 4
     assert _lib.plan(4096, N, K, -1, 16, tune=dict(kernel=5, stages=3))["stages"] == 1  # LDS-DMA staging: one lead, a full stage
     assert _lib.plan(1024, N, K, -1, 16, tune=dict(kernel=5, mt=8))["mt"] == 8 and _lib.plan(1024, N, K, -1, 16, tune=dict(kernel=5))["mt"] == 16
     # a forced 64-column shape is honoured only where it exists (128-token m-blocks, bm = 256, prefetch depth 3 or 4)

@@ -121,8 +121,9 @@ def test_steady_state_loops(table):
         mix, waits = _loop(name)
         assert mix["v_mfma_i32_16x16x64_i8"] == 512 and mix["s_barrier"] == 4, name
         assert _count(mix, "scratch") == 0 and not any("vmcnt(0)" in w for w in waits), (name, waits)
-        assert mix["ds_read_b128"] == 128 and _count(mix, "ds_write") == 0 and mix["buffer_load_dwordx4"] == (64 if mode == 2 else 48), name
-        assert mix.get("buffer_load_dword", 0) == (8 if grouped else 0), name
+        # (round 6, dword weight loads: per trip 32 LDS-DMAs of 16 bytes + 8 steps x 8 one-word ring loads in the packed modes; expanded weights: 32 + 32 sixteen-byte loads)
+        assert mix["ds_read_b128"] == 128 and _count(mix, "ds_write") == 0 and mix["buffer_load_dwordx4"] == (64 if mode == 2 else 32), name
+        assert mix.get("buffer_load_dword", 0) == (0 if mode == 2 else 64 + (8 if grouped else 0)), name
         assert _count(mix, "v_accvgpr") == 0, name  # accumulators never leave the accumulation registers
         total = sum(v for v in mix.values() if isinstance(v, int))
         assert total <= (4.4 if grouped else 1.75 if mode == 2 else 2.6) * 512, (name, total)
@@ -171,7 +172,7 @@ def test_wide_kernel_hand_counted_waits_replayed_on_the_compiled_code():
                 chunks = 2 * (mt // 4) - (1 if hw == 1 else 0)
                 assert len(at_barrier) == 4 and all(b == at_barrier[0] for b in at_barrier), (name, at_barrier)
                 assert at_barrier[0].count("D") == chunks and set(at_barrier[0]) <= set("rD"), (name, at_barrier)
-                refills = (2 * hw if mode == 2 else hw) * 2 + (2 if grouped else 0)  # per stage
+                refills = (2 * hw if mode == 2 else 4 * hw) * 2 + (2 if grouped else 0)  # per stage (packed modes: four one-word loads per half and step)
                 assert refills - 1 <= at_barrier[0].count("r") <= refills + 2 * hw, (name, at_barrier)
                 # what hipcc's own bookkeeping cannot see around the inline asm (tools/check_vmem.py): M0 is written nowhere but
                 # in front of the LDS-DMA that reads it (hipcc reserves M0 -- a clobber is refused as "reserved register" -- so the
@@ -208,7 +209,7 @@ def test_check_waits_flags_planted_faults():
 
 
 
-CHAIN_KERNELS = [f"qqq_wide_kernel<{g},{mt},4,{rs},{hw},true>" for g, rs in ((0, 4), (1, 8)) for mt, hw in ((16, 2), (8, 2), (16, 1))] + ["qqq_wide_kernel<2,16,4,4,2,true>"]
+CHAIN_KERNELS = [f"qqq_wide_kernel<{g},{mt},4,{rs},{hw},true>" for g, rs in ((0, 4), (1, 4)) for mt, hw in ((16, 2), (8, 2), (16, 1))] + ["qqq_wide_kernel<2,16,4,4,2,true>"]
 
 
 def test_tile_walk_waits_replayed_over_the_whole_control_flow_graph():
@@ -307,7 +308,8 @@ def test_wide_transpose_selects_find_their_vcc_mask():
                 selects += 1
             elif pending and (first == "vcc" or (("_co_" in op or op.startswith("v_div_scale") or op.startswith("v_cmp")) and re.search(r"\bvcc\b", args))):
                 problems.append(("VCC written between a mask and its selects", line))
-        assert not problems and pending == 0 and selects >= 32, (name, problems[:3], pending, selects)
+        # (with QQQ_WIDE_DWORD -- the shipped default -- the weights arrive as words and there is no transpose at all: zero selects; a -DQQQ_WIDE_DWORD=0 build has >= 32)
+        assert not problems and pending == 0 and (selects == 0 or selects >= 32), (name, problems[:3], pending, selects)
 
 
 def test_check_waits_replays_lds_reads_too():

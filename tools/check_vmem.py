@@ -197,6 +197,18 @@ def run(ins, count_stores=False, max_states=200000):
             if op.startswith("s_waitcnt"):
                 continue
             used = operand_regs(rest)
+            if op.startswith("v_pk_") and "op_sel_hi:[0,1]" in rest and "op_sel:" not in rest:
+                # a packed op that BROADCASTS the low half of src0 (op_sel_hi:[0,1]: both results take src0.lo): the encoding names the aligned pair v[n:n+1], the
+                # value of v[n+1] is not used -- hipcc parks a scalar factor next to whatever register is free, e.g. a ring word whose load is still in flight (round 6, dword loads)
+                toks_ = [t.strip() for t in rest.split(",")]
+                if len(toks_) >= 2:
+                    pair = regs(toks_[1].split()[0])
+                    if len(pair) == 2:
+                        others = set()
+                        for j, t_ in enumerate(toks_):
+                            if j != 1 and t_:
+                                others |= regs(t_.split()[0])
+                        used = others | {min(pair)}
             if used:
                 for q in queue:
                     if q and (q & used):
