@@ -345,3 +345,32 @@ def test_check_waits_replays_lds_reads_too():
         assert not [p for p in problems if p.startswith("LDS")], (name, sorted(set(problems))[:3])
         n_asm_waits = sum(1 for l in body if "lgkmcnt" in l)
         assert n_asm_waits >= 8, (name, n_asm_waits)  # (hipcc's own waits while QQQ_WIDE_XWAIT is off: the replay is the same)
+
+
+def test_wide_loop_issue_slots_stay_balanced():
+    """Round 6: a wave that is alone on its SIMD issues an instruction every ~5.2 cycles, and a 16-cycle MFMA hides two of them -- a third in the same slot costs its full issue
+    time and no empty slot gives it back (tools/mfma_issue_bench.hip, profiles/r06_mfma_issue_model.txt).  The per-channel loops are scheduled against that: one-instruction
+    unpack items dealt to the slots by capacity, the weights as one-word loads (no transpose).  tools/slot_load.py reads the result off the COMPILED loop; a source or compiler
+    change that piles instructions into one slot again fails here.  (The per-group loop is over the budget by construction -- 17 VALU per packed word -- and is only held
+    to its instruction count.)"""
+    import code_object
+    import slot_load
+    from qqq_amd import build
+
+    ks = {k["demangled"]: k["name"] for k in code_object.kernels(build.LIB)}
+
+    def slots_of(name):
+        n, body = slot_load.hottest_loop_lines(build.LIB, ks[name])
+        return n, slot_load.slots(body)
+
+    n, sl = slots_of("qqq_wide_kernel<0,16,4,4,2,false>")  # the 256 x 256 tiles of the 4096-token point
+    assert n == 512
+    heavy = [s for s in sl if len(s) > 2]
+    assert len(heavy) <= 1, heavy[:4]  # (the loop's last slot carries the trip counter and the branch)
+    assert sum(len(s) for s in sl) <= 1.2 * n, sum(len(s) for s in sl)
+    alone = [s for s in sl if "ds_read_b128" in s]
+    assert len(alone) == 128 and sum(len(s) > 2 for s in alone) <= 1
+    n, sl = slots_of("qqq_wide_kernel<0,8,4,4,2,false>")  # the 128 x 256 tiles of the 1024-token point
+    assert n == 256 and sum(len(s) for s in sl) <= 1.95 * n and sum(len(s) > 3 for s in sl) <= 2, (sum(len(s) for s in sl), [s for s in sl if len(s) > 3][:4])
+    n, sl = slots_of("qqq_wide_kernel<1,16,4,4,2,false>")  # per-group
+    assert n == 512 and sum(len(s) for s in sl) <= 3.0 * n, sum(len(s) for s in sl)
