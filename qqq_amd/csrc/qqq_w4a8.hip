@@ -32,14 +32,16 @@
 //    through LDS, software-pipelined 16x16x64 MFMAs, in-launch split-K with one slot of C per depositing slice.
 //    Uneven K slices (round 5): the last slice is a few stages longer, arrives last and finds the other deposits complete; the slices of a tile run on one XCD.
 //  * "wide" kernel (from ~320 tokens up, qqq_wide.hip.h): 256 x 256 / 256 x 128 / 128 x 256 tiles, four waves with 512 registers each, every
-//    instruction of the loop placed by hand around in-place MFMAs, activations by LDS-DMA, persistent tile walk on short-K layers.
+//    instruction of the loop placed by hand around in-place MFMAs -- since round 6 against the measured issue model of a wave alone on its SIMD: one-instruction
+//    items dealt to the issue slots by capacity, weights as one-word loads (no transpose), running load cursors --, activations by LDS-DMA, persistent tile walk on
+//    short-K layers; opt-in expanded int8 weights (qqq_expand_int8) for the per-group mode.
 //  * "tiled" kernel (round 1; tune.kernel = 2 only since round 5 -- the fuzzers' independent reference, the fallback beyond 4 GB of packed
 //    weights): v_mfma_i32_32x32x32_i8; BMx256 tiles, BK = 128, activations and RAW packed weights staged in LDS by LDS-DMA (XOR-swizzled
 //    16-byte chunks so that every fragment read is bank-conflict free), continuous fragment pipeline, XCD-aware tile order,
 //    in-launch split-K through tile-sized slots of C.
 //  Host side: make_plan() picks family / tile / split from measured cost models whose rates are all GENERATED (qqq_rates.h, tools/fit_rates.py: the panel and wide
-//  kernels' tables, the small-m forms of the column / stream kernels, the 64-token m-block form) -- only the stream kernel's many-m-block branch on large layers is
-//  still hand-fitted -- and held against the committed measurements by tools/cost_model_report.py; the C-ABI entry points are at the end of the file.
+//  kernels' tables, the small-m forms of the column / stream kernels, the 64-token m-block form) -- the stream kernel's hand-fitted many-m-block branch on large layers left the automatic path in round 6 --
+//  and held against the committed measurements by tools/cost_model_report.py; the C-ABI entry points are at the end of the file.
 //
 // The accumulators are the reference's: per-channel weights enter as 16*w4 (high nibble of each
 // byte) and pack() has pre-divided s_channel by 16; per-group weights are re-quantised to int8

@@ -16,7 +16,10 @@
 //     128-row m-blocks' 4 rounds (741 MB per launch at M=4096 against 1137, profiles/r03_pmc_wide_m4096.txt);
 //   * no k-group meet at the end, one barrier per 128-k stage between FOUR waves.
 // The price: nothing hides a wave's own stalls (no partner on the SIMD) and an in-order wave issues one instruction per ~4
-// cycles, i.e. a 16-cycle MFMA leaves room for at most three others.  So:
+// cycles, i.e. a 16-cycle MFMA leaves room for at most three others.  (Round 6 MEASURED it -- tools/mfma_issue_bench.hip: ~5.2 cycles
+// per instruction of any kind, TWO free behind an MFMA, nothing given back by an empty slot -- and rebuilt the loop against that: see
+// QQQ_WIDE_BALANCE / QQQ_WIDE_CURSORS / QQQ_WIDE_DWORD below; with DWORD the weights arrive as one-word loads and the quad transpose
+// described next is gone from the shipped loop.)  So:
 //   * the accumulators are updated IN PLACE by inline-asm MFMAs ("+a"): with the builtin hipcc selects the untied form in the
 //     accumulation registers and, all 256 of them live, bounces accumulators through VGPRs and scratch;
 //   * the issue order is pinned slot by slot (sched_barrier): slot k of a 64-k step = the MFMA of (m-tile k / 4, column set
