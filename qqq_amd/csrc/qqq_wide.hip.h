@@ -236,15 +236,28 @@ __host__ __device__ constexpr int wide_xw_count_at(int mode, int mt, int hw, int
     if (wide_xw_abs(mode, mt, hw, j) >= 0 && wide_xw_abs(mode, mt, hw, j) % (2 * hw * mt) == k && (n < 0 || wide_xw_count(mode, mt, hw, j) < n)) n = wide_xw_count(mode, mt, hw, j);
   return n;
 }
-__host__ __device__ constexpr int wide_bal_cap(int mode, int mt, int hw, int t, int k, bool cursors) {
+// QQQ_WIDE_CHAINPREP (round 6, tile walk): the offsets of a stage's loads are prepared one stage AHEAD, in plain slots of the previous stage's second step (two register
+// sets, picked by the stage's compile-time parity), instead of at the stage's start -- where copies, cursor adds and the tile-end test stood in ONE slot: 13 instructions
+// between two MFMAs, once per stage (tools/slot_load.py).  What is left at the boundary: the countdown, the seam test, the "last P stages" test.
+// Measured (profiles/r06c_tile_walk_prepared_offsets.txt): level.  The walk kernels are out of SGPRs (106, two spilled), hipcc keeps the loop-carried set in VGPRs and the
+// v_readfirstlane read-backs -- which must stand at the stage head, five wait states ahead of the first load -- cost what the boundary bookkeeping did.  Parity-clean, off.
+#ifndef QQQ_WIDE_CHAINPREP
+#define QQQ_WIDE_CHAINPREP 0
+#endif
+__host__ __device__ constexpr int wide_prep_slot(int mode, int mt, int hw, int j) { return wide_plain_after(mode, mt, hw, -1, j); }  // the j-th plain slot of a step (j = 0 .. 3)
+__host__ __device__ constexpr int wide_bal_cap(int mode, int mt, int hw, int t, int k, int cursors) {  // cursors: 0 none, 1 the plain kernel's running cursors, 2 the tile walk's prepared offsets
   if (!wide_plain_slot(mode, mt, hw, k)) return wide_m0_slot(mt, hw, k) && !wide_frag_slot(hw, k) && !wide_dma_slot(mt, hw, k) ? 1 : 0;
   int c = 2;
   if (t == 1 && k == wide_barrier_slot(mode, mt, hw)) c -= 2;
   if (QQQ_WIDE_XWAIT != 0 && wide_xw_count_at(mode, mt, hw, k) >= 0) c -= 1;
-  if (cursors) {
+  if (cursors == 1) {
     if (k == wide_ring_inc_slot(mode, mt, hw)) c -= 1;
     if (t == 0 && k == wide_dma_inc_slot(mode, mt, hw)) c -= 1;
     if (mode == 1 && t == 1 && k == wide_scale_inc_slot(mode, mt, hw)) c -= 1;
+  }
+  if (cursors == 2 && t == 1) {
+    if (k == wide_prep_slot(mode, mt, hw, 0) || k == wide_prep_slot(mode, mt, hw, 1) || (mode == 1 && k == wide_prep_slot(mode, mt, hw, 3))) c -= 2;
+    if (k == wide_prep_slot(mode, mt, hw, 2)) c -= 1;
   }
   return c < 0 ? 0 : c;
 }
@@ -253,7 +266,7 @@ __host__ __device__ constexpr int wide_bal_items(int mode) { return wide_bal_hea
 __host__ __device__ constexpr int wide_bal_cost(int mode, int w) { return w < wide_bal_head(mode) ? 1 : (mode == 1 ? 2 : 1); }  // instructions of item w of a half
 // number of items (of the hw * wide_bal_items(mode) of a step, in order) dealt to slots [0, k): item i goes to the first slot whose cumulative share of the capacity
 // reaches the item's cumulative share of the instructions
-__host__ __device__ constexpr int wide_bal_before(int mode, int mt, int hw, int t, int k, bool cursors) {
+__host__ __device__ constexpr int wide_bal_before(int mode, int mt, int hw, int t, int k, int cursors) {
   const int nslot = 2 * hw * mt, per = wide_bal_items(mode), ni = hw * per;
   int ct = 0, cb = 0, tc = 0;
   for (int j = 0; j < nslot; ++j) ct += wide_bal_cap(mode, mt, hw, t, j, cursors);
@@ -269,7 +282,7 @@ __host__ __device__ constexpr int wide_bal_before(int mode, int mt, int hw, int 
 }
 
 // (the dealing worked out ONCE per shape and step parity: clang's constant evaluator walks the loops above per call, and the slot bodies ask 2 x 64 x 8 times per instantiation)
-template <int MODE, int MT, int HW, int T, bool CURSORS>
+template <int MODE, int MT, int HW, int T, int CURSORS>
 struct WideBalTable {
   struct Tab {
     int before[2 * HW * MT + 1];
@@ -299,8 +312,8 @@ struct WideBalTable {
   static constexpr Tab tab = make();
 };
 
-static_assert(WideBalTable<0, 16, 2, 0, true>::tab.before[17] == wide_bal_before(0, 16, 2, 0, 17, true) && WideBalTable<0, 16, 2, 1, true>::tab.before[63] == wide_bal_before(0, 16, 2, 1, 63, true) &&
-                  WideBalTable<1, 8, 2, 1, false>::tab.before[9] == wide_bal_before(1, 8, 2, 1, 9, false) && WideBalTable<1, 16, 1, 0, true>::tab.before[30] == wide_bal_before(1, 16, 1, 0, 30, true),
+static_assert(WideBalTable<0, 16, 2, 0, 1>::tab.before[17] == wide_bal_before(0, 16, 2, 0, 17, 1) && WideBalTable<0, 16, 2, 1, 1>::tab.before[63] == wide_bal_before(0, 16, 2, 1, 63, 1) &&
+                  WideBalTable<1, 8, 2, 1, 0>::tab.before[9] == wide_bal_before(1, 8, 2, 1, 9, 0) && WideBalTable<1, 16, 1, 0, 2>::tab.before[30] == wide_bal_before(1, 16, 1, 0, 30, 2),
               "the table is the function");
 
 // LDS-DMA staging: the activations go global -> LDS directly (buffer_load_dwordx4 ... lds, one
@@ -816,6 +829,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // the unpack that ran during step s - 1) with step s + RS, and issues the LDS-DMA of one 16-byte chunk per lane of activation
   // stage i + LA every 16 slots.  The waits are hand-counted from the static schedule (wide_loads_between).
   unsigned st_xso = 0, st_swo[2] = {0, 0}, st_sco = 0;  // CHAIN: the scalar offsets of the current stage's loads (do_stage_chain)
+  constexpr bool PREP = CHAIN && QQQ_WIDE_CHAINPREP != 0 && QQQ_WIDE_BALANCE != 0;
+  unsigned pz_xso[2] = {0, 0}, pz_swo[2][2] = {{0, 0}, {0, 0}}, pz_sco[2] = {0, 0};  // PREP: two sets, [stage parity]: the stage reads one while the next one's is written
+  // one set from the running cursors (common case: the next stage's loads stay inside the tile), cursors advanced; in four pieces for four slots
+  auto prep_piece = [&](auto setc, auto jc) __attribute__((always_inline)) {
+    constexpr int ns = decltype(setc)::value, j = decltype(jc)::value;
+    (void)pz_xso[0], (void)pz_swo[0][0], (void)pz_sco[0], (void)cx_so, (void)cr_so, (void)cc_so;
+    // (sgpr(): a no-op on a value that is scalar already; it only tells hipcc so where it cannot see it -- the cursors themselves are not pinned: an "s" operand
+    // of a value hipcc believes to be in a VGPR does not compile)
+    if constexpr (j == 0) {
+      pz_xso[ns] = sgpr(cx_so);
+      cx_so += 128u;
+      asm volatile("" : "+s"(pz_xso[ns]));
+    } else if constexpr (j == 1) {
+      pz_swo[ns][0] = sgpr(cr_so);
+      pz_swo[ns][1] = sgpr(cr_so + wstep);
+      asm volatile("" : "+s"(pz_swo[ns][0]), "+s"(pz_swo[ns][1]));
+    } else if constexpr (j == 2) {
+      cr_so += 2u * wstep;
+    } else if constexpr (GROUPED) {
+      pz_sco[ns] = sgpr(cc_so);
+      cc_so += (unsigned)N * 2u;
+      asm volatile("" : "+s"(pz_sco[ns]));
+    }
+  };
+  auto prep_set = [&](auto setc) __attribute__((always_inline)) { qqq_static_for<4>([&](auto jc) { prep_piece(setc, jc); }); };
   auto step = [&](const int i, auto uc, auto tc) __attribute__((always_inline)) {
     constexpr int t = decltype(tc)::value, u = decltype(uc)::value;
     constexpr int cur = t, nxt = 1 - t;         // 2 P steps per trip: the step's parity is its t
@@ -824,7 +862,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr int su = GROUPED ? ((t == 1) ? (u + 1) % P : u) : 0;  // scales of the NEXT step's stage
     const int st_x = i + LA < NST ? i + LA : NST - 1;
     // (CHAIN: i is not used, do_stage_chain says where the loads read; plain kernel with cursors: the running offsets themselves, advanced in slots of their own below)
-    const unsigned cswo = st_swo[t], csco = st_sco;
+    const unsigned cswo = PREP ? pz_swo[u & 1][t] : st_swo[t], csco = PREP ? pz_sco[u & 1] : st_sco;
     constexpr int BSLOT = wide_barrier_slot(MODE, MT, HW);
     static_assert(!CUR || (wide_ring_inc_slot(MODE, MT, HW) > 0 && (!GROUPED || wide_scale_inc_slot(MODE, MT, HW) > wide_scale_slot(HW))), "every cursor has a slot behind its last use");
     constexpr int NI = HW * (4 + UPARTS);
@@ -855,7 +893,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       } else if constexpr (!(QQQ_WIDE_ABLATE & 4) && QQQ_WIDE_BALANCE != 0) {
         // one-instruction items dealt by slot capacity (see QQQ_WIDE_BALANCE above)
         constexpr int PER = wide_bal_items(MODE);
-        constexpr int lo = WideBalTable<MODE, MT, HW, t, CUR>::tab.before[k], hi = WideBalTable<MODE, MT, HW, t, CUR>::tab.before[k + 1];
+        constexpr int FIX = CUR ? 1 : PREP ? 2 : 0;
+        constexpr int lo = WideBalTable<MODE, MT, HW, t, FIX>::tab.before[k], hi = WideBalTable<MODE, MT, HW, t, FIX>::tab.before[k + 1];
         qqq_static_for<(hi - lo)>([&](auto jc) {
           constexpr int it = lo + decltype(jc)::value;
           constexpr int hf = it / PER, w_ = it % PER;
@@ -934,6 +973,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         else if constexpr (CHAIN) load_sc_so(csco, scr[u]);
         else load_sc(i + P, scr[u]);
       }
+      if constexpr (PREP && t == 1) {  // the NEXT stage's offsets (the other set), piece by piece (wide_bal_cap leaves room for them)
+        qqq_static_for<4>([&](auto jc) {
+          if constexpr (k == wide_prep_slot(MODE, MT, HW, decltype(jc)::value)) prep_piece(std::integral_constant<int, (u + 1) & 1>{}, jc);
+        });
+      }
       if constexpr (CUR) {  // the cursors' scalar adds, one per slot (wide_bal_cap leaves room for them)
         (void)cx_so, (void)cr_so, (void)cc_so;
         if constexpr (k == wide_ring_inc_slot(MODE, MT, HW)) {
@@ -975,7 +1019,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         dma_m0(std::integral_constant<int, (u + LA) % P>{}, std::integral_constant<int, (XPT / 2) * t + k / DP>{});
       if constexpr (wide_dma_slot(MT, HW, k) && !(QQQ_WIDE_ABLATE & 2)) {
         if constexpr (CUR) dma_go_cur(std::integral_constant<int, (XPT / 2) * t + k / DP>{});
-        else dma_go(std::integral_constant<int, (XPT / 2) * t + k / DP>{}, CHAIN ? st_xso : (unsigned)(st0 + st_x) * 128u);
+        else dma_go(std::integral_constant<int, (XPT / 2) * t + k / DP>{}, PREP ? pz_xso[u & 1] : CHAIN ? st_xso : (unsigned)(st0 + st_x) * 128u);
       }
       if constexpr (QQQ_WIDE_BALANCE != 0 && QQQ_WIDE_STAGGER == 0 && t == 1 && k == BSLOT) {
         // the stage's end, in a slot of its own (BALANCE): the LDS-DMA of stage i + 2, issued during stage i + 3 - P, is done when at most the loads issued since
@@ -1230,6 +1274,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     int left = NST;
     auto do_stage_chain = [&](auto uc) __attribute__((always_inline)) {
       const unsigned sstep = (unsigned)N * 2u;
+      constexpr int sset = decltype(uc)::value & 1;
+      if constexpr (PREP) {
+        if (__builtin_expect(left <= P, 0)) {  // the last P stages: the prepared set is overwritten -- the loads cross into the next tile one kind after the other
+          const int done = NST - left;
+          const bool xn = left <= LA;
+          pz_xso[sset] = sgpr(xn ? (unsigned)(LA - left) * 128u : (unsigned)(done + LA) * 128u);
+          xdesc[0] = sgpr(xn ? nx_a_lo : cu_a_lo), xdesc[1] = sgpr(xn ? nx_a_hi : cu_a_hi), xdesc[2] = sgpr(xn ? nx_a_rec : cu_a_rec);
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const int sn_ = 2 * done + t + RL;
+            pz_swo[sset][t] = sgpr(sn_ < KS ? cu_w_so + (unsigned)sn_ * wstep : nx_w_so + (unsigned)(sn_ - KS) * wstep);
+          }
+          pz_sco[sset] = sgpr(nx_s_so + (unsigned)(P - left) * sstep);
+          asm volatile("s_nop 4" : "+s"(pz_xso[sset]), "+s"(pz_swo[sset][0]), "+s"(pz_swo[sset][1]), "+s"(pz_sco[sset]), "+s"(xdesc));  // (settled here: see below)
+        }
+        // in SGPRs HERE, three MFMAs ahead of the first load that reads one: a set that reaches its stage through a loop-carried copy (hipcc keeps those in
+        // VGPRs when SGPRs run short) would otherwise be read back by a v_readfirstlane right in front of the load, inside the 5 wait states (see below)
+        pz_xso[sset] = sgpr(pz_xso[sset]), pz_swo[sset][0] = sgpr(pz_swo[sset][0]), pz_swo[sset][1] = sgpr(pz_swo[sset][1]), pz_sco[sset] = sgpr(pz_sco[sset]);
+        asm volatile("" : "+s"(pz_xso[sset]), "+s"(pz_swo[sset][0]), "+s"(pz_swo[sset][1]), "+s"(pz_sco[sset]));
+      } else
       if (__builtin_expect(left > P, 1)) {  // every load of this stage stays inside the tile
         // (sgpr(): a no-op on a value that is scalar already; it only tells hipcc so where it cannot see it)
         st_xso = sgpr(cx_so), st_swo[0] = sgpr(cr_so), st_swo[1] = sgpr(cr_so + wstep), st_sco = sgpr(cc_so);
@@ -1259,6 +1323,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       asm volatile("s_waitcnt vmcnt(%0)" : : "n"(since) : "memory");
       if constexpr (QQQ_WIDE_STAGGER == 0) __syncthreads();
     };
+    if constexpr (PREP) prep_set(std::integral_constant<int, 0>{});  // the first stage's set (the cursors stand at the run's stage 0)
     bool more = true;
     // (the expectations put the seams and the tile-end offset code out of line: the common stage falls through from one MFMA
     // run into the next -- a taken branch is a fetch bubble nothing hides when the wave is alone on its SIMD)
@@ -1267,6 +1332,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     do_stage_chain(std::integral_constant<int, U>{});         \
     if (__builtin_expect(--left == 0, 0)) {                   \
       seam();                                                 \
+      if constexpr (PREP) prep_set(std::integral_constant<int, (U + 1) & 1>{}); /* the next tile's stage 0, from the cursors the seam restarted */ \
       left = NST;                                             \
       if (ch_pos == ch_tiles) {                               \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      \
